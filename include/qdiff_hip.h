@@ -1,0 +1,196 @@
+/*
+ * qdiff_hip.h — C ABI of libqdiff_hip.so, the MI355X (gfx950) integer engine that sits under
+ * the q-diffusion `qdiff` Python API.
+ *
+ * The reference (Xiuyu-Li/q-diffusion) has no FFI layer: its hot path is a chain of ATen calls
+ * issued from qdiff/quant_layer.py, qdiff/adaptive_rounding.py and qdiff/quant_block.py.  Each
+ * entry point below replaces one of those implicit op sequences and cites
+ * the reference lines whose arithmetic it reproduces.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, ints, POD structs; no torch types.  `stream` is a hipStream_t
+ *     passed as void*.  All kernels are enqueued on `stream` and return without synchronising
+ *     (safe inside hipGraph capture: no allocation, no sync, no host read-back).
+ *   - every function returns 0 on success, non-zero on error; qd_last_error() returns a
+ *     thread-local message.  Nothing falls back to the host: a bad argument is an error.
+ *   - the library is stateless (no global mutable state besides the thread-local error text).
+ *   - quantisation parameters that the reference keeps as tensors / nn.Parameters (delta,
+ *     zero_point) are read by the kernels from DEVICE memory, so the host never has to .item() them.
+ *
+ * Integer conventions
+ *   activation code  q  = clamp(rint(x/delta) + zp, qmin, qmax)        (quant_layer.py:82-87)
+ *   stored byte      a' = q - off,  off = 128 for unsigned 8-bit grids, 0 for signed grids
+ *   "true zero"      z' = zp - off  (the byte that dequantises to 0.0; used for conv padding)
+ *   weight code      W  = clamp(floor(w/dw)+(alpha>=0)+zw, 0, 2^b-1)   (adaptive_rounding.py:49-59)
+ *   stored weight    w' = W - zw (int4 path, unpacked in-kernel) or W - 128 (int8 path, with the
+ *                    per-channel remainder zw-128 folded into the epilogue through row sums).
+ */
+#ifndef QDIFF_HIP_H
+#define QDIFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QD_ABI_VERSION 1
+
+/* element types of floating-point tensors crossing the ABI */
+enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
+
+int         qd_abi_version(void);
+const char* qd_last_error(void);
+/* 1 if a gfx950 device is visible to this process, else 0 (never throws). */
+int         qd_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  activation quantiser.   Replaces UniformAffineQuantizer.forward on an *input activation*
+ *     (qdiff/quant_layer.py:66-89) and the two-quantizer + torch.cat split path of
+ *     QuantModule.forward (quant_layer.py:256-264).
+ *
+ *     x is a logical [B][C][S] tensor addressed by element strides (sb, sc, ss): NCHW-contiguous
+ *     is (C*S, S, 1), channels_last / token-major is (S*C, 1, C).  Channels [c0, c0+clen) are
+ *     quantised with qparams = {delta, zero_point} (two floats in device memory) and written as
+ *     int8 to out[(b*S+s)*ldo + oc0 + (c-c0)]; channels up to clen_pad are filled with the
+ *     "true zero" byte so that padded K lanes contribute nothing.
+ *     qmin/qmax/off describe the integer grid (see header comment).
+ * ------------------------------------------------------------------------------------------ */
+int qd_quantize_act(const void* x, int x_dtype, int64_t B, int64_t C, int64_t S,
+                    int64_t sb, int64_t sc, int64_t ss,
+                    int c0, int clen, int clen_pad,
+                    const float* qparams, int qmin, int qmax, int off,
+                    int8_t* out, int64_t ldo, int oc0, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  weight packer.   Replaces the per-forward weight fake-quant of AdaRoundQuantizer.forward
+ *     (qdiff/adaptive_rounding.py:49-61, branch learned_hard_sigmoid / soft_targets=False) and of
+ *     UniformAffineQuantizer.forward on weights (quant_layer.py:82-88; round-to-nearest) by a
+ *     one-time pack.  w is the fp32 weight viewed as [Cout][Cin_total][taps] (PyTorch OIHW with
+ *     HW flattened); the channel slice [c0, c0+clen) is quantised with per-out-channel delta/zp
+ *     (fp32 [Cout]) and, when alpha != NULL (same layout as the slice, [Cout][clen][taps]),
+ *     AdaRound hard rounding.  Output row n, tap t: bytes [kofs, kofs+clen_pad) of
+ *     wq[(n*taps+t)*ldk ...] hold W-128 (bits==8 → mode 8) or W-zw (mode 0: direct s8) ;
+ *     mode 4 packs W as nibbles (two per byte, layout in DESIGN.md §4.2) at byte offset kofs/2.
+ *     wsum[n] += sum of the stored s8 values (mode 8/0) or of (W-zw) (mode 4) over the slice.
+ *     codes (optional, may be NULL): int32 [Cout][clen][taps] raw W codes for tests.
+ * ------------------------------------------------------------------------------------------ */
+int qd_pack_weights(const float* w, const float* alpha, const float* delta, const float* zp,
+                    int Cout, int Cin_total, int taps, int c0, int clen, int clen_pad,
+                    int n_levels, int mode, uint8_t* wq, int64_t ldk, int kofs,
+                    int32_t* wsum, int32_t* codes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3/K4  integer convolution / GEMM.   Replaces fwd_func(input, weight, bias, **fwd_kwargs) of
+ *     QuantModule.forward (qdiff/quant_layer.py:276 → F.conv2d / F.conv1d(k=1) / F.linear on
+ *     dequantised fp32 operands) by an implicit GEMM on the integer codes:
+ *        M = B*Ho*Wo, N = Cout, K = taps * sum(seg.clen)
+ *        out[m][n] = sum_seg scale_s[n] * I_s[m][n] + bias[n] + rowbias[b(m)][n] + residual[m][n]
+ *        I_s = acc_s - zc_s[n] - zw_s[n] * (Asum_s[m] - kz_s)
+ *     acc_s is the exact int32 MFMA accumulator of stored bytes; zc/zw/kz restore the zero points
+ *     (DESIGN.md §3).  Two segments implement the split-shortcut of quant_layer.py:257-269.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t        c0;       /* first channel of the segment inside an x row (bytes)              */
+    int32_t        clen;     /* channel count, multiple of 16 (padded)                            */
+    int32_t        kofs;     /* offset of the segment inside a weight tap row (elements)          */
+    int32_t        _pad;
+    const int8_t*  wzp;      /* [Cout] weight zero point subtracted at nibble unpack (wbits=4), or NULL */
+    const float*   scale;    /* [Cout]  delta_x * delta_w[n]                                       */
+    const int32_t* zc;       /* [Cout]  z' * Wsum[n]            or NULL (symmetric activations)    */
+    const int32_t* zw;       /* [Cout]  zw[n]-128               or NULL (int4 / direct-s8 weights) */
+    const int32_t* zfill;    /* [2] {z', K_seg*z'} device scalars or NULL (= 0)                    */
+} qd_conv_seg;
+
+typedef struct {
+    const int8_t*  x;        /* [B][H][W][ldx] stored activation bytes                            */
+    const uint8_t* w;        /* [Cout][taps][ldk] s8, or nibbles [Cout][taps][ldk/2] when wbits=4  */
+    void*          out;      /* [M][ldo]                                                           */
+    const float*   bias;     /* [Cout] or NULL                                                     */
+    const float*   rowbias;  /* [B][ld_rowbias] per-sample per-channel add (timestep emb) or NULL  */
+    const void*    residual; /* [M][ldr] same dtype as out, or NULL                                */
+    int64_t        ldx, ldk, ldo, ldr, ld_rowbias;
+    int32_t        B, H, W, Ho, Wo, Cout;
+    int32_t        kh, kw, stride, pad_t, pad_l;
+    int32_t        wbits;    /* 8 or 4                                                             */
+    int32_t        out_dtype;/* QD_F32 / QD_F16                                                    */
+    int32_t        nseg;     /* 1 or 2                                                             */
+    qd_conv_seg    seg[2];
+} qd_conv_desc;
+
+int qd_conv2d_i8(const qd_conv_desc* d, void* stream);
+
+/* Test hook: same contraction, but writes the raw int32 I_s[m][n] of segment 0 (after zero-point
+ * restoration) to iout[M][Cout].  Used for the bit-exact accumulator tests (oracle tier T0). */
+int qd_conv2d_i8_acc(const qd_conv_desc* d, int32_t* iout, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K5  GroupNorm -> SiLU -> quantise.   Replaces nn.GroupNorm(32,C) / GroupNorm32 → x*sigmoid(x)
+ *     → act_quantizer of the following QuantModule (ddim/models/diffusion.py:121-123,127-130;
+ *     ldm/modules/diffusionmodules/openaimodel.py:201-205,225-232, util.py:214-216;
+ *     qdiff/quant_layer.py:82-88).  x is channels-last [B][S][C] (ldx = row stride, elements).
+ *     ws: workspace of qd_groupnorm_ws_bytes(B,C,S) bytes.  apply_silu=0 gives GroupNorm→quant
+ *     (attention blocks: openaimodel.py:324, attention.py:280-281, ddim diffusion.py:175).
+ *     Two-quantizer outputs are not needed here (split only affects 1x1 skips).
+ *     If yout != NULL the fp32 normalised (+SiLU) tensor is also written ([B*S][ldy]).
+ * ------------------------------------------------------------------------------------------ */
+int64_t qd_groupnorm_ws_bytes(int64_t B, int64_t C, int64_t S);
+int qd_groupnorm_silu_quant(const void* x, int x_dtype, int64_t B, int64_t S, int C, int64_t ldx,
+                            int groups, float eps, const float* gamma, const float* beta,
+                            int apply_silu,
+                            const float* qparams, int qmin, int qmax, int off,
+                            int8_t* out, int64_t ldo, float* yout, int64_t ldy,
+                            void* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K9a LayerNorm -> quantise (up to 3 consumers).  Replaces nn.LayerNorm (attention.py:229-231)
+ *     followed by the act_quantizers of to_q/to_k/to_v (or the GEGLU proj) QuantModules.
+ *     x: [M][C] rows (ldx elements).  nout in 1..3; out[i] int8 [M][ldo].
+ * ------------------------------------------------------------------------------------------ */
+int qd_layernorm_quant(const void* x, int x_dtype, int64_t M, int C, int64_t ldx, float eps,
+                       const float* gamma, const float* beta, int nout,
+                       const float* const* qparams, const int* qmin, const int* qmax, const int* off,
+                       int8_t* const* out, int64_t ldo, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K9b GEGLU -> quantise.  Replaces `x, gate = proj(x).chunk(2,-1); x*F.gelu(gate)`
+ *     (ldm/modules/attention.py:42-44) + the act_quantizer of the FF output Linear.
+ *     h: [M][2F] (ldh), out int8 [M][ldo].
+ * ------------------------------------------------------------------------------------------ */
+int qd_geglu_quant(const void* h, int h_dtype, int64_t M, int F, int64_t ldh,
+                   const float* qparams, int qmin, int qmax, int off,
+                   int8_t* out, int64_t ldo, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K7/K8 quantised attention.   Replaces the q/k/v/probability quantisers + the two einsum/bmm
+ *     contractions + fp32 softmax of cross_attn_forward (qdiff/quant_block.py:190-221),
+ *     QuantQKMatMul/QuantSMVMatMul (:123-134,152-157 with openaimodel.py:384-406) and
+ *     QuantAttnBlock.forward (:354-386).
+ *
+ *     Step 1  qd_quantize_heads: x logical [B][T][H][d] (element strides sb, st, sh, sd),
+ *             y = x*prescale quantised like K1 and written head-major:
+ *               transpose=0:  out[(b*H+h)][Tpad][dpad]  (+ rsum[(b*H+h)][Tpad] = row sums)
+ *               transpose=1:  out[(b*H+h)][dpad][Tpad] with the key index permuted inside each
+ *                             32-key tile   (+ rsum[(b*H+h)][dpad] = column sums)
+ *             Padding rows/cols are zero bytes; buffers must be Tpad = ceil32(T), dpad = ceil32(d).
+ *     Step 2  qd_attn_i8: for every (b,h): S = (q-zq)(k-zk)^T * cs ; P = softmax_j(S);
+ *             u = clamp(rint(P/dw)+zpw, wmin, wmax);  O = sum_j (u-zpw)(v-zv) * dw*dv.
+ *             O is written as out[b][t][h*d + c] (merged heads, ldo = row stride, fp32).
+ *     prm: device float[16] = {cs (=dq*dk*scale), zq', zk', dw, zpw, dv_dw (=dw*dv), zv', ...}
+ *          (layout in DESIGN.md §4.4); built once on device by the host, never read back.
+ * ------------------------------------------------------------------------------------------ */
+int qd_quantize_heads(const void* x, int x_dtype, int B, int T, int H, int d,
+                      int64_t sb, int64_t st, int64_t sh, int64_t sd, float prescale,
+                      const float* qparams, int qmin, int qmax, int off, int transpose,
+                      int8_t* out, int32_t* rsum, int Tpad, int dpad, void* stream);
+
+int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt,
+               const int32_t* qsum, const int32_t* ksum, const int32_t* vsum,
+               int BH, int H, int T, int S, int d, int Tpad, int Spad, int dpad,
+               const float* prm, int wbits, int wmin, int wmax,
+               float* out, int64_t ldo, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QDIFF_HIP_H */

@@ -1,0 +1,54 @@
+// common.h — shared helpers for libqdiff_hip.so (gfx950 only; no portability shims).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include "../../include/qdiff_hip.h"
+
+typedef int   v4i  __attribute__((ext_vector_type(4)));
+typedef int   v16i __attribute__((ext_vector_type(16)));
+typedef float v4f  __attribute__((ext_vector_type(4)));
+
+void qd_set_error(const char* fmt, ...);
+
+#define QD_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            qd_set_error(__VA_ARGS__);        \
+            return 1;                         \
+        }                                     \
+    } while (0)
+
+#define QD_LAUNCH_CHECK(name)                                                       \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            qd_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));    \
+            return 2;                                                               \
+        }                                                                           \
+    } while (0)
+
+static inline bool qd_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (observed; used for L2 locality only).
+// Bijective remap so that consecutive logical ids share an XCD (cdna_hip_programming.md §5 T1).
+__device__ __forceinline__ int qd_xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    int xcd = bid % nx, idx = bid / nx;
+    int q = nwg / nx, r = nwg % nx;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// load a float-like element and widen
+template <typename T> __device__ __forceinline__ float qd_ld(const T* p);
+template <> __device__ __forceinline__ float qd_ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float qd_ld<__half>(const __half* p) { return __half2float(*p); }
+
+// quantise one value to its stored byte: clamp(rint(x/delta)+zp, qmin, qmax) - off
+// (true IEEE division + round-half-even, as torch.round(x / delta): quant_layer.py:82)
+__device__ __forceinline__ int qd_code(float x, float delta, float zp, float qmin, float qmax) {
+    float r = rintf(x / delta) + zp;
+    r = fminf(fmaxf(r, qmin), qmax);
+    return (int)r;
+}

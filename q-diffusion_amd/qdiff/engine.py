@@ -1,0 +1,317 @@
+"""Host side of the integer engine: freezes quantiser state into packed weights and per-channel
+epilogue constants ("plans"), and issues the HIP kernels of libqdiff_hip.so through qdiff.hip.
+
+Everything a kernel needs at run time lives in device tensors built here with a handful of torch
+ops when quantiser state changes; the steady-state forward never reads a device value back to the
+host, so a whole UNet evaluation can be captured in a HIP graph (qdiff/graph.py).
+
+Integer conventions: DESIGN.md §3 (stored byte a' = code - off, "true zero" z' = zp - off, ...).
+"""
+import math
+
+import torch
+
+from . import hip
+from .hip import Grid, pad16, pad32
+
+
+# ------------------------------------------------------------------------------------------------
+# quantiser views
+# ------------------------------------------------------------------------------------------------
+def act_grid(n_bits, sym):
+    """Integer grid of an activation quantiser (reference quant_layer.py:54,84-87)."""
+    if n_bits > 8:
+        raise hip.HipEngineError(f"{n_bits}-bit activations do not fit the int8 MFMA operand")
+    if sym:
+        nl = 2 ** (n_bits - 1) - 1
+        return Grid(-nl - 1, nl, 0)
+    return Grid(0, 2 ** n_bits - 1, 128 if n_bits == 8 else 0)
+
+
+def _scalar_tensor(v, device):
+    if torch.is_tensor(v):
+        return v.detach().to(device=device, dtype=torch.float32).reshape(())
+    return torch.tensor(float(v), dtype=torch.float32, device=device)
+
+
+def qparams_of(quantizer, device):
+    """[delta, zero_point] as a 2-float device tensor (no host sync)."""
+    d = _scalar_tensor(quantizer.delta, device)
+    z = _scalar_tensor(quantizer.zero_point, device)
+    return torch.stack([d, z])
+
+
+def quantizer_key(q):
+    """Cheap identity of a quantiser's state: changes whenever delta / zero_point / alpha are
+    re-assigned or modified in place (resume_cali_model does both: reference utils.py:397-457)."""
+    if q is None:
+        return None
+
+    def one(v):
+        if torch.is_tensor(v):
+            return (id(v), v._version, v.data_ptr())
+        return v
+    return (id(q), one(getattr(q, "delta", None)), one(getattr(q, "zero_point", None)),
+            one(getattr(q, "alpha", None)), getattr(q, "n_bits", None), getattr(q, "sym", None))
+
+
+# ------------------------------------------------------------------------------------------------
+# weight packing (K2)
+# ------------------------------------------------------------------------------------------------
+class WeightPack:
+    __slots__ = ("wq", "ldk", "wbits", "mode", "segs", "Cout", "taps", "Cin")
+
+
+def _w_levels(q):
+    return int(q.n_levels)
+
+
+def pack_module_weights(weight, quantizers, split):
+    """weight: fp32 [Cout, Cin, *k] on the GPU; quantizers: [wq] or [wq, wq_0] (UniformAffine- or
+    AdaRound-like objects with delta/zero_point[/alpha]/n_levels).  Returns a WeightPack."""
+    dev = weight.device
+    w = weight.detach().float().contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    taps = 1
+    for s in w.shape[2:]:
+        taps *= int(s)
+    bounds = [(0, Cin)] if split == 0 else [(0, split), (split, Cin)]
+    if len(bounds) != len(quantizers):
+        raise hip.HipEngineError("split / quantiser count mismatch")
+    levels = _w_levels(quantizers[0])
+    zps = [q.zero_point.detach().float().reshape(-1).to(dev) if torch.is_tensor(q.zero_point)
+           else torch.full((Cout,), float(q.zero_point), device=dev) for q in quantizers]
+    zall = torch.cat(zps)
+    zmin, zmax = int(zall.min().item()), int(zall.max().item())  # one-time host read at pack time
+    if levels <= 16 and zmin >= 0 and zmax <= 127:
+        mode = 4
+    elif zmin >= 0 and zmax <= 128 and levels - 1 - zmin <= 127:
+        mode = 0
+    else:
+        mode = 8
+    pk = WeightPack()
+    pk.Cout, pk.taps, pk.Cin = Cout, taps, Cin
+    pk.mode, pk.wbits = mode, (4 if mode == 4 else 8)
+    kofs, segs = 0, []
+    for (c0, c1) in bounds:
+        clen = c1 - c0
+        segs.append(dict(c0w=c0, clen=clen, clen_pad=pad16(clen), kofs=kofs))
+        kofs += pad16(clen)
+    pk.ldk = max(pad32(kofs), 32)
+    nbytes = Cout * taps * pk.ldk // (2 if mode == 4 else 1)
+    pk.wq = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    for sg, q, z in zip(segs, quantizers, zps):
+        delta = q.delta.detach().float().reshape(-1).to(dev).contiguous()
+        if delta.numel() != Cout:
+            raise hip.HipEngineError("weight quantiser must be channel-wise (per output channel)")
+        alpha = getattr(q, "alpha", None)
+        if alpha is not None:
+            if getattr(q, "soft_targets", False):
+                raise hip.HipEngineError("AdaRound soft targets are a calibration-time mode; the integer engine packs hard rounding only")
+            alpha = alpha.detach().float().contiguous()
+        wsum = torch.zeros(Cout, dtype=torch.int32, device=dev)
+        hip.pack_weights(w, alpha, delta, z.contiguous(), Cout, Cin, taps, sg["c0w"], sg["clen"], levels, mode,
+                         pk.wq, pk.ldk, sg["kofs"], wsum)
+        sg["wsum"] = wsum
+        sg["delta_w"] = delta
+        sg["zw"] = (z.to(torch.int32) - 128).contiguous() if mode == 8 else None
+        sg["wzp"] = z.to(torch.int8).contiguous() if mode == 4 else None
+    pk.segs = segs
+    return pk
+
+
+# ------------------------------------------------------------------------------------------------
+# conv / linear plans (K3/K4)
+# ------------------------------------------------------------------------------------------------
+class ConvPlan:
+    """Frozen launch state of one QuantModule in (weight_quant, act_quant) = (True, True)."""
+    __slots__ = ("pack", "kh", "kw", "stride", "pad", "bias", "segs", "grids", "qparams", "Cout", "Cin", "ldx")
+
+
+def build_conv_plan(pack, act_quantizers, kh, kw, stride, pad, bias):
+    dev = pack.wq.device
+    plan = ConvPlan()
+    plan.pack, plan.kh, plan.kw, plan.stride, plan.pad = pack, kh, kw, stride, pad
+    plan.bias = bias.detach().float().contiguous() if bias is not None else None
+    plan.Cout, plan.Cin = pack.Cout, pack.Cin
+    plan.segs, plan.grids, plan.qparams = [], [], []
+    for sg, aq in zip(pack.segs, act_quantizers):
+        grid = act_grid(aq.n_bits, aq.sym)
+        qp = qparams_of(aq, dev)
+        K = pack.taps * sg["clen_pad"]
+        d = dict(c0=sg["kofs"], clen=sg["clen_pad"], kofs=sg["kofs"], scale=(qp[0] * sg["delta_w"]).contiguous(),
+                 zw=sg["zw"], wzp=sg["wzp"], zc=None, zfill=None)
+        if not aq.sym:
+            zprime = (qp[1] - grid.off).round().to(torch.int32)          # device scalar z'
+            d["zc"] = (zprime * sg["wsum"]).to(torch.int32).contiguous()
+            d["zfill"] = torch.stack([zprime, zprime * K]).to(torch.int32).contiguous()
+        plan.segs.append(d)
+        plan.grids.append(grid)
+        plan.qparams.append(qp)
+    # activation rows are laid out segment after segment, each padded to 16 bytes: same offsets as the
+    # packed weight rows, so c0 == kofs.
+    plan.ldx = pad16(sum(s["clen_pad"] for s in pack.segs))
+    return plan
+
+
+def quantize_rows(x, plan, B, C, S, strides, out=None):
+    """Quantise a logical [B][C][S] float tensor into the plan's int8 row layout [B*S][ldx]."""
+    if out is None:
+        out = torch.empty((B * S, plan.ldx), dtype=torch.int8, device=x.device)
+    for sg, d, grid, qp in zip(plan.pack.segs, plan.segs, plan.grids, plan.qparams):
+        hip.quantize_act(x, B, C, S, strides, qp, grid, out, plan.ldx, c0=sg["c0w"], clen=sg["clen"], oc0=d["c0"])
+    return out
+
+
+def conv_out_hw(H, W, plan, pad_br=None):
+    """Output size for symmetric padding `plan.pad` (or explicit bottom/right padding)."""
+    pb = plan.pad if pad_br is None else pad_br
+    Ho = (H + plan.pad + pb - plan.kh) // plan.stride + 1
+    Wo = (W + plan.pad + pb - plan.kw) // plan.stride + 1
+    return Ho, Wo
+
+
+def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, residual=None, acc_out=None,
+                 out_dtype=torch.float32, pad_tl=None):
+    """Run K3/K4 on quantised rows xq [B*H*W][ldx].  Returns out [B*Ho*Wo][Cout] (row-major)."""
+    if Ho is None:
+        Ho, Wo = conv_out_hw(H, W, plan)
+    M = B * Ho * Wo
+    if out is None and acc_out is None:
+        out = torch.empty((M, plan.Cout), dtype=out_dtype, device=xq.device)
+    pad = plan.pad if pad_tl is None else pad_tl
+    call = hip.ConvCall(x=xq, w=plan.pack.wq, out=out, bias=plan.bias, rowbias=rowbias,
+                        residual=residual, ldx=plan.ldx, ldk=plan.pack.ldk,
+                        ldo=(out.stride(0) if out is not None else 0),
+                        ldr=(residual.stride(0) if residual is not None else 0),
+                        ld_rowbias=(rowbias.stride(0) if rowbias is not None else 0),
+                        B=B, H=H, W=W, Ho=Ho, Wo=Wo, Cout=plan.Cout, kh=plan.kh, kw=plan.kw, stride=plan.stride,
+                        pad_t=pad, pad_l=pad, wbits=plan.pack.wbits, segs=plan.segs)
+    hip.conv2d_i8(call, acc_out=acc_out)
+    return out if acc_out is None else acc_out
+
+
+# ------------------------------------------------------------------------------------------------
+# producers (K5, K9)
+# ------------------------------------------------------------------------------------------------
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (device, torch.cuda.current_stream().cuda_stream if device.type == "cuda" else 0)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def groupnorm_silu_quant(x_rows, B, S, C, gn, silu, plan=None, want_float=False):
+    """x_rows: channels-last rows [B*S][>=C] (fp32/fp16).  Returns (int8 rows for `plan`, float rows)."""
+    dev = x_rows.device
+    ws = _workspace(hip.groupnorm_ws_bytes(B, C, S), dev)
+    out = torch.empty((B * S, plan.ldx), dtype=torch.int8, device=dev) if plan is not None else None
+    y = torch.empty((B * S, C), dtype=torch.float32, device=dev) if want_float else None
+    if plan is not None and (len(plan.segs) != 1 or plan.pack.segs[0]["clen"] != C):
+        raise hip.HipEngineError("groupnorm producer feeds single-segment consumers of the same width only")
+    hip.groupnorm_silu_quant(x_rows, B, S, C, x_rows.stride(0), gn.num_groups, gn.eps, gn.weight, gn.bias, silu,
+                             plan.qparams[0] if plan is not None else None, plan.grids[0] if plan is not None else None,
+                             out, plan.ldx if plan is not None else 0, ws, yout=y, ldy=C)
+    return out, y
+
+
+def layernorm_quant(x_rows, M, C, ln, plans):
+    """LayerNorm + one quantised copy per consumer plan (to_q / to_k / to_v have distinct deltas)."""
+    outs = [torch.empty((M, p.ldx), dtype=torch.int8, device=x_rows.device) for p in plans]
+    ldo = plans[0].ldx
+    if any(p.ldx != ldo or len(p.segs) != 1 for p in plans):
+        raise hip.HipEngineError("layernorm consumers must share one row layout")
+    hip.layernorm_quant(x_rows, M, C, x_rows.stride(0), ln.eps, ln.weight, ln.bias, [p.qparams[0] for p in plans],
+                        [p.grids[0] for p in plans], outs, ldo)
+    return outs
+
+
+def geglu_quant(h_rows, M, F, plan):
+    out = torch.empty((M, plan.ldx), dtype=torch.int8, device=h_rows.device)
+    hip.geglu_quant(h_rows, M, F, h_rows.stride(0), plan.qparams[0], plan.grids[0], out, plan.ldx)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# attention (K7/K8)
+# ------------------------------------------------------------------------------------------------
+class AttnPlan:
+    __slots__ = ("prm", "grids", "qparams", "wbits", "wmin", "wmax", "asym", "prescale", "scale")
+
+
+def build_attn_plan(aq_q, aq_k, aq_v, aq_w, scale, prescale, device):
+    """aq_*: the four activation quantisers of an attention block (quant_block.py:240-252,345-351).
+    scale multiplies the integer scores (d^-1/2 for SD/CIFAR, 1 for LDM where q*s, k*s are quantised)."""
+    ap = AttnPlan()
+    gq, gk, gv = act_grid(aq_q.n_bits, aq_q.sym), act_grid(aq_k.n_bits, aq_k.sym), act_grid(aq_v.n_bits, aq_v.sym)
+    if aq_w.n_bits not in (8, 16) and aq_w.n_bits > 8:
+        raise hip.HipEngineError(f"softmax bit-width {aq_w.n_bits} unsupported (<=8 or 16)")
+    if aq_w.sym:
+        nl = 2 ** (aq_w.n_bits - 1) - 1
+        wmin, wmax = -nl - 1, nl
+    else:
+        wmin, wmax = 0, 2 ** aq_w.n_bits - 1
+    ap.wbits = 16 if aq_w.n_bits > 8 else 8
+    ap.wmin, ap.wmax = wmin, wmax
+    qq, qk, qv, qw = (qparams_of(a, device) for a in (aq_q, aq_k, aq_v, aq_w))
+    prm = torch.zeros(16, dtype=torch.float32, device=device)
+    prm[0] = qq[0] * qk[0] * float(scale)
+    prm[1] = qq[1] - gq.off
+    prm[2] = qk[1] - gk.off
+    prm[3] = qw[0]
+    prm[4] = qw[1]
+    prm[5] = qw[0] * qv[0]
+    prm[6] = qv[1] - gv.off
+    ap.prm = prm
+    ap.grids = (gq, gk, gv)
+    ap.qparams = (qq, qk, qv)
+    ap.asym = not (aq_q.sym and aq_k.sym)
+    ap.prescale = float(prescale)
+    ap.scale = float(scale)
+    return ap
+
+
+def attention(ap, q, k, v, B, T, S, H, d, q_strides, k_strides, v_strides, out=None):
+    """q: logical [B][T][H][d] addressed by element strides (sb, st, sh, sd); k, v: [B][S][H][d].
+    Returns merged-head rows out[B*T][H*d] fp32."""
+    dev = q.device
+    Tpad, Spad, dpad = pad32(T), pad32(S), pad32(d)
+    BH = B * H
+    q8 = torch.empty((BH, Tpad, dpad), dtype=torch.int8, device=dev)
+    k8 = torch.empty((BH, Spad, dpad), dtype=torch.int8, device=dev)
+    v8 = torch.empty((BH, dpad, Spad), dtype=torch.int8, device=dev)
+    qsum = torch.empty((BH, Tpad), dtype=torch.int32, device=dev) if ap.asym else None
+    ksum = torch.empty((BH, Spad), dtype=torch.int32, device=dev) if ap.asym else None
+    vsum = torch.empty((BH, dpad), dtype=torch.int32, device=dev)
+    gq, gk, gv = ap.grids
+    hip.quantize_heads(q, B, T, H, d, q_strides, ap.prescale, ap.qparams[0], gq, False, q8, qsum, Tpad, dpad)
+    hip.quantize_heads(k, B, S, H, d, k_strides, ap.prescale, ap.qparams[1], gk, False, k8, ksum, Spad, dpad)
+    hip.quantize_heads(v, B, S, H, d, v_strides, 1.0, ap.qparams[2], gv, True, v8, vsum, Spad, dpad)
+    if out is None:
+        out = torch.empty((B * T, H * d), dtype=torch.float32, device=dev)
+    hip.attn_i8(q8, k8, v8, qsum, ksum, vsum, BH, H, T, S, d, Tpad, Spad, dpad, ap.prm, ap.wbits, ap.wmin, ap.wmax,
+                out, out.stride(0))
+    return out
+
+
+def sinusoid(timesteps, dim, flavour):
+    """Timestep sinusoid table (K6 front half; tiny, kept in torch).  flavour 'ldm': cos|sin with
+    /half (ldm util.py:151-171); 'ddim': sin|cos with /(half-1) (ddim diffusion.py:6-24)."""
+    half = dim // 2
+    ar = torch.arange(half, dtype=torch.float32, device=timesteps.device)
+    if flavour == "ldm":
+        freqs = torch.exp(-math.log(10000) * ar / half)
+        args = timesteps[:, None].float() * freqs[None]
+        emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    else:
+        freqs = torch.exp(ar * -(math.log(10000) / (half - 1)))
+        args = timesteps.float()[:, None] * freqs[None, :]
+        emb = torch.cat([torch.sin(args), torch.cos(args)], dim=1)
+    if dim % 2:
+        emb = torch.nn.functional.pad(emb, (0, 1))
+    return emb

@@ -1,0 +1,216 @@
+"""ctypes binding of libqdiff_hip.so (include/qdiff_hip.h) for torch tensors.
+
+This module is the only place where device pointers cross from PyTorch (used for HBM allocation,
+streams and torch.distributed only) into the HIP engine.  There is no fallback: if the shared
+library is missing or a tensor is not on the GPU, calls raise.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libqdiff_hip.so")
+
+F32, F16 = 0, 1
+_DT = {torch.float32: F32, torch.float16: F16}
+
+
+class HipEngineError(RuntimeError):
+    pass
+
+
+class ConvSeg(ctypes.Structure):
+    _fields_ = [("c0", ctypes.c_int32), ("clen", ctypes.c_int32), ("kofs", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("wzp", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("zc", ctypes.c_void_p), ("zw", ctypes.c_void_p), ("zfill", ctypes.c_void_p)]
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("bias", ctypes.c_void_p), ("rowbias", ctypes.c_void_p), ("residual", ctypes.c_void_p),
+                ("ldx", ctypes.c_int64), ("ldk", ctypes.c_int64), ("ldo", ctypes.c_int64), ("ldr", ctypes.c_int64),
+                ("ld_rowbias", ctypes.c_int64),
+                ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("Ho", ctypes.c_int32),
+                ("Wo", ctypes.c_int32), ("Cout", ctypes.c_int32),
+                ("kh", ctypes.c_int32), ("kw", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad_t", ctypes.c_int32),
+                ("pad_l", ctypes.c_int32),
+                ("wbits", ctypes.c_int32), ("out_dtype", ctypes.c_int32), ("nseg", ctypes.c_int32),
+                ("seg", ConvSeg * 2)]
+
+
+EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_quantize_act", "qd_pack_weights", "qd_conv2d_i8",
+           "qd_conv2d_i8_acc", "qd_groupnorm_ws_bytes", "qd_groupnorm_silu_quant", "qd_layernorm_quant",
+           "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8"]
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises HipEngineError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipEngineError(f"{LIB_PATH} not found: build it with `python q-diffusion_amd/build.py` "
+                             "(or __graft_entry__.build()); the quantised path has no fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.qd_last_error.restype = ctypes.c_char_p
+    lib.qd_groupnorm_ws_bytes.restype = ctypes.c_int64
+    lib.qd_groupnorm_ws_bytes.argtypes = [ctypes.c_int64] * 3
+    i64, i32, vp, f32 = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_float
+    lib.qd_quantize_act.argtypes = [vp, i32, i64, i64, i64, i64, i64, i64, i32, i32, i32, vp, i32, i32, i32, vp, i64, i32, vp]
+    lib.qd_pack_weights.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp, vp, vp]
+    lib.qd_conv2d_i8.argtypes = [ctypes.POINTER(ConvDesc), vp]
+    lib.qd_conv2d_i8_acc.argtypes = [ctypes.POINTER(ConvDesc), vp, vp]
+    lib.qd_groupnorm_silu_quant.argtypes = [vp, i32, i64, i64, i32, i64, i32, f32, vp, vp, i32, vp, i32, i32, i32, vp,
+                                            i64, vp, i64, vp, vp]
+    lib.qd_layernorm_quant.argtypes = [vp, i32, i64, i32, i64, f32, vp, vp, i32, ctypes.POINTER(vp),
+                                       ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32),
+                                       ctypes.POINTER(vp), i64, vp]
+    lib.qd_geglu_quant.argtypes = [vp, i32, i64, i32, i64, vp, i32, i32, i32, vp, i64, vp]
+    lib.qd_quantize_heads.argtypes = [vp, i32, i32, i32, i32, i32, i64, i64, i64, i64, f32, vp, i32, i32, i32, i32,
+                                      vp, vp, i32, i32, vp]
+    lib.qd_attn_i8.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp,
+                               i64, vp]
+    if lib.qd_abi_version() != 1:
+        raise HipEngineError("libqdiff_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def available():
+    try:
+        return bool(load().qd_device_ok())
+    except (HipEngineError, OSError):
+        return False
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise HipEngineError(f"{what} failed ({rc}): {load().qd_last_error().decode()}")
+
+
+def _ptr(t, name="tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipEngineError(f"{name} must live in GPU memory (got device={t.device}); the integer engine has no host path")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dtype(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise HipEngineError(f"unsupported dtype {t.dtype}")
+
+
+class Grid:
+    """Integer grid of a quantiser: codes in [qmin, qmax], stored as code - off."""
+    __slots__ = ("qmin", "qmax", "off")
+
+    def __init__(self, qmin, qmax, off):
+        self.qmin, self.qmax, self.off = int(qmin), int(qmax), int(off)
+
+
+def pad16(n):
+    return (n + 15) // 16 * 16
+
+
+def pad32(n):
+    return (n + 31) // 32 * 32
+
+
+def quantize_act(x, B, C, S, strides, qparams, grid, out, ldo, c0=0, clen=None, oc0=0):
+    """x: any float tensor addressed as logical [B][C][S] by element strides (sb, sc, ss)."""
+    clen = C - c0 if clen is None else clen
+    sb, sc, ss = strides
+    _check(load().qd_quantize_act(_ptr(x, "x"), _dtype(x), B, C, S, sb, sc, ss, c0, clen, pad16(clen),
+                                  _ptr(qparams, "qparams"), grid.qmin, grid.qmax, grid.off, _ptr(out, "out"), ldo, oc0,
+                                  _stream()), "qd_quantize_act")
+
+
+def pack_weights(w, alpha, delta, zp, Cout, Cin_total, taps, c0, clen, n_levels, mode, wq, ldk, kofs, wsum, codes=None):
+    _check(load().qd_pack_weights(_ptr(w), _ptr(alpha), _ptr(delta), _ptr(zp), Cout, Cin_total, taps, c0, clen,
+                                  pad16(clen), n_levels, mode, _ptr(wq), ldk, kofs, _ptr(wsum), _ptr(codes), _stream()),
+           "qd_pack_weights")
+
+
+class ConvCall:
+    """Python-side description of one qd_conv2d_i8 launch (tensors, not pointers)."""
+    __slots__ = ("x", "w", "out", "bias", "rowbias", "residual", "ldx", "ldk", "ldo", "ldr", "ld_rowbias",
+                 "B", "H", "W", "Ho", "Wo", "Cout", "kh", "kw", "stride", "pad_t", "pad_l", "wbits", "segs")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+
+def conv2d_i8(c, acc_out=None):
+    """c: ConvCall.  segs: list of dicts {c0, clen, kofs, wzp, scale, zc, zw, zfill} (tensors or None)."""
+    d = ConvDesc()
+    d.x, d.w = _ptr(c.x, "x"), _ptr(c.w, "w")
+    d.out = _ptr(c.out, "out")
+    d.bias, d.rowbias, d.residual = _ptr(c.bias, "bias"), _ptr(c.rowbias, "rowbias"), _ptr(c.residual, "residual")
+    d.ldx, d.ldk, d.ldo = c.ldx, c.ldk, c.ldo or 0
+    d.ldr, d.ld_rowbias = c.ldr or 0, c.ld_rowbias or 0
+    d.B, d.H, d.W, d.Ho, d.Wo, d.Cout = c.B, c.H, c.W, c.Ho, c.Wo, c.Cout
+    d.kh, d.kw, d.stride, d.pad_t, d.pad_l = c.kh, c.kw, c.stride, c.pad_t, c.pad_l
+    d.wbits = c.wbits
+    d.out_dtype = _dtype(c.out) if c.out is not None else F32
+    d.nseg = len(c.segs)
+    for i, s in enumerate(c.segs):
+        g = d.seg[i]
+        g.c0, g.clen, g.kofs = s["c0"], s["clen"], s["kofs"]
+        g.wzp = _ptr(s.get("wzp"), "wzp")
+        g.scale, g.zc, g.zw, g.zfill = _ptr(s["scale"], "scale"), _ptr(s.get("zc")), _ptr(s.get("zw")), _ptr(s.get("zfill"))
+    if acc_out is None:
+        _check(load().qd_conv2d_i8(ctypes.byref(d), _stream()), "qd_conv2d_i8")
+    else:
+        _check(load().qd_conv2d_i8_acc(ctypes.byref(d), _ptr(acc_out), _stream()), "qd_conv2d_i8_acc")
+
+
+def groupnorm_ws_bytes(B, C, S):
+    return int(load().qd_groupnorm_ws_bytes(B, C, S))
+
+
+def groupnorm_silu_quant(x, B, S, C, ldx, groups, eps, gamma, beta, silu, qparams, grid, out, ldo, ws, yout=None, ldy=0):
+    g = grid or Grid(0, 0, 0)
+    _check(load().qd_groupnorm_silu_quant(_ptr(x), _dtype(x), B, S, C, ldx, groups, float(eps), _ptr(gamma), _ptr(beta),
+                                          1 if silu else 0, _ptr(qparams), g.qmin, g.qmax, g.off, _ptr(out), ldo,
+                                          _ptr(yout), ldy, _ptr(ws), _stream()), "qd_groupnorm_silu_quant")
+
+
+def layernorm_quant(x, M, C, ldx, eps, gamma, beta, qparams_list, grids, outs, ldo):
+    n = len(outs)
+    vp, i32 = ctypes.c_void_p, ctypes.c_int
+    qp = (vp * n)(*[q.data_ptr() for q in qparams_list])
+    for q in list(qparams_list) + list(outs):
+        _ptr(q)
+    mn = (i32 * n)(*[g.qmin for g in grids])
+    mx = (i32 * n)(*[g.qmax for g in grids])
+    of = (i32 * n)(*[g.off for g in grids])
+    op = (vp * n)(*[o.data_ptr() for o in outs])
+    _check(load().qd_layernorm_quant(_ptr(x), _dtype(x), M, C, ldx, float(eps), _ptr(gamma), _ptr(beta), n, qp, mn, mx,
+                                     of, op, ldo, _stream()), "qd_layernorm_quant")
+
+
+def geglu_quant(h, M, F, ldh, qparams, grid, out, ldo):
+    _check(load().qd_geglu_quant(_ptr(h), _dtype(h), M, F, ldh, _ptr(qparams), grid.qmin, grid.qmax, grid.off, _ptr(out),
+                                 ldo, _stream()), "qd_geglu_quant")
+
+
+def quantize_heads(x, B, T, H, d, strides, prescale, qparams, grid, transpose, out, rsum, Tpad, dpad):
+    sb, st, sh, sd = strides
+    _check(load().qd_quantize_heads(_ptr(x), _dtype(x), B, T, H, d, sb, st, sh, sd, float(prescale), _ptr(qparams),
+                                    grid.qmin, grid.qmax, grid.off, 1 if transpose else 0, _ptr(out), _ptr(rsum), Tpad,
+                                    dpad, _stream()), "qd_quantize_heads")
+
+
+def attn_i8(q, k, vt, qsum, ksum, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, wmax, out, ldo):
+    _check(load().qd_attn_i8(_ptr(q), _ptr(k), _ptr(vt), _ptr(qsum), _ptr(ksum), _ptr(vsum), BH, H, T, S, d, Tpad, Spad,
+                             dpad, _ptr(prm), wbits, wmin, wmax, _ptr(out), ldo, _stream()), "qd_attn_i8")

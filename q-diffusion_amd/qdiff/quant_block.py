@@ -1,0 +1,559 @@
+"""Quantised UNet blocks — counterpart of the reference's qdiff/quant_block.py (same class names,
+constructor signatures, quantiser attribute names and therefore state-dict keys).
+
+Each block has two forwards:
+  * `_forward_sim`: the reference composition (norm -> act -> QuantModule ...), used whenever the
+    block is not fully in (weight_quant, act_quant) = (True, True) state, under autograd
+    (calibration), or while a quantiser still needs its data-dependent initialisation;
+  * `_forward_int`: the MI355X path.  Activations stay channels-last; GroupNorm+SiLU (K5),
+    LayerNorm (K9a) and GEGLU (K9b) are *producers* that emit the next QuantModule's int8 rows
+    directly, the timestep-embedding add and the residual add ride in the conv epilogue (K3), and
+    q/k/softmax/v quantisation + both attention contractions are one fused kernel (K7/K8).
+"""
+import logging
+from types import MethodType
+
+import torch
+import torch as th
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import engine
+from .arch import ddim_unet, ldm_unet
+from .quant_layer import QuantModule, StraightThrough, UniformAffineQuantizer
+
+logger = logging.getLogger(__name__)
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------
+def _nhwc_rows(x):
+    """[B,C,H,W] (any strides) -> channels-last rows view [B*H*W, C]."""
+    B, C, H, W = x.shape
+    if x.stride(1) != 1 or x.stride(3) != C or x.stride(2) != W * C or x.stride(0) != H * W * C:
+        x = x.contiguous(memory_format=torch.channels_last)
+        if x.stride(1) != 1:  # degenerate shapes where channels_last == contiguous
+            x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+
+
+def _rows_to_nchw(rows, B, H, W):
+    return rows.view(B, H, W, rows.shape[1]).permute(0, 3, 1, 2)
+
+
+def _int_mode(*modules):
+    """All given QuantModules take the integer path and autograd is off."""
+    return (not torch.is_grad_enabled()) and all(isinstance(m, QuantModule) and m.int_ready() for m in modules)
+
+
+def _aq_ready(*quantizers):
+    return all(q.inited for q in quantizers)
+
+
+def _gn_silu_to(conv, rows, B, S, C, gn, silu=True):
+    """GroupNorm(+SiLU) -> int8 rows for `conv`; initialises conv's act quantiser on first use."""
+    if not conv.act_quantizer.inited:
+        y = F.group_norm(rows.view(B, S, C).permute(0, 2, 1).float(), gn.num_groups, gn.weight, gn.bias, gn.eps)
+        conv._init_act_quantizers(F.silu(y) if silu else y)
+    xq, _ = engine.groupnorm_silu_quant(rows, B, S, C, gn, silu, plan=conv.conv_plan())
+    return xq
+
+
+def _ln_to(consumers, rows, M, C, ln):
+    """LayerNorm -> one int8 copy per consumer QuantModule."""
+    if not all(m.act_quantizer.inited for m in consumers):
+        y = F.layer_norm(rows, (C,), ln.weight, ln.bias, ln.eps)
+        for m in consumers:
+            m._init_act_quantizers(y)
+    return engine.layernorm_quant(rows, M, C, ln, [m.conv_plan() for m in consumers])
+
+
+def _linear_rows(lin, rows, residual=None):
+    """QuantModule linear on float rows [M,K] -> [M,N] (quantise + integer GEMM)."""
+    lin._init_act_quantizers(rows)
+    plan = lin.conv_plan()
+    M, K = rows.shape
+    xq = engine.quantize_rows(rows, plan, 1, K, M, (0, rows.stride(1), rows.stride(0)))
+    return engine.conv_forward(plan, xq, 1, 1, M, 1, M, residual=residual)
+
+
+class _AttnQuant:
+    """Mixin: cached AttnPlan for the four attention quantisers of a block."""
+
+    def _attn_plan(self, owner, scale, prescale, device):
+        qs = (owner.act_quantizer_q, owner.act_quantizer_k, owner.act_quantizer_v, owner.act_quantizer_w)
+        key = tuple(engine.quantizer_key(q) for q in qs) + (scale, prescale)
+        cache = owner.__dict__.setdefault("_attn_plan_cache", [None, None])
+        if cache[0] != key:
+            cache[0], cache[1] = key, engine.build_attn_plan(*qs, scale, prescale, device)
+        return cache[1]
+
+
+def _reference_classes():
+    """The reference's own UNet classes, when its `ldm` / `ddim` packages are importable (drop-in
+    use inside the q-diffusion source tree): they are rewritten exactly like this repo's classes."""
+    out = {}
+    try:
+        from ldm.modules.diffusionmodules import openaimodel as ref_oai
+        from ldm.modules.attention import BasicTransformerBlock as RefBTB
+        out.update(ResBlock=ref_oai.ResBlock, AttentionBlock=ref_oai.AttentionBlock, QKMatMul=ref_oai.QKMatMul,
+                   SMVMatMul=ref_oai.SMVMatMul, BasicTransformerBlock=RefBTB, TimestepBlock=ref_oai.TimestepBlock)
+    except Exception:  # noqa: BLE001 - optional dependency
+        pass
+    try:
+        from ddim.models import diffusion as ref_ddim
+        out.update(ResnetBlock=ref_ddim.ResnetBlock, AttnBlock=ref_ddim.AttnBlock)
+    except Exception:  # noqa: BLE001
+        pass
+    return out
+
+
+_REF = _reference_classes()
+# QuantResBlock must be recognised as a TimestepBlock by whichever TimestepEmbedSequential hosts it
+_TIMESTEP_BASES = (ldm_unet.TimestepBlock,) + ((_REF["TimestepBlock"],) if "TimestepBlock" in _REF else ())
+
+
+# ------------------------------------------------------------------------------------------------
+# base
+# ------------------------------------------------------------------------------------------------
+class BaseQuantBlock(nn.Module):
+    """reference quant_block.py:20-41"""
+
+    def __init__(self, act_quant_params: dict = {}):
+        super().__init__()
+        self.use_weight_quant = False
+        self.use_act_quant = False
+        self.act_quantizer = UniformAffineQuantizer(**act_quant_params)   # never initialised: no state-dict keys
+        self.activation_function = StraightThrough()
+        self.ignore_reconstruction = False
+
+    def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
+        self.use_weight_quant = weight_quant
+        self.use_act_quant = act_quant
+        for m in self.modules():
+            if isinstance(m, QuantModule):
+                m.set_quant_state(weight_quant, act_quant)
+
+
+# ------------------------------------------------------------------------------------------------
+# LDM / SD residual block  (reference quant_block.py:44-111)
+# ------------------------------------------------------------------------------------------------
+class QuantResBlock(BaseQuantBlock, *_TIMESTEP_BASES):
+    def __init__(self, res, act_quant_params: dict = {}):
+        super().__init__(act_quant_params)
+        for name in ("channels", "emb_channels", "dropout", "out_channels", "use_conv", "use_checkpoint",
+                     "use_scale_shift_norm", "in_layers", "updown", "h_upd", "x_upd", "emb_layers", "out_layers",
+                     "skip_connection"):
+            setattr(self, name, getattr(res, name))
+
+    def forward(self, x, emb=None, split=0):
+        # the split argument is only forwarded until the skip connection has recorded it (reference :75-81)
+        if split != 0 and self.skip_connection.split == 0:
+            return self._forward(x, emb, split)
+        return self._forward(x, emb)
+
+    def _forward(self, x, emb, split=0):
+        if emb is None:
+            x, emb = x
+        assert x.shape[2] == x.shape[3]
+        conv1, conv2 = self.in_layers[-1], self.out_layers[-1]
+        if (not self.updown and not self.use_scale_shift_norm and _int_mode(conv1, conv2, self.emb_layers[-1])
+                and conv1.split == 0 and conv2.split == 0):
+            return self._forward_int(x, emb, split, conv1, conv2)
+        return self._forward_sim(x, emb, split)
+
+    def _forward_sim(self, x, emb, split=0):
+        if self.updown:
+            h = self.in_layers[:-1](x)
+            h, x = self.h_upd(h), self.x_upd(x)
+            h = self.in_layers[-1](h)
+        else:
+            h = self.in_layers(x)
+        e = self.emb_layers(emb).type(h.dtype)
+        while e.dim() < h.dim():
+            e = e[..., None]
+        if self.use_scale_shift_norm:
+            scale, shift = th.chunk(e, 2, dim=1)
+            h = self.out_layers[1:](self.out_layers[0](h) * (1 + scale) + shift)
+        else:
+            h = self.out_layers(h + e)
+        if split != 0:
+            return self.skip_connection(x, split=split) + h
+        return self.skip_connection(x) + h
+
+    def _forward_int(self, x, emb, split, conv1, conv2):
+        B, C, H, W = x.shape
+        S = H * W
+        rows = _nhwc_rows(x)
+        xq = _gn_silu_to(conv1, rows, B, S, C, self.in_layers[0])
+        e = self.emb_layers(emb)                                      # SiLU + integer linear -> [B, Cout]
+        h = conv1.forward_codes(xq, B, H, W, rowbias=e.float().contiguous())
+        hq = _gn_silu_to(conv2, h, B, S, self.out_channels, self.out_layers[0])
+        if isinstance(self.skip_connection, nn.Identity):
+            res = rows
+        else:
+            sk = self.skip_connection(x, split=split) if split != 0 else self.skip_connection(x)
+            res = _nhwc_rows(sk)
+        out = conv2.forward_codes(hq, B, H, W, residual=res)
+        return _rows_to_nchw(out, B, H, W)
+
+
+# ------------------------------------------------------------------------------------------------
+# LDM attention matmuls  (reference quant_block.py:114-160)
+# ------------------------------------------------------------------------------------------------
+class QuantQKMatMul(BaseQuantBlock):
+    def __init__(self, act_quant_params: dict = {}):
+        super().__init__(act_quant_params)
+        self.scale = None
+        self.use_act_quant = False
+        self.act_quantizer_q = UniformAffineQuantizer(**act_quant_params)
+        self.act_quantizer_k = UniformAffineQuantizer(**act_quant_params)
+
+    def forward(self, q, k):
+        if self.use_act_quant:
+            q, k = self.act_quantizer_q(q * self.scale), self.act_quantizer_k(k * self.scale)
+        else:
+            q, k = q * self.scale, k * self.scale
+        return th.einsum("bct,bcs->bts", q, k)
+
+    def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
+        self.use_act_quant = act_quant
+
+
+class QuantSMVMatMul(BaseQuantBlock):
+    def __init__(self, act_quant_params: dict = {}, sm_abit=8):
+        super().__init__(act_quant_params)
+        self.use_act_quant = False
+        self.act_quantizer_v = UniformAffineQuantizer(**act_quant_params)
+        params_w = act_quant_params.copy()
+        params_w['n_bits'] = sm_abit
+        params_w['symmetric'] = False
+        params_w['always_zero'] = True
+        self.act_quantizer_w = UniformAffineQuantizer(**params_w)
+
+    def forward(self, weight, v):
+        if self.use_act_quant:
+            weight, v = self.act_quantizer_w(weight), self.act_quantizer_v(v)
+        return th.einsum("bts,bcs->bct", weight, v)
+
+    def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
+        self.use_act_quant = act_quant
+
+
+class QuantAttentionBlock(BaseQuantBlock, _AttnQuant):
+    """LDM AttentionBlock (reference quant_block.py:163-187).  With quantised activations and this
+    repo's own QKVAttentionLegacy (whose two matmuls were swapped for QuantQKMatMul / QuantSMVMatMul),
+    the whole qkv -> attention chain runs fused on the integer engine."""
+
+    def __init__(self, attn, act_quant_params: dict = {}, sm_abit: int = 8, quant_matmuls: bool = False):
+        super().__init__(act_quant_params)
+        self.channels = attn.channels
+        self.num_heads = attn.num_heads
+        self.use_checkpoint = attn.use_checkpoint
+        self.norm = attn.norm
+        self.qkv = attn.qkv
+        self.attention = attn.attention
+        self.proj_out = attn.proj_out
+        if quant_matmuls:
+            # quantised-activation mode: the two matmul modules inside QKVAttentionLegacy become their
+            # quantised counterparts (what the reference's recursion does, quant_model.py:45-61)
+            if isinstance(getattr(self.attention, "qkv_matmul", None), ldm_unet.QKMatMul):
+                self.attention.qkv_matmul = QuantQKMatMul(act_quant_params)
+            if isinstance(getattr(self.attention, "smv_matmul", None), ldm_unet.SMVMatMul):
+                self.attention.smv_matmul = QuantSMVMatMul(act_quant_params, sm_abit=sm_abit)
+
+    def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
+        super().set_quant_state(weight_quant, act_quant)
+        for m in (getattr(self.attention, "qkv_matmul", None), getattr(self.attention, "smv_matmul", None)):
+            if isinstance(m, (QuantQKMatMul, QuantSMVMatMul)):
+                m.set_quant_state(weight_quant, act_quant)
+
+    def forward(self, x):
+        return self._forward(x)
+
+    def _fusable(self):
+        att = self.attention
+        qk, smv = getattr(att, "qkv_matmul", None), getattr(att, "smv_matmul", None)
+        return (isinstance(qk, QuantQKMatMul) and isinstance(smv, QuantSMVMatMul) and qk.use_act_quant
+                and smv.use_act_quant and _int_mode(self.qkv, self.proj_out)
+                and _aq_ready(qk.act_quantizer_q, qk.act_quantizer_k, smv.act_quantizer_v, smv.act_quantizer_w))
+
+    def _forward(self, x):
+        b, c, *spatial = x.shape
+        if x.dim() == 4 and self._fusable():
+            return self._forward_int(x)
+        xf = x.reshape(b, c, -1)
+        h = self.proj_out(self.attention(self.qkv(self.norm(xf))))
+        return (xf + h).reshape(b, c, *spatial)
+
+    def _forward_int(self, x):
+        B, C, H, W = x.shape
+        T, nh = H * W, self.num_heads
+        d = C // nh
+        rows = _nhwc_rows(x)
+        xq = _gn_silu_to(self.qkv, rows, B, T, C, self.norm, silu=False)
+        qkv = self.qkv.forward_codes(xq, B, 1, T)                     # [B*T, 3C]; channel = head*3d + {q,k,v}*d + i
+        qk, smv = self.attention.qkv_matmul, self.attention.smv_matmul
+        holder = self.__dict__.setdefault("_aq_view", type("V", (), {})())
+        holder.act_quantizer_q, holder.act_quantizer_k = qk.act_quantizer_q, qk.act_quantizer_k
+        holder.act_quantizer_v, holder.act_quantizer_w = smv.act_quantizer_v, smv.act_quantizer_w
+        scale = float(qk.scale) if qk.scale is not None else d ** -0.25
+        ap = self._attn_plan(holder, 1.0, scale, x.device)
+        ld = qkv.stride(0)
+        strides = (T * ld, ld, 3 * d, 1)
+        att = engine.attention(ap, qkv, qkv[:, d:], qkv[:, 2 * d:], B, T, T, nh, d, strides, strides, strides)
+        out = _linear_like_conv1d(self.proj_out, att, B, T, residual=rows)
+        return _rows_to_nchw(out, B, H, W)
+
+
+def _linear_like_conv1d(mod, rows, B, T, residual=None):
+    """conv1d(k=1) QuantModule applied to token rows [B*T, C]."""
+    mod._init_act_quantizers(rows.view(B, T, -1).permute(0, 2, 1))
+    plan = mod.conv_plan()
+    M, K = rows.shape
+    xq = engine.quantize_rows(rows, plan, 1, K, M, (0, rows.stride(1), rows.stride(0)))
+    return engine.conv_forward(plan, xq, B, 1, T, 1, T, residual=residual)
+
+
+# ------------------------------------------------------------------------------------------------
+# SD transformer block  (reference quant_block.py:190-282)
+# ------------------------------------------------------------------------------------------------
+def cross_attn_forward(self, x, context=None, mask=None):
+    """Bound onto attn1/attn2 (as the reference does, quant_block.py:254-255): simulation-tier
+    forward with the four activation quantisers; the fused integer path lives in
+    QuantBasicTransformerBlock._attn_int."""
+    h = self.heads
+    context = x if context is None else context
+    q, k, v = self.to_q(x), self.to_k(context), self.to_v(context)
+    q, k, v = (ldm_unet._split_heads(t, h) for t in (q, k, v))
+    if self.use_act_quant:
+        q, k = self.act_quantizer_q(q), self.act_quantizer_k(k)
+    sim = th.einsum('b i d, b j d -> b i j', q, k) * self.scale
+    if mask is not None:
+        mask = mask.reshape(mask.shape[0], -1)[:, None, :].repeat_interleave(h, dim=0)
+        sim.masked_fill_(~mask, -th.finfo(sim.dtype).max)
+    attn = sim.softmax(dim=-1)
+    if self.use_act_quant:
+        attn, v = self.act_quantizer_w(attn), self.act_quantizer_v(v)
+    out = th.einsum('b i j, b j d -> b i d', attn, v)
+    return self.to_out(ldm_unet._merge_heads(out, h))
+
+
+class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
+    def __init__(self, tran, act_quant_params: dict = {}, sm_abit: int = 8):
+        super().__init__(act_quant_params)
+        self.attn1, self.ff, self.attn2 = tran.attn1, tran.ff, tran.attn2
+        self.norm1, self.norm2, self.norm3 = tran.norm1, tran.norm2, tran.norm3
+        self.checkpoint = tran.checkpoint
+        params_w = act_quant_params.copy()
+        params_w['n_bits'] = sm_abit
+        params_w['always_zero'] = True
+        for att in (self.attn1, self.attn2):
+            att.act_quantizer_q = UniformAffineQuantizer(**act_quant_params)
+            att.act_quantizer_k = UniformAffineQuantizer(**act_quant_params)
+            att.act_quantizer_v = UniformAffineQuantizer(**act_quant_params)
+            att.act_quantizer_w = UniformAffineQuantizer(**params_w)
+            att.forward = MethodType(cross_attn_forward, att)
+            att.use_act_quant = False
+
+    def forward(self, x, context=None):
+        return self._forward(x, context)
+
+    def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
+        self.attn1.use_act_quant = act_quant
+        self.attn2.use_act_quant = act_quant
+        super().set_quant_state(weight_quant, act_quant)
+
+    def _attn_inited(self, att):
+        return _aq_ready(att.act_quantizer_q, att.act_quantizer_k, att.act_quantizer_v, att.act_quantizer_w)
+
+    def _forward(self, x, context=None):
+        if context is None and isinstance(x, (tuple, list)):
+            x, context = x
+        a1, a2 = self.attn1, self.attn2
+        mods = [a1.to_q, a1.to_k, a1.to_v, a1.to_out[0], a2.to_q, a2.to_k, a2.to_v, a2.to_out[0], self.ff.net[-1]]
+        glu = isinstance(self.ff.net[0], ldm_unet.GEGLU) or type(self.ff.net[0]).__name__ == "GEGLU"
+        if (glu and a1.use_act_quant and a2.use_act_quant and _int_mode(*mods, self.ff.net[0].proj)
+                and self._attn_inited(a1) and self._attn_inited(a2)):
+            return self._forward_int(x, context)
+        x = self.attn1(self.norm1(x)) + x
+        x = self.attn2(self.norm2(x), context=context) + x
+        return self.ff(self.norm3(x)) + x
+
+    def _attn_int(self, att, rows, B, T, C, ln, ctx_rows, S):
+        """norm -> q/k/v projections -> fused quantised attention -> to_out (+ residual rows)."""
+        h = att.heads
+        if ctx_rows is None:
+            q8, k8, v8 = _ln_to([att.to_q, att.to_k, att.to_v], rows, B * T, C, ln)
+            q = att.to_q.forward_codes(q8, 1, 1, B * T)
+            k = att.to_k.forward_codes(k8, 1, 1, B * T)
+            v = att.to_v.forward_codes(v8, 1, 1, B * T)
+            S = T
+        else:
+            (q8,) = _ln_to([att.to_q], rows, B * T, C, ln)
+            q = att.to_q.forward_codes(q8, 1, 1, B * T)
+            k = _linear_rows(att.to_k, ctx_rows)
+            v = _linear_rows(att.to_v, ctx_rows)
+        inner = q.shape[1]
+        d = inner // h
+        ap = self._attn_plan(att, float(att.scale), 1.0, rows.device)
+        o = engine.attention(ap, q, k, v, B, T, S, h, d, (T * inner, inner, d, 1), (S * inner, inner, d, 1),
+                             (S * inner, inner, d, 1))
+        return _linear_rows(att.to_out[0], o, residual=rows)
+
+    def _forward_int(self, x, context):
+        B, T, C = x.shape
+        rows = x.reshape(B * T, C)
+        if rows.stride(1) != 1 or rows.stride(0) != C:
+            rows = rows.contiguous()
+        rows = self._attn_int(self.attn1, rows, B, T, C, self.norm1, None, T)
+        if context is None:
+            rows = self._attn_int(self.attn2, rows, B, T, C, self.norm2, None, T)
+        else:
+            S = context.shape[1]
+            ctx = context.reshape(B * S, context.shape[2]).float()
+            if ctx.stride(1) != 1:
+                ctx = ctx.contiguous()
+            rows = self._attn_int(self.attn2, rows, B, T, C, self.norm2, ctx, S)
+        proj, ff_out = self.ff.net[0].proj, self.ff.net[-1]
+        (h8,) = _ln_to([proj], rows, B * T, C, self.norm3)
+        hcat = proj.forward_codes(h8, 1, 1, B * T)                    # [M, 2F]
+        Fdim = hcat.shape[1] // 2
+        if not ff_out.act_quantizer.inited:
+            ff_out._init_act_quantizers(hcat[:, :Fdim] * F.gelu(hcat[:, Fdim:]))
+        g8 = engine.geglu_quant(hcat, B * T, Fdim, ff_out.conv_plan())
+        rows = ff_out.forward_codes(g8, 1, 1, B * T, residual=rows)
+        return rows.view(B, T, C)
+
+
+# ------------------------------------------------------------------------------------------------
+# DDIM (CIFAR) blocks  (reference quant_block.py:286-386)
+# ------------------------------------------------------------------------------------------------
+class QuantResnetBlock(BaseQuantBlock):
+    def __init__(self, res, act_quant_params: dict = {}):
+        super().__init__(act_quant_params)
+        self.in_channels, self.out_channels = res.in_channels, res.out_channels
+        self.use_conv_shortcut = res.use_conv_shortcut
+        self.norm1, self.conv1, self.temb_proj = res.norm1, res.conv1, res.temb_proj
+        self.norm2, self.dropout, self.conv2 = res.norm2, res.dropout, res.conv2
+        if self.in_channels != self.out_channels:
+            if self.use_conv_shortcut:
+                self.conv_shortcut = res.conv_shortcut
+            else:
+                self.nin_shortcut = res.nin_shortcut
+
+    def forward(self, x, temb=None, split=0):
+        if temb is None:
+            x, temb = x
+        if _int_mode(self.conv1, self.conv2, self.temb_proj):
+            return self._forward_int(x, temb, split)
+        h = self.conv1(ddim_unet.nonlinearity(self.norm1(x)))
+        h = h + self.temb_proj(ddim_unet.nonlinearity(temb))[:, :, None, None]
+        h = self.conv2(self.dropout(ddim_unet.nonlinearity(self.norm2(h))))
+        if self.in_channels != self.out_channels:
+            x = self.conv_shortcut(x) if self.use_conv_shortcut else self.nin_shortcut(x, split=split)
+        return x + h
+
+    def _forward_int(self, x, temb, split):
+        B, C, H, W = x.shape
+        S = H * W
+        rows = _nhwc_rows(x)
+        xq = _gn_silu_to(self.conv1, rows, B, S, C, self.norm1)
+        e = self.temb_proj(ddim_unet.nonlinearity(temb))
+        h = self.conv1.forward_codes(xq, B, H, W, rowbias=e.float().contiguous())
+        hq = _gn_silu_to(self.conv2, h, B, S, self.out_channels, self.norm2)
+        if self.in_channels != self.out_channels:
+            sk = self.conv_shortcut(x) if self.use_conv_shortcut else self.nin_shortcut(x, split=split)
+            res = _nhwc_rows(sk)
+        else:
+            res = rows
+        out = self.conv2.forward_codes(hq, B, H, W, residual=res)
+        return _rows_to_nchw(out, B, H, W)
+
+
+class QuantAttnBlock(BaseQuantBlock, _AttnQuant):
+    def __init__(self, attn, act_quant_params: dict = {}, sm_abit=8):
+        super().__init__(act_quant_params)
+        self.in_channels = attn.in_channels
+        self.norm, self.q, self.k, self.v, self.proj_out = attn.norm, attn.q, attn.k, attn.v, attn.proj_out
+        self.act_quantizer_q = UniformAffineQuantizer(**act_quant_params)
+        self.act_quantizer_k = UniformAffineQuantizer(**act_quant_params)
+        self.act_quantizer_v = UniformAffineQuantizer(**act_quant_params)
+        params_w = act_quant_params.copy()
+        params_w['n_bits'] = sm_abit
+        self.act_quantizer_w = UniformAffineQuantizer(**params_w)
+
+    def forward(self, x):
+        if (self.use_act_quant and _int_mode(self.q, self.k, self.v, self.proj_out)
+                and _aq_ready(self.act_quantizer_q, self.act_quantizer_k, self.act_quantizer_v, self.act_quantizer_w)):
+            return self._forward_int(x)
+        hn = self.norm(x)
+        q, k, v = self.q(hn), self.k(hn), self.v(hn)
+        b, c, h, w = q.shape
+        q = q.reshape(b, c, h * w).permute(0, 2, 1)
+        k = k.reshape(b, c, h * w)
+        if self.use_act_quant:
+            q, k = self.act_quantizer_q(q), self.act_quantizer_k(k)
+        w_ = F.softmax(th.bmm(q, k) * (int(c) ** (-0.5)), dim=2)
+        v = v.reshape(b, c, h * w)
+        w_ = w_.permute(0, 2, 1)
+        if self.use_act_quant:
+            v, w_ = self.act_quantizer_v(v), self.act_quantizer_w(w_)
+        out = th.bmm(v, w_).reshape(b, c, h, w)
+        return x + self.proj_out(out)
+
+    def _forward_int(self, x):
+        B, C, H, W = x.shape
+        T = H * W
+        rows = _nhwc_rows(x)
+        # one GroupNorm, three consumers with their own act quantisers
+        ws_plan = None
+        _, y = engine.groupnorm_silu_quant(rows, B, T, C, self.norm, False, plan=ws_plan, want_float=True)
+        q = _linear_like_conv2d(self.q, y, B, H, W)
+        k = _linear_like_conv2d(self.k, y, B, H, W)
+        v = _linear_like_conv2d(self.v, y, B, H, W)
+        ap = self._attn_plan(self, int(C) ** (-0.5), 1.0, x.device)
+        st = (T * C, C, C, 1)
+        o = engine.attention(ap, q, k, v, B, T, T, 1, C, st, st, st)
+        out = _linear_like_conv2d(self.proj_out, o, B, H, W, residual=rows)
+        return _rows_to_nchw(out, B, H, W)
+
+
+def _linear_like_conv2d(mod, rows, B, H, W, residual=None):
+    """1x1 Conv2d QuantModule applied to channels-last rows."""
+    mod._init_act_quantizers(rows)
+    plan = mod.conv_plan()
+    M, K = rows.shape
+    xq = engine.quantize_rows(rows, plan, 1, K, M, (0, rows.stride(1), rows.stride(0)))
+    return engine.conv_forward(plan, xq, B, H, W, H, W, residual=residual)
+
+
+# ------------------------------------------------------------------------------------------------
+# dispatch table  (reference quant_block.py:389-401)
+# ------------------------------------------------------------------------------------------------
+def get_specials(quant_act=False):
+    specials = {
+        ldm_unet.ResBlock: QuantResBlock,
+        ldm_unet.BasicTransformerBlock: QuantBasicTransformerBlock,
+        ddim_unet.ResnetBlock: QuantResnetBlock,
+        ddim_unet.AttnBlock: QuantAttnBlock,
+    }
+    ref = _REF
+    for name, target in (("ResBlock", QuantResBlock), ("BasicTransformerBlock", QuantBasicTransformerBlock),
+                         ("ResnetBlock", QuantResnetBlock), ("AttnBlock", QuantAttnBlock)):
+        if name in ref:
+            specials[ref[name]] = target
+    if quant_act:
+        specials[ldm_unet.QKMatMul] = QuantQKMatMul
+        specials[ldm_unet.SMVMatMul] = QuantSMVMatMul
+        # this repo's AttentionBlock is wrapped as well so that qkv -> attention -> proj runs fused
+        specials[ldm_unet.AttentionBlock] = QuantAttentionBlock
+        if "QKMatMul" in ref:
+            specials[ref["QKMatMul"]] = QuantQKMatMul
+            specials[ref["SMVMatMul"]] = QuantSMVMatMul
+    else:
+        specials[ldm_unet.AttentionBlock] = QuantAttentionBlock
+        if "AttentionBlock" in ref:
+            specials[ref["AttentionBlock"]] = QuantAttentionBlock
+    return specials

@@ -1,0 +1,401 @@
+"""Quantisers and the quantised Conv/Linear wrapper — MI355X-native counterpart of the reference's
+qdiff/quant_layer.py (same public names, constructor signatures, attributes and state-dict keys).
+
+What differs from the reference: with weight *and* activation quantisation switched on,
+`QuantModule.forward` does not simulate integers in fp32 (reference quant_layer.py:256-276); it
+quantises the input once to int8 (K1), and runs the contraction on MFMA-int8 with int4/int8 packed
+weights and a fused dequantising epilogue (K3/K4, csrc/igemm_i8.hip).  The weight codes are packed
+once per quantiser state (the reference re-quantises every weight tensor on every forward).
+
+The fp32 simulation itself (`UniformAffineQuantizer.forward`) is kept as a differentiable torch
+function because calibration code and the scripts call quantisers directly; it is not used by the
+(True, True) inference path.
+"""
+import logging
+import warnings
+from typing import Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import engine, hip
+
+logger = logging.getLogger(__name__)
+
+
+class StraightThrough(nn.Module):
+    """Identity placeholder (reference quant_layer.py:11-16)."""
+
+    def __init__(self, channel_num: int = 1):
+        super().__init__()
+
+    def forward(self, input):
+        return input
+
+
+def round_ste(x: torch.Tensor):
+    """Round with a straight-through gradient (reference quant_layer.py:19-23)."""
+    return x + (x.round() - x).detach()
+
+
+def lp_loss(pred, tgt, p=2.0, reduction='none'):
+    """L_p reconstruction loss (reference quant_layer.py:26-33)."""
+    err = (pred - tgt).abs().pow(p)
+    return err.sum(1).mean() if reduction == 'none' else err.mean()
+
+
+class UniformAffineQuantizer(nn.Module):
+    """Uniform affine (asymmetric) / symmetric quantiser.
+
+    Constructor keywords, attributes (`delta`, `zero_point`, `inited`, `sym`, `n_bits`, `n_levels`,
+    `running_stat`, `leaf_param`, `x_min`, `x_max`) and the lazy data-dependent initialisation on the
+    first tensor seen follow reference quant_layer.py:36-200.
+    """
+
+    def __init__(self, n_bits: int = 8, symmetric: bool = False, channel_wise: bool = False,
+                 scale_method: str = 'max', leaf_param: bool = False, always_zero: bool = False):
+        super().__init__()
+        self.sym = symmetric
+        self.n_bits = n_bits
+        self.n_levels = 2 ** n_bits if not symmetric else 2 ** (n_bits - 1) - 1
+        self.delta = None
+        self.zero_point = None
+        self.inited = False
+        self.leaf_param = leaf_param
+        self.channel_wise = channel_wise
+        self.scale_method = scale_method
+        self.running_stat = False
+        self.always_zero = always_zero
+        if leaf_param:
+            self.x_min, self.x_max = None, None
+
+    # -- integer grid -------------------------------------------------------------------------
+    def code_range(self):
+        """[lo, hi] of the integer codes (reference quant_layer.py:84-87)."""
+        if self.sym:
+            return -self.n_levels - 1, self.n_levels
+        return 0, self.n_levels - 1
+
+    # -- initialisation -----------------------------------------------------------------------
+    def ensure_init(self, x: torch.Tensor):
+        """Data-dependent init from the first tensor seen (reference quant_layer.py:68-75)."""
+        if self.inited:
+            return
+        delta, zero_point = self.init_quantization_scale(x, self.channel_wise)
+        self.delta = nn.Parameter(delta) if self.leaf_param else delta
+        self.zero_point = zero_point
+        self.inited = True
+
+    def forward(self, x: torch.Tensor):
+        self.ensure_init(x)
+        if self.running_stat:
+            self.act_momentum_update(x)
+        lo, hi = self.code_range()
+        codes = torch.clamp(round_ste(x / self.delta) + self.zero_point, lo, hi)
+        return (codes - self.zero_point) * self.delta
+
+    def act_momentum_update(self, x: torch.Tensor, act_range_momentum: float = 0.95):
+        """EMA range tracking used during calibration (reference quant_layer.py:91-110)."""
+        assert self.inited and self.leaf_param
+        m = act_range_momentum
+        self.x_min = self.x_min * m + x.data.min() * (1 - m)
+        self.x_max = self.x_max * m + x.data.max() * (1 - m)
+        if self.sym:
+            delta = torch.max(self.x_min.abs(), self.x_max.abs()) / self.n_levels
+        elif self.always_zero:
+            delta = self.x_max / (self.n_levels - 1)
+        else:
+            delta = (self.x_max - self.x_min) / (self.n_levels - 1)
+        delta = torch.clamp(delta, min=1e-8)
+        if not self.sym:
+            self.zero_point = 0 if self.always_zero else (-self.x_min / delta).round()
+        self.delta = nn.Parameter(delta)
+
+    def _init_max_channelwise(self, x):
+        """Vectorised form of the reference's per-channel Python loop (quant_layer.py:114-136,
+        142-160).  fp64 arithmetic reproduces the reference's Python-float math exactly: delta is
+        a double quotient rounded to fp32, zero_point is round-half-even of a double quotient."""
+        flat = x.detach().reshape(x.shape[0], -1).double()
+        mx, mn = flat.max(dim=1)[0], flat.min(dim=1)[0]
+        lo = torch.clamp(mn, max=0.0)
+        hi = torch.clamp(mx, min=0.0)
+        if 'scale' in self.scale_method:
+            lo = lo * (self.n_bits + 2) / 8
+            hi = hi * (self.n_bits + 2) / 8
+        if self.sym:
+            delta = torch.maximum(lo.abs(), hi) / self.n_levels
+        else:
+            delta = (mx - mn) / (self.n_levels - 1)
+        if bool((delta < 1e-8).any()):
+            warnings.warn('Quantization range close to zero in at least one channel')
+            delta = torch.clamp(delta, min=1e-8)
+        if self.sym or self.always_zero:
+            zp = torch.zeros_like(delta)
+        else:
+            zp = torch.round(-lo / delta)
+        shape = (-1,) + (1,) * (x.dim() - 1)
+        return delta.to(x.dtype).view(shape), zp.to(x.dtype).view(shape)
+
+    def init_quantization_scale(self, x: torch.Tensor, channel_wise: bool = False):
+        if channel_wise:
+            if 'max' in self.scale_method:
+                return self._init_max_channelwise(x)
+            xc = x.clone().detach()
+            delta = torch.zeros(xc.shape[0], dtype=x.dtype, device=x.device)
+            zero_point = torch.zeros_like(delta)
+            for c in range(xc.shape[0]):
+                delta[c], zero_point[c] = self.init_quantization_scale(xc[c], channel_wise=False)
+            shape = (-1,) + (1,) * (x.dim() - 1)
+            return delta.view(shape), zero_point.view(shape)
+
+        if self.leaf_param:
+            self.x_min = x.data.min()
+            self.x_max = x.data.max()
+        if 'max' in self.scale_method:
+            raw_min, raw_max = x.min().item(), x.max().item()
+            x_min, x_max = min(raw_min, 0), max(raw_max, 0)
+            if 'scale' in self.scale_method:
+                x_min = x_min * (self.n_bits + 2) / 8
+                x_max = x_max * (self.n_bits + 2) / 8
+            if self.sym:
+                delta = max(abs(x_min), x_max) / self.n_levels
+            else:
+                delta = float(raw_max - raw_min) / (self.n_levels - 1)
+            if delta < 1e-8:
+                warnings.warn('Quantization range close to zero: [{}, {}]'.format(x_min, x_max))
+                delta = 1e-8
+            zero_point = 0 if (self.sym or self.always_zero) else round(-x_min / delta)
+            return torch.tensor(delta).type_as(x), zero_point
+        if self.scale_method == 'mse':
+            # LAPQ-style range search (reference quant_layer.py:162-177)
+            x_max, x_min = x.max(), x.min()
+            best_score, delta, zero_point = 1e+10, None, None
+            for i in range(80):
+                new_max = x_max * (1.0 - (i * 0.01))
+                new_min = x_min * (1.0 - (i * 0.01))
+                score = lp_loss(x, self.quantize(x, new_max, new_min), p=2.4, reduction='all')
+                if score < best_score:
+                    best_score = score
+                    span = new_max if self.always_zero else (new_max - new_min)
+                    delta = span / (2 ** self.n_bits - 1)
+                    zero_point = 0 if self.always_zero else (-new_min / delta).round()
+            return delta, zero_point
+        raise NotImplementedError(self.scale_method)
+
+    def quantize(self, x, max, min):
+        span = max if self.always_zero else (max - min)
+        delta = span / (2 ** self.n_bits - 1)
+        zero_point = 0 if self.always_zero else (-min / delta).round()
+        codes = torch.clamp(torch.round(x / delta) + zero_point, 0, self.n_levels - 1)
+        return (codes - zero_point) * delta
+
+    def bitwidth_refactor(self, refactored_bit: int):
+        self.n_bits = refactored_bit
+        self.n_levels = 2 ** self.n_bits
+
+    def extra_repr(self):
+        return (f'bit={self.n_bits}, scale_method={self.scale_method}, symmetric={self.sym}, '
+                f'channel_wise={self.channel_wise}, leaf_param={self.leaf_param}')
+
+
+def _module_kind(m):
+    if isinstance(m, nn.Conv2d):
+        return 'conv2d'
+    if isinstance(m, nn.Conv1d):
+        return 'conv1d'
+    if isinstance(m, nn.Linear):
+        return 'linear'
+    raise TypeError(f'QuantModule wraps Conv2d / Conv1d / Linear, got {type(m).__name__}')
+
+
+class QuantModule(nn.Module):
+    """Quantised Conv2d / Conv1d / Linear.  Public surface as reference quant_layer.py:203-294:
+    attributes `weight`, `bias`, `org_weight`, `org_bias`, `use_weight_quant`, `use_act_quant`,
+    `weight_quantizer[_0]`, `act_quantizer[_0]`, `split`, `ignore_reconstruction`,
+    `activation_function`, `fwd_kwargs`, `fwd_func`, `disable_act_quant`; `forward(input, split=0)`.
+    """
+
+    def __init__(self, org_module: Union[nn.Conv2d, nn.Linear, nn.Conv1d], weight_quant_params: dict = {},
+                 act_quant_params: dict = {}, disable_act_quant: bool = False, act_quant_mode: str = 'qdiff'):
+        super().__init__()
+        self.weight_quant_params = weight_quant_params
+        self.act_quant_params = act_quant_params
+        self.kind = _module_kind(org_module)
+        if self.kind == 'linear':
+            self.fwd_kwargs = dict()
+            self.fwd_func = F.linear
+        else:
+            self.fwd_kwargs = dict(stride=org_module.stride, padding=org_module.padding,
+                                   dilation=org_module.dilation, groups=org_module.groups)
+            self.fwd_func = F.conv2d if self.kind == 'conv2d' else F.conv1d
+        self.weight = org_module.weight
+        self.org_weight = org_module.weight.data.clone()      # plain attribute, as in the reference
+        if org_module.bias is not None:
+            self.bias = org_module.bias
+            self.org_bias = org_module.bias.data.clone()
+        else:
+            self.bias = None
+            self.org_bias = None
+        self.use_weight_quant = False
+        self.use_act_quant = False
+        self.act_quant_mode = act_quant_mode
+        self.disable_act_quant = disable_act_quant
+        self.weight_quantizer = UniformAffineQuantizer(**self.weight_quant_params)
+        if self.act_quant_mode == 'qdiff':
+            self.act_quantizer = UniformAffineQuantizer(**self.act_quant_params)
+        self.split = 0
+        self.activation_function = StraightThrough()
+        self.ignore_reconstruction = False
+        self.extra_repr = org_module.extra_repr
+        # frozen integer state (not part of the state dict)
+        self._pack, self._pack_key = None, None
+        self._plan, self._plan_key = None, None
+        self._wdq, self._wdq_key = None, None
+
+    # -- reference-visible controls -----------------------------------------------------------
+    def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
+        self.use_weight_quant = weight_quant
+        self.use_act_quant = act_quant
+
+    def set_split(self):
+        self.weight_quantizer_0 = UniformAffineQuantizer(**self.weight_quant_params)
+        if self.act_quant_mode == 'qdiff':
+            self.act_quantizer_0 = UniformAffineQuantizer(**self.act_quant_params)
+
+    def set_running_stat(self, running_stat: bool):
+        if self.act_quant_mode == 'qdiff':
+            self.act_quantizer.running_stat = running_stat
+            if self.split != 0:
+                self.act_quantizer_0.running_stat = running_stat
+
+    def _note_split(self, split):
+        """Sticky split bookkeeping (reference quant_layer.py:249-254)."""
+        if split != 0 and self.split != 0:
+            assert split == self.split
+        elif split != 0:
+            logger.info(f"split at {split}!")
+            self.split = split
+            self.set_split()
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _weight_quantizers(self):
+        return [self.weight_quantizer] if self.split == 0 else [self.weight_quantizer, self.weight_quantizer_0]
+
+    def _act_quantizers(self):
+        return [self.act_quantizer] if self.split == 0 else [self.act_quantizer, self.act_quantizer_0]
+
+    def _weight_slices(self):
+        if self.split == 0:
+            return [self.weight]
+        return [self.weight[:, :self.split, ...], self.weight[:, self.split:, ...]]
+
+    def _input_slices(self, x):
+        if self.split == 0:
+            return [x]
+        return [x[:, :self.split], x[:, self.split:]]
+
+    def _geometry(self):
+        """(kh, kw, stride, pad) or None when the integer kernel does not cover the configuration."""
+        if self.kind == 'linear':
+            return 1, 1, 1, 0
+        kw = self.fwd_kwargs
+        one = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v,) * (2 if self.kind == 'conv2d' else 1)
+        st, pd, dl = one(kw['stride']), one(kw['padding']), one(kw['dilation'])
+        if kw['groups'] != 1 or any(d != 1 for d in dl) or len(set(st)) != 1 or len(set(pd)) != 1:
+            return None
+        ks = tuple(self.weight.shape[2:])
+        if self.kind == 'conv1d':
+            return 1, ks[0], st[0], pd[0]
+        return ks[0], ks[1], st[0], pd[0]
+
+    def int_ready(self):
+        """True when this module will take the integer path on its next forward."""
+        return (self.use_weight_quant and self.use_act_quant and not self.disable_act_quant
+                and self.act_quant_mode == 'qdiff' and self._geometry() is not None)
+
+    def dequantized_weight(self):
+        """fp32 weight after fake quantisation, cached per quantiser state (weights-only mode)."""
+        qs = self._weight_quantizers()
+        key = (tuple(engine.quantizer_key(q) for q in qs), self.weight._version, self.weight.data_ptr(), self.split)
+        if self._wdq_key != key or torch.is_grad_enabled():
+            parts = [q(w) for q, w in zip(qs, self._weight_slices())]
+            w = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+            if torch.is_grad_enabled():
+                return w
+            self._wdq, self._wdq_key = w, key
+        return self._wdq
+
+    # -- integer plan -------------------------------------------------------------------------
+    def conv_plan(self):
+        """Packed weights + epilogue constants for the current quantiser state (lazy, cached)."""
+        wqs, aqs = self._weight_quantizers(), self._act_quantizers()
+        for q, w in zip(wqs, self._weight_slices()):
+            if hasattr(q, 'ensure_init'):
+                q.ensure_init(w)
+        wkey = (tuple(engine.quantizer_key(q) for q in wqs), self.weight._version, self.weight.data_ptr(), self.split)
+        if self._pack_key != wkey:
+            self._pack = engine.pack_module_weights(self.weight, wqs, self.split)
+            self._pack_key, self._plan_key = wkey, None
+        bias_key = None if self.bias is None else (self.bias._version, self.bias.data_ptr())
+        akey = (wkey, tuple(engine.quantizer_key(q) for q in aqs), bias_key)
+        if self._plan_key != akey:
+            kh, kw, stride, pad = self._geometry()
+            self._plan = engine.build_conv_plan(self._pack, aqs, kh, kw, stride, pad, self.bias)
+            self._plan_key = akey
+        return self._plan
+
+    def _init_act_quantizers(self, x):
+        for q, xs in zip(self._act_quantizers(), self._input_slices(x)):
+            q.ensure_init(xs)
+            if q.running_stat:
+                q.act_momentum_update(xs)
+
+    def _forward_int(self, x):
+        self._init_act_quantizers(x)
+        plan = self.conv_plan()
+        if self.kind == 'conv2d':
+            B, C, H, W = x.shape
+            sb, sc, sh, sw = x.stride()
+            if sh != W * sw:
+                x = x.contiguous(memory_format=torch.channels_last)
+                sb, sc, sh, sw = x.stride()
+            xq = engine.quantize_rows(x, plan, B, C, H * W, (sb, sc, sw))
+            Ho, Wo = engine.conv_out_hw(H, W, plan)
+            out = engine.conv_forward(plan, xq, B, H, W, Ho, Wo)
+            return out.view(B, Ho, Wo, plan.Cout).permute(0, 3, 1, 2)
+        if self.kind == 'conv1d':
+            B, C, T = x.shape
+            sb, sc, st = x.stride()
+            xq = engine.quantize_rows(x, plan, B, C, T, (sb, sc, st))
+            To = (T + 2 * plan.pad - plan.kw) // plan.stride + 1
+            out = engine.conv_forward(plan, xq, B, 1, T, 1, To)
+            return out.view(B, To, plan.Cout).permute(0, 2, 1)
+        lead, K = x.shape[:-1], x.shape[-1]
+        rows = x.reshape(-1, K)
+        if rows.stride(1) != 1:
+            rows = rows.contiguous()
+        M = rows.shape[0]
+        xq = engine.quantize_rows(rows, plan, 1, K, M, (0, 1, rows.stride(0)))
+        out = engine.conv_forward(plan, xq, 1, 1, M, 1, M)
+        return out.view(*lead, plan.Cout)
+
+    def forward_codes(self, xq, B, H, W, Ho=None, Wo=None, rowbias=None, residual=None, pad_tl=None):
+        """Integer path for a producer that already emitted this module's int8 rows (fused blocks)."""
+        return engine.conv_forward(self.conv_plan(), xq, B, H, W, Ho, Wo, rowbias=rowbias, residual=residual,
+                                   pad_tl=pad_tl)
+
+    # -- forward ------------------------------------------------------------------------------
+    def forward(self, input: torch.Tensor, split: int = 0):
+        self._note_split(split)
+        if self.int_ready() and not torch.is_grad_enabled():
+            return self.activation_function(self._forward_int(input))
+        # simulated / floating-point states: (False, *), weights-only, or calibration under autograd
+        if not self.disable_act_quant and self.use_act_quant and self.act_quant_mode == 'qdiff':
+            parts = [q(xs) for q, xs in zip(self._act_quantizers(), self._input_slices(input))]
+            input = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+        if self.use_weight_quant:
+            weight, bias = self.dequantized_weight(), self.bias
+        else:
+            weight, bias = self.org_weight, self.org_bias
+        return self.activation_function(self.fwd_func(input, weight, bias, **self.fwd_kwargs))

@@ -1,0 +1,390 @@
+"""GPU parity tests of every C-ABI entry point against the CPU oracle (oracle/quant_ref.py).
+
+Integer work (codes, packed weights, int32 accumulators) must match BIT-EXACTLY (oracle tier T0);
+floating-point outputs are compared with the tolerance written in each test (tier T1).
+"""
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import quant_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _aq(delta, zp, n_bits=8, sym=False):
+    return NS(delta=torch.tensor(float(delta)), zero_point=zp, n_bits=n_bits, sym=sym)
+
+
+def _grid_off(n_bits, sym):
+    return 0 if sym or n_bits < 8 else 128
+
+
+# ------------------------------------------------------------------------------------------------
+# K1
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("sym", [True, False])
+@pytest.mark.parametrize("C", [3, 48, 100])
+def test_quantize_act_bit_exact(cuda, layout, sym, C):
+    from qdiff import engine, hip
+    g = torch.Generator().manual_seed(1)
+    B, H, W = 2, 9, 7
+    x = torch.randn(B, C, H, W, generator=g) * 2.0
+    x[0, 0, 0, :4] = torch.tensor([0.5, 1.5, 2.5, -0.5]) * 0.037  # exact ties: round-half-even
+    delta, zp = 0.037, (0 if sym else 131)
+    codes = R.uaq_codes(x, torch.tensor(delta), zp, 8, sym)
+    off = _grid_off(8, sym)
+    xd = x.to(cuda)
+    if layout == "nhwc":
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    S = H * W
+    sb, sc, sh, sw = xd.stride()
+    assert sh == W * sw
+    grid = engine.act_grid(8, sym)
+    qp = torch.tensor([delta, float(zp)], device=cuda)
+    ldo = hip.pad16(C) + 16
+    out = torch.full((B * S, ldo), 77, dtype=torch.int8, device=cuda)
+    hip.quantize_act(xd, B, C, S, (sb, sc, sw), qp, grid, out, ldo, oc0=16)
+    torch.cuda.synchronize()
+    got = out.cpu().view(B, H, W, ldo)
+    want = (codes - off).permute(0, 2, 3, 1).to(torch.int8)
+    assert torch.equal(got[..., 16:16 + C], want)
+    assert (got[..., :16] == 77).all()                       # untouched prefix
+    assert (got[..., 16 + C:] == zp - off).all()              # pad lanes hold "true zero"
+
+
+def test_quantize_act_split_segments(cuda):
+    from qdiff import engine, hip
+    g = torch.Generator().manual_seed(2)
+    B, C, H, W, split = 2, 80, 4, 4, 32
+    x = torch.randn(B, C, H, W, generator=g)
+    p0, p1 = (0.02, 120), (0.05, 97)
+    xd = x.to(cuda)
+    out = torch.zeros((B * H * W, 80), dtype=torch.int8, device=cuda)
+    grid = engine.act_grid(8, False)
+    for (c0, clen, oc0, (d, z)) in [(0, split, 0, p0), (split, C - split, 32, p1)]:
+        hip.quantize_act(xd, B, C, H * W, (C * H * W, H * W, 1), torch.tensor([d, float(z)], device=cuda), grid, out, 80,
+                         c0=c0, clen=clen, oc0=oc0)
+    got = out.cpu().view(B, H, W, 80).permute(0, 3, 1, 2)
+    w0 = R.uaq_codes(x[:, :split], torch.tensor(p0[0]), p0[1], 8, False) - 128
+    w1 = R.uaq_codes(x[:, split:], torch.tensor(p1[0]), p1[1], 8, False) - 128
+    assert torch.equal(got[:, :32].long(), w0) and torch.equal(got[:, 32:].long(), w1)
+
+
+# ------------------------------------------------------------------------------------------------
+# K2
+# ------------------------------------------------------------------------------------------------
+def _weight_quantizer(w, n_bits, adaround, g):
+    delta, zp = R.uaq_init_scale(w, n_bits, False, True, "max")
+    q = NS(delta=delta, zero_point=zp, n_bits=n_bits, sym=False, n_levels=2 ** n_bits)
+    if adaround:
+        q.alpha = (torch.rand(w.shape, generator=g) - 0.5)
+        q.soft_targets = False
+    return q
+
+
+def _codes(w, q):
+    if getattr(q, "alpha", None) is not None:
+        return R.adaround_codes(w, q.delta, q.zero_point, q.alpha, q.n_levels)
+    return R.nearest_codes(w, q.delta, q.zero_point, q.n_levels)
+
+
+@pytest.mark.parametrize("n_bits,adaround", [(8, True), (8, False), (4, True), (4, False), (6, True)])
+def test_pack_weights_codes_bit_exact(cuda, n_bits, adaround):
+    from qdiff import hip
+    g = torch.Generator().manual_seed(3)
+    Cout, Cin, kh = 37, 40, 3
+    w = torch.randn(Cout, Cin, kh, kh, generator=g) * 0.1
+    q = _weight_quantizer(w, n_bits, adaround, g)
+    want = _codes(w, q)
+    taps = kh * kh
+    ldk = 64
+    for mode in ([8, 0] if n_bits > 4 else [4, 8]):
+        if mode == 0:
+            continue  # direct mode needs zp in [0,128]; covered through engine.pack_module_weights
+        wq = torch.zeros(Cout * taps * ldk // (2 if mode == 4 else 1), dtype=torch.uint8, device=cuda)
+        wsum = torch.zeros(Cout, dtype=torch.int32, device=cuda)
+        codes = torch.zeros((Cout, Cin, taps), dtype=torch.int32, device=cuda)
+        hip.pack_weights(w.to(cuda), q.alpha.to(cuda) if adaround else None, q.delta.reshape(-1).to(cuda),
+                         q.zero_point.reshape(-1).to(cuda), Cout, Cin, taps, 0, Cin, 2 ** n_bits, mode, wq, ldk, 0, wsum, codes)
+        torch.cuda.synchronize()
+        assert torch.equal(codes.cpu().long().view(Cout, Cin, kh, kh), want)
+        zp = q.zero_point.reshape(-1).long()
+        if mode == 8:
+            rows = wq.cpu().view(torch.int8).view(Cout, taps, ldk).long()
+            got = rows[:, :, :Cin].permute(0, 2, 1).reshape(Cout, Cin, kh, kh)
+            assert torch.equal(got, want - 128)
+            assert (rows[:, :, Cin:48] == 0).all()
+            assert torch.equal(wsum.cpu().long(), (want - 128).sum(dim=(1, 2, 3)))
+        else:
+            raw = wq.cpu().view(Cout, taps, ldk // 2).long()
+            lo, hi = raw & 15, raw >> 4
+            k = torch.zeros(Cout, taps, ldk, dtype=torch.long)
+            for chunk in range(ldk // 16):
+                for word in range(2):
+                    for b in range(4):
+                        byte = chunk * 8 + word * 4 + b
+                        k[:, :, chunk * 16 + word * 8 + b] = lo[:, :, byte]
+                        k[:, :, chunk * 16 + word * 8 + 4 + b] = hi[:, :, byte]
+            got = k[:, :, :Cin].permute(0, 2, 1).reshape(Cout, Cin, kh, kh)
+            assert torch.equal(got, want)
+            pad = 48 - Cin
+            assert torch.equal(wsum.cpu().long(), (want - zp.view(-1, 1, 1, 1)).sum(dim=(1, 2, 3)) - zp * pad * taps)
+
+
+# ------------------------------------------------------------------------------------------------
+# K3/K4: exact accumulators and fp epilogue
+# ------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # name,            B, Cin, H,  W, Cout, k, stride, pad, asym_pad
+    ("c3x3_s1",        2, 48, 12, 12, 40, 3, 1, 1, False),
+    ("c3x3_big",       4, 64, 32, 32, 256, 3, 1, 1, False),   # exercises the 128x128 tile
+    ("c3x3_s2_p1",     2, 32, 16, 16, 48, 3, 2, 1, False),
+    ("c3x3_s2_asym",   2, 32, 16, 16, 48, 3, 2, 0, True),     # CIFAR Downsample: F.pad(0,1,0,1)+pad 0
+    ("c1x1",           3, 80, 8, 8, 96, 1, 1, 0, False),
+    ("stem_c3",        2, 3, 16, 16, 32, 3, 1, 1, False),
+    ("out_c4",         2, 64, 16, 16, 4, 3, 1, 1, False),
+    ("k224",           2, 224, 8, 8, 64, 3, 1, 1, False),      # K-step tail masking (224 = 3.5 * 64)
+]
+
+
+def _run_conv(cuda, x, w, bias, q, aq, k, stride, pad, asym_pad, acc=False, rowbias=None, residual=None):
+    from qdiff import engine
+    B, Cin, H, W = x.shape
+    pack = engine.pack_module_weights(w.to(cuda), [q], 0)
+    plan = engine.build_conv_plan(pack, [aq], k, k, stride, pad, bias.to(cuda) if bias is not None else None)
+    xd = x.to(cuda)
+    xq = engine.quantize_rows(xd, plan, B, Cin, H * W, (Cin * H * W, H * W, 1))
+    if asym_pad:
+        Ho, Wo = (H + 1 - k) // stride + 1, (W + 1 - k) // stride + 1
+    else:
+        Ho, Wo = engine.conv_out_hw(H, W, plan)
+    acc_out = torch.zeros((B * Ho * Wo, plan.Cout), dtype=torch.int32, device=cuda) if acc else None
+    out = engine.conv_forward(plan, xq, B, H, W, Ho, Wo, acc_out=acc_out,
+                              rowbias=rowbias.to(cuda) if rowbias is not None else None,
+                              residual=residual.to(cuda) if residual is not None else None)
+    torch.cuda.synchronize()
+    return out.cpu().view(B, Ho, Wo, -1).permute(0, 3, 1, 2), pack.mode
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize("w_bits", [8, 4])
+@pytest.mark.parametrize("a_sym", [True, False])
+def test_conv_int32_accumulators_bit_exact(cuda, case, w_bits, a_sym):
+    _, B, Cin, H, W, Cout, k, stride, pad, asym_pad = case
+    g = torch.Generator().manual_seed(hash(case[0]) % 1000 + w_bits)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    x = F.silu(x) if not a_sym else x
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
+    q = _weight_quantizer(w, w_bits, True, g)
+    d, z = R.uaq_init_scale(x, 8, a_sym, False, "max")
+    aq = _aq(d, z, 8, a_sym)
+    got, mode = _run_conv(cuda, x, w, None, q, aq, k, stride, pad, asym_pad, acc=True)
+    xc = R.uaq_codes(x, aq.delta, aq.zero_point, 8, a_sym)
+    xin = xc
+    kw = dict(stride=stride, padding=pad)
+    if asym_pad:
+        xin = F.pad(xc - int(z), (0, 1, 0, 1)) + int(z)      # pad holds real 0 == code zp
+    want = R.int_conv_exact(xin, int(z), _codes(w, q), q.zero_point.reshape(-1).long(), "conv2d", kw)
+    assert mode == (4 if w_bits == 4 else 8)
+    assert torch.equal(got.long(), want), f"max |diff| = {(got.long() - want).abs().max().item()}"
+
+
+@pytest.mark.parametrize("case", CONV_CASES[:5], ids=[c[0] for c in CONV_CASES[:5]])
+@pytest.mark.parametrize("w_bits", [8, 4])
+def test_conv_fp32_matches_fake_quant(cuda, case, w_bits):
+    """vs the reference's fp32 simulation (tier T1): rel tolerance 2e-5 of the output range
+    (SURVEY.md §7 measured 3e-7; fp32 accumulation order differs)."""
+    _, B, Cin, H, W, Cout, k, stride, pad, asym_pad = case
+    g = torch.Generator().manual_seed(11)
+    x = F.silu(torch.randn(B, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
+    bias = torch.randn(Cout, generator=g)
+    q = _weight_quantizer(w, w_bits, True, g)
+    d, z = R.uaq_init_scale(x, 8, False, False, "max")
+    aq = _aq(d, z)
+    rowbias = torch.randn(B, Cout, generator=g)
+    got, _ = _run_conv(cuda, x, w, bias, q, aq, k, stride, pad, asym_pad, rowbias=rowbias)
+    xin = F.pad(x, (0, 1, 0, 1)) if asym_pad else x
+    want = R.quant_module_forward(xin, w, bias, "conv2d", dict(stride=stride, padding=pad),
+                                  [dict(delta=q.delta, zero_point=q.zero_point, alpha=q.alpha, n_levels=q.n_levels)],
+                                  [dict(delta=aq.delta, zero_point=z, n_bits=8, sym=False)])
+    want = want + rowbias[:, :, None, None]
+    tol = 2e-5 * want.abs().max().item()
+    assert (got - want).abs().max().item() <= tol
+
+
+def test_conv_split_two_segments(cuda):
+    """1x1 split shortcut (quant_layer.py:257-269): two activation + two weight quantisers."""
+    from qdiff import engine
+    g = torch.Generator().manual_seed(5)
+    for w_bits in (8, 4):
+        B, C, H, W, Cout, split = 2, 224 + 96, 8, 8, 72, 224
+        x = torch.randn(B, C, H, W, generator=g)
+        x[:, split:] *= 3.0
+        w = torch.randn(Cout, C, 1, 1, generator=g) * 0.05
+        bias = torch.randn(Cout, generator=g)
+        q0 = _weight_quantizer(w[:, :split], w_bits, True, g)
+        q1 = _weight_quantizer(w[:, split:], w_bits, True, g)
+        d0, z0 = R.uaq_init_scale(x[:, :split], 8, False, False, "max")
+        d1, z1 = R.uaq_init_scale(x[:, split:], 8, False, False, "max")
+        a0, a1 = _aq(d0, z0), _aq(d1, z1)
+        pack = engine.pack_module_weights(w.to(cuda), [q0, q1], split)
+        plan = engine.build_conv_plan(pack, [a0, a1], 1, 1, 1, 0, bias.to(cuda))
+        xq = engine.quantize_rows(x.to(cuda), plan, B, C, H * W, (C * H * W, H * W, 1))
+        res = torch.randn(B * H * W, Cout, generator=g)
+        out = engine.conv_forward(plan, xq, B, H, W, residual=res.to(cuda))
+        torch.cuda.synchronize()
+        got = out.cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
+        want = R.quant_module_forward(
+            x, w, bias, "conv2d", dict(stride=1, padding=0),
+            [dict(delta=q.delta, zero_point=q.zero_point, alpha=q.alpha, n_levels=q.n_levels) for q in (q0, q1)],
+            [dict(delta=a.delta, zero_point=a.zero_point, n_bits=8, sym=False) for a in (a0, a1)], split=split)
+        want = want + res.view(B, H, W, Cout).permute(0, 3, 1, 2)
+        assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+
+
+def test_linear_tokens(cuda):
+    from qdiff import engine
+    g = torch.Generator().manual_seed(6)
+    M, K, N = 2 * 77, 768, 320
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.03
+    q = _weight_quantizer(w, 4, True, g)
+    d, z = R.uaq_init_scale(x, 8, False, False, "max")
+    aq = _aq(d, z)
+    pack = engine.pack_module_weights(w.to(cuda), [q], 0)
+    plan = engine.build_conv_plan(pack, [aq], 1, 1, 1, 0, None)
+    xq = engine.quantize_rows(x.to(cuda), plan, 1, K, M, (0, 1, K))
+    out = engine.conv_forward(plan, xq, 1, 1, M)
+    torch.cuda.synchronize()
+    want = R.quant_module_forward(x, w, None, "linear", {}, [dict(delta=q.delta, zero_point=q.zero_point, alpha=q.alpha, n_levels=16)],
+                                  [dict(delta=aq.delta, zero_point=z, n_bits=8, sym=False)])
+    assert (out.cpu() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------
+# K5 / K9
+# ------------------------------------------------------------------------------------------------
+def _code_mismatch(got, want):
+    diff = (got.long() - want.long()).abs()
+    return diff.max().item(), (diff > 0).float().mean().item()
+
+
+@pytest.mark.parametrize("silu", [True, False])
+@pytest.mark.parametrize("C,S", [(64, 100), (320, 64), (1920, 16)])
+def test_groupnorm_silu_quant(cuda, silu, C, S):
+    """float path differs from torch GroupNorm by rounding only, so codes may flip by one on exact
+    ties: allow <= 0.1 % of elements off by one code, none by more."""
+    from qdiff import engine, hip
+    g = torch.Generator().manual_seed(7)
+    B = 3
+    x = torch.randn(B, C, 1, S, generator=g) * 2 + 0.3
+    gn = torch.nn.GroupNorm(32, C, eps=1e-6)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C, generator=g))
+        gn.bias.copy_(torch.randn(C, generator=g))
+        y = gn(x)
+        y = R.silu(y) if silu else y
+    d, z = R.uaq_init_scale(y, 8, False, False, "max")
+    want = R.uaq_codes(y, d, z, 8, False) - 128
+    rows = x.to(cuda).permute(0, 2, 3, 1).reshape(B * S, C).contiguous()
+    ws = torch.empty(hip.groupnorm_ws_bytes(B, C, S), dtype=torch.uint8, device=cuda)
+    out = torch.empty((B * S, C), dtype=torch.int8, device=cuda)
+    yo = torch.empty((B * S, C), dtype=torch.float32, device=cuda)
+    hip.groupnorm_silu_quant(rows, B, S, C, C, 32, 1e-6, gn.weight.data.to(cuda), gn.bias.data.to(cuda), silu,
+                             torch.tensor([float(d), float(z)], device=cuda), engine.act_grid(8, False), out, C, ws, yout=yo, ldy=C)
+    torch.cuda.synchronize()
+    yref = y.permute(0, 2, 3, 1).reshape(B * S, C)
+    assert (yo.cpu() - yref).abs().max().item() <= 1e-5 * max(1.0, yref.abs().max().item())
+    mx, frac = _code_mismatch(out.cpu(), want.permute(0, 2, 3, 1).reshape(B * S, C))
+    assert mx <= 1 and frac <= 1e-3
+
+
+def test_layernorm_quant_three_consumers(cuda):
+    from qdiff import engine, hip
+    g = torch.Generator().manual_seed(8)
+    M, C = 70, 320
+    x = torch.randn(M, C, generator=g) * 1.7
+    ln = torch.nn.LayerNorm(C)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(C, generator=g))
+        ln.bias.copy_(torch.randn(C, generator=g))
+        y = ln(x)
+    params = [(0.031, 120), (0.02, 133), (0.05, 100)]
+    outs = [torch.empty((M, C), dtype=torch.int8, device=cuda) for _ in params]
+    hip.layernorm_quant(x.to(cuda), M, C, C, ln.eps, ln.weight.data.to(cuda), ln.bias.data.to(cuda),
+                        [torch.tensor([d, float(z)], device=cuda) for d, z in params], [engine.act_grid(8, False)] * 3, outs, C)
+    torch.cuda.synchronize()
+    for o, (d, z) in zip(outs, params):
+        mx, frac = _code_mismatch(o.cpu(), R.uaq_codes(y, torch.tensor(d), z, 8, False) - 128)
+        assert mx <= 1 and frac <= 1e-3
+
+
+def test_geglu_quant(cuda):
+    from qdiff import engine, hip
+    g = torch.Generator().manual_seed(9)
+    M, Fdim = 50, 640
+    h = torch.randn(M, 2 * Fdim, generator=g)
+    y = R.geglu(h)
+    d, z = R.uaq_init_scale(y, 8, False, False, "max")
+    out = torch.empty((M, Fdim), dtype=torch.int8, device=cuda)
+    hip.geglu_quant(h.to(cuda), M, Fdim, 2 * Fdim, torch.tensor([float(d), float(z)], device=cuda), engine.act_grid(8, False), out, Fdim)
+    torch.cuda.synchronize()
+    mx, frac = _code_mismatch(out.cpu(), R.uaq_codes(y, d, z, 8, False) - 128)
+    assert mx <= 1 and frac <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# K7/K8
+# ------------------------------------------------------------------------------------------------
+ATTN_CASES = [
+    # name, B, H, T, S, d, sm_bits, sym, scale
+    ("sd_self_d40", 2, 8, 96, 96, 40, 16, False, 40 ** -0.5),
+    ("sd_cross_77", 2, 8, 64, 77, 80, 16, False, 80 ** -0.5),
+    ("sd_d160", 1, 8, 64, 64, 160, 16, False, 160 ** -0.5),
+    ("cifar_c256_sym", 2, 1, 256, 256, 256, 8, True, 256 ** -0.5),
+    ("cifar_mid_T16", 2, 1, 16, 16, 256, 8, True, 256 ** -0.5),
+    ("ldm_d32", 2, 14, 64, 64, 32, 8, False, 1.0),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
+def test_attention_fused(cuda, case):
+    """Fused attention vs the integer oracle (exact integer contractions, fp64 softmax): the only
+    fp work is the softmax, so 16-bit probability codes may differ by a few ulps of exp():
+    tolerance 2e-4 of the output range; vs the reference's fp32 simulation 1e-3."""
+    from qdiff import engine
+    name, B, H, T, S, d, smb, sym, scale = case
+    g = torch.Generator().manual_seed(12)
+    q = torch.randn(B, T, H * d, generator=g)
+    k = torch.randn(B, S, H * d, generator=g)
+    v = torch.randn(B, S, H * d, generator=g)
+    pre = (d ** -0.25) if name.startswith("ldm") else 1.0
+
+    def mk(t, n_bits=8, s=sym, always_zero=False):
+        dd, zz = R.uaq_init_scale(t, n_bits, s, False, "max", always_zero)
+        return dict(delta=dd, zero_point=zz, n_bits=n_bits, sym=s)
+    aq_q, aq_k, aq_v = mk(q * pre), mk(k * pre), mk(v)
+    heads = lambda t, L: t.view(B, L, H, d).permute(0, 2, 1, 3).reshape(B * H, L, d)
+    with torch.no_grad():
+        sim = torch.einsum("bid,bjd->bij", heads(q, T) * pre, heads(k, S) * pre) * scale
+        p = sim.softmax(-1)
+    w_sym = sym if name.startswith("cifar") else False
+    aq_w = mk(p, smb, w_sym, always_zero=not name.startswith("cifar"))
+    want_int, _ = R.attention_int(heads(q, T), heads(k, S), heads(v, S), scale, aq_q, aq_k, aq_v, aq_w, pre_scale=pre)
+    want_fq = R.attention_fq(heads(q, T), heads(k, S), heads(v, S), scale, aq_q, aq_k, aq_v, aq_w, pre_scale=pre)
+    ns = lambda a: NS(delta=a["delta"], zero_point=a["zero_point"], n_bits=a["n_bits"], sym=a["sym"])
+    ap = engine.build_attn_plan(ns(aq_q), ns(aq_k), ns(aq_v), ns(aq_w), scale, pre, cuda)
+    C = H * d
+    out = engine.attention(ap, q.to(cuda), k.to(cuda), v.to(cuda), B, T, S, H, d,
+                           (T * C, C, d, 1), (S * C, C, d, 1), (S * C, C, d, 1))
+    torch.cuda.synchronize()
+    got = out.cpu().view(B, T, H, d).permute(0, 2, 1, 3).reshape(B * H, T, d)
+    rng = want_int.abs().max().item()
+    assert (got.double() - want_int).abs().max().item() <= 2e-4 * rng
+    assert (got - want_fq).abs().max().item() <= 1e-3 * rng
