@@ -108,7 +108,7 @@ def pack_module_weights(weight, quantizers, split):
         if alpha is not None:
             if getattr(q, "soft_targets", False):
                 raise hip.HipEngineError("AdaRound soft targets are a calibration-time mode; the integer engine packs hard rounding only")
-            alpha = alpha.detach().float().contiguous()
+            alpha = alpha.detach().to(device=dev, dtype=torch.float32).contiguous()
         wsum = torch.zeros(Cout, dtype=torch.int32, device=dev)
         hip.pack_weights(w, alpha, delta, z.contiguous(), Cout, Cin, taps, sg["c0w"], sg["clen"], levels, mode,
                          pk.wq, pk.ldk, sg["kofs"], wsum)

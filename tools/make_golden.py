@@ -1,0 +1,319 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.pt by running the REAL reference (/root/reference) on CPU.
+
+Run in the build container only (the GPU box has no /root/reference):
+    python tools/make_golden.py [ops] [cifar_tiny] [ldm_tiny] [sd_tiny] [cifar_full] [ldm_full] [sd_full]
+
+The reference's `qdiff`, `ldm`, `ddim` packages are imported read-only; this repo's package is NOT
+imported (both are called `qdiff`) — only q-diffusion_amd/qdiff/synthetic.py is loaded by path, so
+that reference and engine models receive identical key-derived weights.
+
+Each model fixture holds: the reference-format checkpoint's keys/shapes, every quantiser's
+delta / zero_point (data-dependent initialisation performed by the reference's own code), seeds of
+the inputs, and the reference's output after its own `resume_cali_model` round trip.
+"""
+import importlib.util
+import json
+import os
+import sys
+import tempfile
+import time
+import types
+from types import SimpleNamespace as NS
+
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, REF)
+
+# --- shims (test side only; reference files untouched) -------------------------------------------
+_oc = types.ModuleType("omegaconf")
+_lc = types.ModuleType("omegaconf.listconfig")
+_lc.ListConfig = type("ListConfig", (list,), {})
+_oc.listconfig = _lc
+sys.modules.setdefault("omegaconf", _oc)
+sys.modules.setdefault("omegaconf.listconfig", _lc)
+torch.Tensor.cuda = lambda self, *a, **k: self      # resume_cali_model hard-codes .cuda() (utils.py:390-393)
+
+spec = importlib.util.spec_from_file_location("amd_synthetic", os.path.join(ROOT, "q-diffusion_amd", "qdiff", "synthetic.py"))
+synthetic = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(synthetic)
+
+from qdiff import QuantModel  # noqa: E402  (the reference's)
+from qdiff.adaptive_rounding import AdaRoundQuantizer  # noqa: E402
+from qdiff.quant_layer import QuantModule, UniformAffineQuantizer  # noqa: E402
+from qdiff.utils import convert_adaround, resume_cali_model  # noqa: E402
+
+
+def cifar_cfg(tiny, split=True):
+    if tiny:
+        model = NS(type="simple", in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 2], num_res_blocks=1,
+                   attn_resolutions=[8], dropout=0.1, resamp_with_conv=True)
+        data = NS(image_size=16, channels=3)
+    else:
+        model = NS(type="simple", in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 2, 2], num_res_blocks=2,
+                   attn_resolutions=[16], dropout=0.1, resamp_with_conv=True)
+        data = NS(image_size=32, channels=3)
+    return NS(model=model, data=data, diffusion=NS(num_diffusion_timesteps=1000), split_shortcut=split)
+
+
+MODELS = {
+    # name: (family, unet kwargs | cfg, wq, aq, sm_abit, split, input shape, context shape)
+    "cifar_tiny": dict(family="cifar", tiny=True, w_bits=8, a_bits=8, a_sym=True, sm_abit=8, split=True, x=(3, 16, 16), ctx=None),
+    "cifar_full": dict(family="cifar", tiny=False, w_bits=8, a_bits=8, a_sym=True, sm_abit=8, split=True, x=(3, 32, 32), ctx=None),
+    "ldm_tiny": dict(family="ldm", w_bits=4, a_bits=8, a_sym=True, sm_abit=8, split=True, x=(3, 16, 16), ctx=None,
+                     unet=dict(image_size=16, in_channels=3, out_channels=3, model_channels=32, attention_resolutions=[2, 1],
+                               num_res_blocks=1, channel_mult=[1, 2], num_head_channels=16)),
+    "sd_tiny": dict(family="ldm", w_bits=4, a_bits=8, a_sym=False, sm_abit=16, split=True, x=(4, 16, 16), ctx=(7, 48),
+                    unet=dict(image_size=16, in_channels=4, out_channels=4, model_channels=64, attention_resolutions=[2, 1],
+                              num_res_blocks=1, channel_mult=[1, 2], num_heads=4, use_spatial_transformer=True,
+                              transformer_depth=1, context_dim=48, use_checkpoint=True, legacy=False)),
+    "ldm_full": dict(family="ldm", w_bits=4, a_bits=8, a_sym=True, sm_abit=8, split=True, x=(3, 64, 64), ctx=None,
+                     unet=dict(image_size=64, in_channels=3, out_channels=3, model_channels=224, attention_resolutions=[8, 4, 2],
+                               num_res_blocks=2, channel_mult=[1, 2, 3, 4], num_head_channels=32)),
+    "sd_full": dict(family="ldm", w_bits=4, a_bits=8, a_sym=False, sm_abit=16, split=True, x=(4, 64, 64), ctx=(77, 768),
+                    unet=dict(image_size=32, in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1],
+                              num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+                              transformer_depth=1, context_dim=768, use_checkpoint=True, legacy=False)),
+}
+
+
+def build_fp(spec):
+    if spec["family"] == "cifar":
+        from ddim.models.diffusion import Model
+        m = Model(cifar_cfg(spec["tiny"], spec["split"]))
+    else:
+        from ldm.modules.diffusionmodules.openaimodel import UNetModel
+        m = UNetModel(**spec["unet"])
+        m.split = bool(spec["split"])
+    m.load_state_dict(synthetic.fill_state_dict(m.state_dict(), seed=0))
+    return m.eval()
+
+
+def quant_params(spec):
+    wq = dict(n_bits=spec["w_bits"], channel_wise=True, scale_method="max")
+    aq = dict(n_bits=spec["a_bits"], channel_wise=False, scale_method="max", leaf_param=True)
+    if spec["a_sym"]:
+        aq["symmetric"] = True
+    return wq, aq
+
+
+def inputs(spec, batch, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((batch,) + tuple(spec["x"]), generator=g)
+    t = torch.randint(0, 1000, (batch,), generator=g)
+    if spec["family"] == "cifar":
+        t = t.float()
+    c = torch.randn((batch,) + tuple(spec["ctx"]), generator=g) if spec["ctx"] else None
+    return x, t, c
+
+
+def call(qnn, x, t, c):
+    with torch.no_grad():
+        return qnn(x, t, c) if c is not None else qnn(x, t)
+
+
+def make_model_fixture(name):
+    spec = MODELS[name]
+    t0 = time.time()
+    wq, aq = quant_params(spec)
+    cal = inputs(spec, 1, seed=100)
+    test = inputs(spec, 2, seed=200)
+
+    # 1) reference: data-dependent init of every quantiser, AdaRound conversion, key-derived alpha
+    qnn = QuantModel(build_fp(spec), wq, aq, sm_abit=spec["sm_abit"]).eval()
+    qnn.set_quant_state(True, True)
+    call(qnn, *cal)
+    convert_adaround(qnn)
+    for key, mod in qnn.named_modules():
+        if isinstance(mod, AdaRoundQuantizer):
+            mod.alpha.data.copy_(synthetic.tensor_for(key + ".alpha", mod.alpha.shape, seed=0))
+    # 2) the reference's save sequence (scripts/sample_diffusion_ddim.py:223-234)
+    for m in qnn.model.modules():
+        if isinstance(m, AdaRoundQuantizer):
+            m.zero_point = nn.Parameter(m.zero_point)
+            m.delta = nn.Parameter(m.delta)
+        elif isinstance(m, UniformAffineQuantizer) and m.zero_point is not None:
+            zp = m.zero_point if torch.is_tensor(m.zero_point) else torch.tensor(float(m.zero_point))
+            m.zero_point = nn.Parameter(zp)
+    ckpt = {k: v.detach().clone() for k, v in qnn.state_dict().items()}
+    del qnn
+    # 3) the reference's resume path on a fresh model, then the golden forward
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "ckpt.pth")
+        torch.save(ckpt, path)
+        qnn2 = QuantModel(build_fp(spec), wq, aq, sm_abit=spec["sm_abit"]).eval()
+        cali = tuple(a for a in cal if a is not None)
+        resume_cali_model(qnn2, path, cali, quant_act=True, cond=spec["ctx"] is not None)
+    out_wa = call(qnn2, *test)
+    qnn2.set_quant_state(True, False)
+    out_w = call(qnn2, *test)
+    qnn2.set_quant_state(False, False)
+    out_fp = call(qnn2, *test)
+
+    leafs = ("delta", "zero_point")
+    fixture = dict(
+        name=name, spec=spec,
+        keys=[(k, list(v.shape)) for k, v in ckpt.items()],
+        qparams={k: v.clone() for k, v in ckpt.items() if k.rsplit(".", 1)[-1] in leafs},
+        cal_seed=100, test_seed=200, out_wa=out_wa.clone(), out_w=out_w.clone(), out_fp=out_fp.clone(),
+        n_quant_modules=sum(isinstance(m, QuantModule) for m in qnn2.modules()),
+        torch_version=torch.__version__,
+    )
+    os.makedirs(OUT, exist_ok=True)
+    torch.save(fixture, os.path.join(OUT, f"model_{name}.pt"))
+    nbytes = os.path.getsize(os.path.join(OUT, f"model_{name}.pt"))
+    print(f"[golden] {name}: {len(ckpt)} keys, {fixture['n_quant_modules']} QuantModules, "
+          f"|out_wa|max={out_wa.abs().max():.4f}, file {nbytes / 1e6:.2f} MB, {time.time() - t0:.1f}s")
+
+
+# -------------------------------------------------------------------------------------------------
+# op-level known-answer vectors
+# -------------------------------------------------------------------------------------------------
+def make_op_fixtures():
+    import torch.nn.functional as F
+    from qdiff.quant_block import QuantAttnBlock, QuantBasicTransformerBlock, QuantQKMatMul, QuantSMVMatMul
+    from ddim.models.diffusion import AttnBlock, get_timestep_embedding
+    from ldm.modules.attention import BasicTransformerBlock
+    from ldm.modules.diffusionmodules.util import timestep_embedding
+    g = torch.Generator().manual_seed(7)
+    fx = {}
+
+    # UniformAffineQuantizer: init + forward, several grids (quant_layer.py:66-181)
+    cases = []
+    for (n_bits, sym, always_zero, method) in [(8, False, False, "max"), (8, True, False, "max"), (4, False, False, "max"),
+                                               (16, False, True, "max"), (8, False, False, "mse"), (8, True, False, "mse"),
+                                               (8, False, True, "mse")]:
+        x = torch.randn(3, 5, 7, generator=g) * 1.3 + (0.4 if not sym else 0.0)
+        if always_zero:
+            x = torch.softmax(x, dim=-1)
+        q = UniformAffineQuantizer(n_bits=n_bits, symmetric=sym, channel_wise=False, scale_method=method,
+                                   leaf_param=True, always_zero=always_zero)
+        y = q(x)
+        cases.append(dict(n_bits=n_bits, sym=sym, always_zero=always_zero, method=method, x=x, y=y.detach(),
+                          delta=q.delta.detach().clone(), zero_point=q.zero_point))
+    fx["uaq"] = cases
+
+    # channel-wise weight quantiser init (quant_layer.py:114-136) + AdaRound forward (adaptive_rounding.py:49-61)
+    wcases = []
+    for n_bits, shape in [(8, (6, 5, 3, 3)), (4, (6, 5, 3, 3)), (4, (7, 9)), (8, (5, 4, 1))]:
+        w = torch.randn(shape, generator=g) * 0.2
+        q = UniformAffineQuantizer(n_bits=n_bits, channel_wise=True, scale_method="max")
+        y_nearest = q(w)
+        ada = AdaRoundQuantizer(uaq=q, round_mode="learned_hard_sigmoid", weight_tensor=w)
+        alpha0 = ada.alpha.detach().clone()
+        y_init = ada(w).detach()
+        alpha = torch.rand(shape, generator=g) * 2 - 1
+        ada.alpha.data.copy_(alpha)
+        wcases.append(dict(n_bits=n_bits, w=w, delta=q.delta.clone(), zero_point=q.zero_point.clone(), y_nearest=y_nearest,
+                           alpha_init=alpha0, y_alpha_init=y_init, alpha=alpha, y_alpha=ada(w).detach()))
+    fx["weights"] = wcases
+
+    # QuantModule.forward (quant_layer.py:248-279): conv3x3, strided asym-pad conv, 1x1 split, conv1d, linear
+    mcases = []
+
+    def run_module(org, x, wq, aq, split=0, pre=None):
+        m = QuantModule(org, wq, aq)
+        m.set_quant_state(True, True)
+        with torch.no_grad():
+            xin = pre(x) if pre else x
+            y0 = m(xin, split=split) if split else m(xin)          # init pass (uniform quantisers)
+            convert_one = []
+            if split:
+                m.weight_quantizer = AdaRoundQuantizer(m.weight_quantizer, m.org_weight.data[:, :split], "learned_hard_sigmoid")
+                m.weight_quantizer_0 = AdaRoundQuantizer(m.weight_quantizer_0, m.org_weight.data[:, split:], "learned_hard_sigmoid")
+                convert_one = [m.weight_quantizer, m.weight_quantizer_0]
+            else:
+                m.weight_quantizer = AdaRoundQuantizer(m.weight_quantizer, m.org_weight.data, "learned_hard_sigmoid")
+                convert_one = [m.weight_quantizer]
+            alphas = []
+            for a in convert_one:
+                al = torch.rand(a.alpha.shape, generator=g) * 2 - 1
+                a.alpha.data.copy_(al)
+                alphas.append(al)
+            y = m(xin)
+        aqs = [m.act_quantizer] + ([m.act_quantizer_0] if split else [])
+        return dict(weight=org.weight.detach().clone(), bias=None if org.bias is None else org.bias.detach().clone(),
+                    x=x, y_uniform=y0, y=y, split=split, alphas=alphas,
+                    w_delta=[a.delta.clone() for a in convert_one], w_zp=[a.zero_point.clone() for a in convert_one],
+                    a_delta=[q.delta.detach().clone() for q in aqs], a_zp=[q.zero_point for q in aqs])
+
+    torch.manual_seed(3)
+    for wb, a_sym in [(8, True), (4, False), (8, False), (4, True)]:
+        wq = dict(n_bits=wb, channel_wise=True, scale_method="max")
+        aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True, symmetric=a_sym)
+        x = F.silu(torch.randn(2, 16, 9, 9, generator=g))
+        mcases.append(dict(kind="conv2d", w_bits=wb, a_sym=a_sym, kw=dict(stride=1, padding=1), **run_module(nn.Conv2d(16, 24, 3, padding=1), x, wq, aq)))
+        mcases.append(dict(kind="conv2d", w_bits=wb, a_sym=a_sym, kw=dict(stride=2, padding=0), asym_pad=True,
+                           **run_module(nn.Conv2d(16, 24, 3, stride=2, padding=0), x, wq, aq, pre=lambda v: F.pad(v, (0, 1, 0, 1)))))
+        xs = torch.cat([x, 3 * torch.randn(2, 8, 9, 9, generator=g)], dim=1)
+        mcases.append(dict(kind="conv2d", w_bits=wb, a_sym=a_sym, kw=dict(stride=1, padding=0), **run_module(nn.Conv2d(24, 12, 1), xs, wq, aq, split=16)))
+        mcases.append(dict(kind="conv1d", w_bits=wb, a_sym=a_sym, kw=dict(stride=1, padding=0), **run_module(nn.Conv1d(16, 48, 1), torch.randn(2, 16, 30, generator=g), wq, aq)))
+        mcases.append(dict(kind="linear", w_bits=wb, a_sym=a_sym, kw=dict(), **run_module(nn.Linear(40, 24), torch.randn(2, 11, 40, generator=g), wq, aq)))
+    fx["modules"] = mcases
+
+    # timestep embeddings
+    t = torch.tensor([0, 1, 17, 500, 999])
+    fx["temb"] = dict(t=t, ddim=get_timestep_embedding(t.float(), 128), ldm=timestep_embedding(t, 320), ldm_odd=timestep_embedding(t, 33))
+
+    # attention blocks with quantised activations
+    torch.manual_seed(5)
+    acases = []
+    for a_sym, sm in [(True, 8), (False, 8)]:
+        aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True, symmetric=a_sym)
+        blk = AttnBlock(32)
+        sd = synthetic.fill_state_dict(blk.state_dict(), seed=1)
+        blk.load_state_dict(sd)
+        qb = QuantAttnBlock(blk, aq, sm_abit=sm)
+        qb.use_act_quant = True
+        x = torch.randn(2, 32, 6, 6, generator=g)
+        with torch.no_grad():
+            y = qb(x)
+        acases.append(dict(kind="cifar_attn", a_sym=a_sym, sm_abit=sm, x=x, y=y, sd=sd,
+                           q={n: (getattr(qb, n).delta.detach().clone(), getattr(qb, n).zero_point) for n in
+                              ("act_quantizer_q", "act_quantizer_k", "act_quantizer_v", "act_quantizer_w")}))
+    for sm in (8, 16):
+        aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True)
+        blk = BasicTransformerBlock(64, 4, 16, context_dim=24, checkpoint=False)
+        sd = synthetic.fill_state_dict(blk.state_dict(), seed=2)
+        blk.load_state_dict(sd)
+        qb = QuantBasicTransformerBlock(blk, aq, sm_abit=sm)
+        qb.attn1.use_act_quant = qb.attn2.use_act_quant = True
+        x, ctx = torch.randn(2, 20, 64, generator=g), torch.randn(2, 5, 24, generator=g)
+        with torch.no_grad():
+            y = qb(x, ctx)
+        qs = {}
+        for an in ("attn1", "attn2"):
+            for n in ("act_quantizer_q", "act_quantizer_k", "act_quantizer_v", "act_quantizer_w"):
+                qz = getattr(getattr(qb, an), n)
+                qs[f"{an}.{n}"] = (qz.delta.detach().clone(), qz.zero_point)
+        acases.append(dict(kind="sd_transformer", sm_abit=sm, x=x, ctx=ctx, y=y, sd=sd, q=qs))
+    aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True, symmetric=True)
+    qk, smv = QuantQKMatMul(aq), QuantSMVMatMul(aq, sm_abit=8)
+    qk.scale = 16 ** -0.25
+    qk.use_act_quant = smv.use_act_quant = True
+    q_, k_, v_ = (torch.randn(6, 16, 12, generator=g) for _ in range(3))
+    with torch.no_grad():
+        w_ = qk(q_, k_)
+        p_ = torch.softmax(w_.float(), dim=-1)
+        a_ = smv(p_, v_)
+    acases.append(dict(kind="ldm_qk_smv", q=q_, k=k_, v=v_, scale=qk.scale, weight=w_, out=a_,
+                       qq={n: (getattr(qk, n).delta.detach().clone(), getattr(qk, n).zero_point) for n in ("act_quantizer_q", "act_quantizer_k")},
+                       qs={n: (getattr(smv, n).delta.detach().clone(), getattr(smv, n).zero_point) for n in ("act_quantizer_v", "act_quantizer_w")}))
+    fx["attention"] = acases
+
+    os.makedirs(OUT, exist_ok=True)
+    torch.save(fx, os.path.join(OUT, "ops.pt"))
+    print(f"[golden] ops.pt {os.path.getsize(os.path.join(OUT, 'ops.pt')) / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["ops", "cifar_tiny", "ldm_tiny", "sd_tiny"]
+    for w in what:
+        if w == "ops":
+            make_op_fixtures()
+        else:
+            make_model_fixture(w)
