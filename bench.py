@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoising images/sec, SD-v1.4 UNet W4A8 (sm_abit=16, split shortcut),
+512x512 (latent 4x64x64), PLMS 50 steps = 51 UNet evaluations per image at CFG batch 2n.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = one sampler step of the hot path on one batch of synthetic input: a UNet evaluation on
+the CFG-doubled batch (2n latents, context 77x768) through qdiff.QuantModel (HIP graph replay) +
+guidance combine + PLMS multistep update.  Weights are random-init (key-derived, qdiff/synthetic.py),
+quantisers are initialised from data exactly as the reference does on a first forward and converted to
+AdaRound with alpha ~ U(-1,1); no network, no checkpoints.  All inputs are resident in HBM before the
+timed region.  images/sec = N * n / (51 * seconds_per_step)   (51 evals per 50-step PLMS image batch).
+
+Extra objects on the JSON line:
+  roofline     — the dominant kernel class (igemm int8 MFMA contraction): algorithmic int ops of every
+                 launch of one UNet evaluation / their HIP-event durations on the launch stream.
+  cpu_baseline — the oracle (CPU port of the reference fake-quant forward, oracle/unet_ref.py) timed on
+                 this box's host cores for ONE UNet evaluation at batch 2 (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "q-diffusion_amd"))
+sys.path.insert(0, ROOT)
+
+I8_MFMA_PEAK_TOPS = 5000.0     # dense int8 MFMA = 2x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md); ubench ceiling 4404
+EVALS_PER_IMAGE_BATCH = 51     # PLMS S=50: 50 steps + 1 extra evaluation on the first step (plms.py:222-227)
+
+
+def build_quantised_unet(kind, device, seed=0):
+    import qdiff
+    from qdiff import synthetic
+    from qdiff.adaptive_rounding import AdaRoundQuantizer
+    from qdiff.arch import ddim_unet, ldm_unet
+    from qdiff.utils import convert_adaround
+    if kind == "sd":
+        model = ldm_unet.UNetModel(**ldm_unet.sd_v1_config())
+        model.split = True
+        wq = dict(n_bits=4, channel_wise=True, scale_method="max")
+        aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True)
+        sm_abit = 16
+    elif kind == "ldm":
+        model = ldm_unet.UNetModel(**ldm_unet.lsun_beds_config())
+        model.split = True
+        wq = dict(n_bits=4, channel_wise=True, scale_method="max")
+        aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True, symmetric=True)
+        sm_abit = 8
+    else:
+        model = ddim_unet.Model(ddim_unet.cifar10_config(split_shortcut=True))
+        wq = dict(n_bits=8, channel_wise=True, scale_method="max")
+        aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True, symmetric=True)
+        sm_abit = 8
+    synthetic.load_synthetic_weights(model, seed=seed)
+    model = model.to(device).eval()
+    qnn = qdiff.QuantModel(model, wq, aq, sm_abit=sm_abit).to(device).eval()
+    qnn.set_quant_state(True, True)
+    x, t, c = synthetic.synthetic_inputs(kind, 2, seed=seed)
+    args = [a.to(device) for a in (x, t, c) if a is not None]
+    with torch.no_grad():
+        qnn(*args)                                   # data-dependent init of every quantiser (+ split)
+    convert_adaround(qnn)
+    g = torch.Generator(device=device).manual_seed(1234 + seed)
+    for m in qnn.modules():
+        if isinstance(m, AdaRoundQuantizer):
+            m.alpha.data.copy_(torch.rand(m.alpha.shape, generator=g, device=device) * 2 - 1)
+    return qnn, dict(w_bits=wq["n_bits"], a_bits=8, a_sym=bool(aq.get("symmetric", False)), sm_abit=sm_abit)
+
+
+def measure_igemm(qnn, args):
+    """HIP events around every qd_conv2d_i8 launch of one eager UNet evaluation, on the launch stream."""
+    from qdiff import hip
+    records = []
+    orig = hip.conv2d_i8
+
+    def timed(call, acc_out=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st = torch.cuda.current_stream()
+        e0.record(st)
+        orig(call, acc_out)
+        e1.record(st)
+        k = call.kh * call.kw * sum(s["clen"] for s in call.segs)
+        m = call.B * call.Ho * call.Wo
+        records.append((e0, e1, 2.0 * m * k * call.Cout, m, call.Cout, k))
+    hip.conv2d_i8 = timed
+    try:
+        with torch.no_grad():
+            qnn.model(*args)
+        torch.cuda.synchronize()
+    finally:
+        hip.conv2d_i8 = orig
+    ms = sum(a.elapsed_time(b) for a, b, *_ in records)
+    ops = sum(r[2] for r in records)
+    return dict(launches=len(records), total_ms=ms, ops=ops)
+
+
+def cpu_baseline(qnn, qspec, kind, cfg):
+    from oracle import unet_ref as U
+    from qdiff import synthetic
+    from qdiff.utils import export_cali_state_dict
+    sd = {k: v.cpu() for k, v in export_cali_state_dict(qnn).items()}
+    Q = U.QuantCkpt(sd, qspec["w_bits"], qspec["a_bits"], qspec["a_sym"], qspec["sm_abit"])
+    x, t, c = synthetic.synthetic_inputs(kind, 2, seed=7)
+    t0 = time.time()
+    with torch.no_grad():
+        if kind == "cifar":
+            U.cifar_forward(Q, cfg, x, t, split_shortcut=True)
+        else:
+            U.ldm_forward(Q, cfg, x, t, c, split=True)
+    dt = time.time() - t0
+    return dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--images-per-gpu", type=int, default=8, help="n images per GPU (UNet batch 2n with CFG)")
+    ap.add_argument("--model", default="sd", choices=["sd", "ldm", "cifar"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the integer engine has no host path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    from qdiff import hip, sampling
+    hip.load()
+
+    kind, n = a.model, a.images_per_gpu
+    qnn, qspec = build_quantised_unet(kind, dev)
+    nbytes = sampling.broadcast_quant_state(qnn, src=0)          # the only collective: packed quant state over xGMI
+
+    from qdiff.arch import ldm_unet
+    if kind == "sd":
+        shape, ctx_shape, guide, evals = (4, 64, 64), (77, 768), 7.5, EVALS_PER_IMAGE_BATCH
+        betas = sampling.ldm_betas(0.00085, 0.0120)
+        ocfg = ldm_unet.sd_v1_config()
+    elif kind == "ldm":
+        shape, ctx_shape, guide, evals = (3, 64, 64), None, 1.0, 200
+        betas = sampling.ldm_betas(0.0015, 0.0195)
+        ocfg = ldm_unet.lsun_beds_config()
+    else:
+        shape, ctx_shape, guide, evals = (3, 32, 32), None, 1.0, 100
+        betas = sampling.ddpm_betas()
+        ocfg = dict(ch=128, ch_mult=[1, 2, 2, 2], num_res_blocks=2, attn_resolutions=[16], resolution=32)
+    table = sampling.StepTable(betas, 50 if kind == "sd" else (200 if kind == "ldm" else 100), eta=0.0)
+    gb = n * world
+    x = sampling.sharded_noise((gb,) + shape, seed=0, world_size=world, rank=rank, device=dev)
+    cond = uncond = None
+    if ctx_shape:
+        cond = sampling.sharded_noise((gb,) + ctx_shape, 1, world, rank, dev)
+        uncond = sampling.sharded_noise((gb,) + ctx_shape, 2, world, rank, dev)
+    if not a.no_graph:
+        qnn.enable_hip_graphs(True)
+
+    def unet(xx, tt, cc=None):
+        return qnn(xx, tt, cc) if cc is not None else qnn(xx, tt.float() if kind == "cifar" else tt)
+
+    state = dict(x=x, old=[], i=0)
+
+    def one_step():
+        i = state["i"] % len(table)
+        index = len(table) - i - 1
+        t = torch.full((state["x"].shape[0],), int(table.timesteps[index]), device=dev, dtype=torch.long)
+        e = sampling.guided_eps(unet, state["x"], t, cond, uncond, guide)
+        old = state["old"]
+        if kind == "sd" and len(old) >= 3:
+            e_prime = (55 * e - 59 * old[-1] + 37 * old[-2] - 9 * old[-3]) / 24
+        else:
+            e_prime = e
+        state["x"], _ = table.update(state["x"], e_prime, index)
+        old.append(e)
+        if len(old) >= 4:
+            old.pop(0)
+        state["i"] += 1
+
+    with torch.no_grad():
+        for _ in range(max(a.warmup, 4 if kind == "sd" else 1)):
+            one_step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            one_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(state["x"]).all(), "sampler state diverged"
+
+    ms_per_step = 1000.0 * elapsed / a.steps
+    images_per_s = gb / (evals * ms_per_step / 1000.0)
+    out = {
+        "metric": "denoising images/sec (whole node), SD-v1.4 W4A8 512x512 50-step PLMS" if kind == "sd" else f"denoising images/sec ({kind})",
+        "value": round(images_per_s, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int8xint4->int32 (fp32 residual stream)", "data": "synthetic",
+        "config": {"workload": f"{kind} UNet eval batch {2 * n if guide != 1.0 else n} per GPU, {evals} evals per image batch, "
+                               f"W{qspec['w_bits']}A8 sm_abit={qspec['sm_abit']} split, hip-graph={'off' if a.no_graph else 'on'}",
+                   "images_per_gpu": n, "global_batch": gb, "single_unet_step_ms": round(ms_per_step, 4),
+                   "parallelism": f"batch-sharded x{world}, quant-state broadcast {nbytes} B"},
+    }
+    if rank == 0:
+        # ---- roofline of the dominant kernel class (live HIP events, eager launches) ----------------
+        xb = state["x"]
+        tb = torch.full((xb.shape[0],), 500, device=dev, dtype=torch.long)
+        if guide != 1.0:
+            margs = [torch.cat([xb] * 2), torch.cat([tb] * 2), torch.cat([uncond, cond])]
+        else:
+            margs = [xb, tb.float() if kind == "cifar" else tb]
+        measure_igemm(qnn, margs)                      # warm (eager path, caches)
+        r = measure_igemm(qnn, margs)
+        ach = r["ops"] / (r["total_ms"] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
+                           "frac": round(ach / I8_MFMA_PEAK_TOPS, 4), "traffic": None,
+                           "kernel": "igemm_kernel (qd_conv2d_i8)", "launches_per_eval": r["launches"],
+                           "avg_launch_us": round(1000.0 * r["total_ms"] / r["launches"], 2),
+                           "igemm_ms_per_eval": round(r["total_ms"], 3), "algorithmic_GOP_per_eval": round(r["ops"] / 1e9, 1)}
+        if world == 1 and not a.no_cpu_baseline:
+            dt = cpu_baseline(qnn, qspec, kind, ocfg)
+            # one eval at batch 2 = one image's CFG pair (SD) / two images (unconditional models)
+            imgs = 1 if guide != 1.0 else 2
+            out["cpu_baseline"] = {"value": round(imgs / (evals * dt), 6), "unit": "images/s", "cores": torch.get_num_threads(),
+                                   "kind": "port", "sample": f"1 UNet evaluation at batch 2 ({dt:.1f} s), extrapolated x{evals} evals per image"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,12 +13,20 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+_FREQ_CACHE = {}
+
+
 def get_timestep_embedding(timesteps, embedding_dim):
     """sin|cos table with the fairseq/tensor2tensor (half-1) denominator (reference :6-24)."""
     assert timesteps.dim() == 1
     half = embedding_dim // 2
-    rate = math.log(10000) / (half - 1)
-    freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -rate).to(timesteps.device)
+    key = (embedding_dim, timesteps.device)
+    freqs = _FREQ_CACHE.get(key)
+    if freqs is None:
+        # host-computed like the reference, uploaded once: no H2D copy in the per-step forward
+        rate = math.log(10000) / (half - 1)
+        freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -rate).to(timesteps.device)
+        _FREQ_CACHE[key] = freqs
     ang = timesteps.float()[:, None] * freqs[None, :]
     emb = torch.cat([ang.sin(), ang.cos()], dim=1)
     if embedding_dim % 2:

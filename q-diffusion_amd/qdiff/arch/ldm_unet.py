@@ -15,12 +15,21 @@ import torch.nn.functional as F
 # ------------------------------------------------------------------------------------------------
 # small pieces (reference ldm/modules/diffusionmodules/util.py)
 # ------------------------------------------------------------------------------------------------
+_FREQ_CACHE = {}
+
+
 def timestep_embedding(timesteps, dim, max_period=10000, repeat_only=False):
     """cos|sin sinusoid table (reference util.py:151-171)."""
     if repeat_only:
         return timesteps[:, None].expand(-1, dim)
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(timesteps.device)
+    key = (dim, max_period, timesteps.device)
+    freqs = _FREQ_CACHE.get(key)
+    if freqs is None:
+        # computed on the host exactly as the reference does, uploaded once (keeps the per-step
+        # forward free of host->device copies, so it can be captured in a HIP graph)
+        freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(timesteps.device)
+        _FREQ_CACHE[key] = freqs
     ang = timesteps[:, None].float() * freqs[None]
     emb = torch.cat([ang.cos(), ang.sin()], dim=-1)
     if dim % 2:

@@ -1,0 +1,43 @@
+"""HIP-graph replay of a whole quantised UNet evaluation.
+
+One SD UNet evaluation is ~1.9k kernel launches (282 integer contractions + producers + attention);
+at sampling batch sizes the host cannot issue them fast enough through Python, so the launch-bound
+inner loop of the samplers (reference plms.py:142, ddim.py:143, denoising.py:16) is captured once per
+input shape into a hipGraph and replayed.  Everything the kernels read (packed weights, scales, zero
+points) already lives in device tensors (engine.py), so the capture contains no host read-backs.
+"""
+import torch
+
+
+class GraphedUNet:
+    def __init__(self, qnn, x, t, context=None, warmup=2):
+        self.qnn = qnn
+        self.sx, self.st = x.detach().clone(), t.detach().clone()
+        self.sc = context.detach().clone() if context is not None else None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):                      # quantiser init, weight packing, plan caches
+                self._eval()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out = self._eval()
+
+    def _eval(self):
+        if self.sc is not None:
+            return self.qnn.model(self.sx, self.st, self.sc)
+        return self.qnn.model(self.sx, self.st)
+
+    def __call__(self, x, t, context=None):
+        self.sx.copy_(x)
+        self.st.copy_(t)
+        if self.sc is not None:
+            self.sc.copy_(context)
+        self.graph.replay()
+        return self.out
+
+
+def signature(x, t, context):
+    return (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype,
+            None if context is None else (tuple(context.shape), context.dtype), x.device)

@@ -8,6 +8,7 @@ reference's.  On top of the reference surface it offers
 """
 import logging
 
+import torch
 import torch.nn as nn
 
 from .quant_block import (BaseQuantBlock, QuantAttentionBlock, QuantAttnBlock, QuantBasicTransformerBlock,
@@ -32,6 +33,7 @@ class QuantModel(nn.Module):
         self.quant_module_refactor(self.model, weight_quant_params, act_quant_params)
         self.quant_block_refactor(self.model, weight_quant_params, act_quant_params)
         self._graphs = None
+        self._quant_state = (False, False)
 
     def quant_module_refactor(self, module: nn.Module, weight_quant_params: dict = {}, act_quant_params: dict = {}):
         """Conv2d / Conv1d / Linear -> QuantModule, recursively (reference :25-43)."""
@@ -61,12 +63,26 @@ class QuantModel(nn.Module):
                 setattr(module, name, target(child, act_quant_params))
 
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
+        self._quant_state = (bool(weight_quant), bool(act_quant))
         for m in self.model.modules():
             if isinstance(m, (QuantModule, BaseQuantBlock)):
                 m.set_quant_state(weight_quant, act_quant)
 
     def forward(self, x, timesteps=None, context=None):
+        if self._graphs is not None and not torch.is_grad_enabled() and torch.is_tensor(timesteps) and x.is_cuda:
+            from .graph import GraphedUNet, signature
+            key = signature(x, timesteps, context) + (self._quant_state,)
+            g = self._graphs.get(key)
+            if g is None:
+                g = self._graphs[key] = GraphedUNet(self, x, timesteps, context)
+            return g(x, timesteps, context).clone()
         return self.model(x, timesteps, context)
+
+    def enable_hip_graphs(self, on: bool = True):
+        """Replay each (shape, quant-state) UNet evaluation as one HIP graph (qdiff/graph.py).
+        Quantiser parameters are baked into device tensors at capture; call again (or toggle the
+        quant state) after changing them."""
+        self._graphs = {} if on else None
 
     def set_running_stat(self, running_stat: bool, sm_only=False):
         """reference :71-87"""

@@ -1,0 +1,252 @@
+"""Sampler host loops that drive the quantised UNet, and their batch-sharded launcher.
+
+The reference keeps the samplers outside `qdiff` (ldm/models/diffusion/{plms,ddim}.py,
+ddim/functions/denoising.py) and they keep working unmodified on top of `qdiff.QuantModel`.  This
+module restates their update rules for deployments where those packages are absent (bench, tests,
+the GPU box) and adds what the reference lacks: one-process-per-GPU batch sharding with a single
+RCCL broadcast of the packed quantisation state.
+
+Differences from the reference loops, none of which change the arithmetic:
+  * no per-step device->host copies (denoising.py:24,30; plms.py:166-171 keep intermediates on CPU);
+  * per-step coefficients are precomputed once in fp32 (same values as the reference's torch.full
+    scalars) instead of being re-materialised as [B,1,1,1] tensors every step.
+"""
+import math
+
+import numpy as np
+import torch
+
+
+# ------------------------------------------------------------------------------------------------
+# schedules
+# ------------------------------------------------------------------------------------------------
+def ldm_betas(linear_start, linear_end, n_timestep=1000):
+    """'linear' schedule of ldm (util.py:21-26): linspace in sqrt space, squared; fp64."""
+    return (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2).numpy()
+
+
+def ddpm_betas(beta_start=0.0001, beta_end=0.02, n_timestep=1000):
+    """'linear' schedule of the DDIM code base (sample_diffusion_ddim.py:52-55)."""
+    return np.linspace(beta_start, beta_end, n_timestep, dtype=np.float64)
+
+
+def ddim_timesteps(method, num_ddim, num_ddpm):
+    """util.py:46-63 (the +1 shift included)."""
+    if method == "uniform":
+        steps = np.asarray(list(range(0, num_ddpm, num_ddpm // num_ddim)))
+    elif method == "quad":
+        steps = ((np.linspace(0, np.sqrt(num_ddpm * .8), num_ddim)) ** 2).astype(int)
+    else:
+        raise NotImplementedError(method)
+    return steps + 1
+
+
+def ddim_parameters(alphacums, steps, eta):
+    """util.py:66-78: (sigmas, alphas, alphas_prev) as fp64 numpy arrays."""
+    alphas = alphacums[steps]
+    alphas_prev = np.asarray([alphacums[0]] + alphacums[steps[:-1]].tolist())
+    sigmas = eta * np.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+    return sigmas, alphas, alphas_prev
+
+
+class StepTable:
+    """fp32 per-step coefficients of x_prev = sqrt(a_prev)*x0 + sqrt(1-a_prev-s^2)*e + s*noise with
+    x0 = (x - sqrt(1-a_t)*e)/sqrt(a_t)  (plms.py:203-218, ddim.py:196-219)."""
+
+    def __init__(self, betas, num_steps, eta=0.0, method="uniform"):
+        alphacums = np.cumprod(1.0 - betas, axis=0)
+        self.timesteps = ddim_timesteps(method, num_steps, betas.shape[0])
+        sig, a, ap = ddim_parameters(alphacums, self.timesteps, eta)
+        f32 = lambda v: torch.tensor(np.asarray(v), dtype=torch.float32)
+        a_t, a_prev, s_t = f32(a), f32(ap), f32(sig)
+        self.sqrt_one_minus_at = f32(np.sqrt(1.0 - a)).tolist()        # the reference takes this sqrt in fp64
+        self.sqrt_at = a_t.sqrt().tolist()
+        self.sqrt_aprev = a_prev.sqrt().tolist()
+        self.dir_coef = (1.0 - a_prev - s_t ** 2).sqrt().tolist()
+        self.sigma = s_t.tolist()
+
+    def __len__(self):
+        return len(self.timesteps)
+
+    def update(self, x, e, index, noise=None):
+        pred_x0 = (x - self.sqrt_one_minus_at[index] * e) / self.sqrt_at[index]
+        x_prev = self.sqrt_aprev[index] * pred_x0 + self.dir_coef[index] * e
+        if noise is not None and self.sigma[index] != 0.0:
+            x_prev = x_prev + self.sigma[index] * noise
+        return x_prev, pred_x0
+
+
+# ------------------------------------------------------------------------------------------------
+# samplers
+# ------------------------------------------------------------------------------------------------
+def guided_eps(unet, x, t, cond, uncond, scale):
+    """Classifier-free guidance on a doubled batch (plms.py:183-190 / ddim.py:176-193)."""
+    if uncond is None or scale == 1.0:
+        return unet(x, t, cond)
+    e_u, e_c = unet(torch.cat([x] * 2), torch.cat([t] * 2), torch.cat([uncond, cond])).chunk(2)
+    return e_u + scale * (e_c - e_u)
+
+
+@torch.no_grad()
+def plms_sample(unet, x_T, table, cond=None, uncond=None, scale=1.0, callback=None):
+    """PLMS (pseudo linear multistep) sampling, eta = 0: plms.py:115-173, 176-240.
+    `unet(x, t, context)` is the noise predictor; S steps cost S+1 evaluations."""
+    x = x_T
+    b, dev = x.shape[0], x.device
+    order = np.flip(table.timesteps)
+    total = len(order)
+    old = []
+    for i, step in enumerate(order):
+        index = total - i - 1
+        t = torch.full((b,), int(step), device=dev, dtype=torch.long)
+        e = guided_eps(unet, x, t, cond, uncond, scale)
+        if len(old) == 0:
+            x_euler, _ = table.update(x, e, index)
+            t_next = torch.full((b,), int(order[min(i + 1, total - 1)]), device=dev, dtype=torch.long)
+            e_next = guided_eps(unet, x_euler, t_next, cond, uncond, scale)
+            e_prime = (e + e_next) / 2
+        elif len(old) == 1:
+            e_prime = (3 * e - old[-1]) / 2
+        elif len(old) == 2:
+            e_prime = (23 * e - 16 * old[-1] + 5 * old[-2]) / 12
+        else:
+            e_prime = (55 * e - 59 * old[-1] + 37 * old[-2] - 9 * old[-3]) / 24
+        x, _ = table.update(x, e_prime, index)
+        old.append(e)
+        if len(old) >= 4:
+            old.pop(0)
+        if callback:
+            callback(i)
+    return x
+
+
+@torch.no_grad()
+def ddim_sample(unet, x_T, table, cond=None, uncond=None, scale=1.0, noise_fn=None):
+    """DDIM sampling (ddim.py:117-167, 170-220).  noise_fn(i, shape) supplies the per-step noise when
+    eta > 0 (full-batch-then-slice under sharding)."""
+    x = x_T
+    b, dev = x.shape[0], x.device
+    order = np.flip(table.timesteps)
+    total = len(order)
+    for i, step in enumerate(order):
+        index = total - i - 1
+        t = torch.full((b,), int(step), device=dev, dtype=torch.long)
+        e = guided_eps(unet, x, t, cond, uncond, scale)
+        noise = None
+        if table.sigma[index] != 0.0:
+            noise = noise_fn(i, x.shape) if noise_fn is not None else torch.randn(x.shape, device=dev)
+        x, _ = table.update(x, e, index, noise)
+    return x
+
+
+def quad_sequence(num_timesteps, steps):
+    """'quad' skip used for CIFAR (sample_diffusion_ddim.py:294-301)."""
+    seq = np.linspace(0, np.sqrt(num_timesteps * 0.8), steps) ** 2
+    return [int(s) for s in list(seq)]
+
+
+@torch.no_grad()
+def generalized_steps(unet, x, seq, betas, eta=0.0, noise_fn=None):
+    """DDIM 'generalized' sampling of the pixel-space code base (denoising.py:10-32), kept on device.
+    betas: fp32 tensor on x.device.  Returns the final x_0 estimate trajectory end (xs[-1])."""
+    n = x.size(0)
+    alphas = torch.cat([torch.zeros(1, device=betas.device), betas], dim=0)
+    alphas = (1 - alphas).cumprod(dim=0)
+    seq_next = [-1] + list(seq[:-1])
+    for k, (i, j) in enumerate(zip(reversed(seq), reversed(seq_next))):
+        t = torch.ones(n, device=x.device) * i
+        at = alphas[i + 1].view(1, 1, 1, 1)
+        at_next = alphas[j + 1].view(1, 1, 1, 1)
+        et = unet(x, t)
+        x0_t = (x - et * (1 - at).sqrt()) / at.sqrt()
+        c1 = eta * ((1 - at / at_next) * (1 - at_next) / (1 - at)).sqrt()
+        c2 = ((1 - at_next) - c1 ** 2).sqrt()
+        x = at_next.sqrt() * x0_t + c2 * et
+        if eta != 0.0:
+            noise = noise_fn(k, x.shape) if noise_fn is not None else torch.randn_like(x)
+            x = x + c1 * noise
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# batch sharding over the GPUs of one node (one process per GPU, RCCL over xGMI)
+# ------------------------------------------------------------------------------------------------
+def shard_bounds(global_batch, world_size, rank):
+    """Contiguous shard [lo, hi) of the batch owned by `rank` (remainder spread over low ranks)."""
+    base, rem = divmod(global_batch, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def sharded_noise(shape, seed, world_size, rank, device, stream_id=0):
+    """The reference draws x_T = randn(full_batch) once (plms.py:124, ddim.py:126): every rank draws
+    the FULL batch from the same seeded CPU generator and keeps its slice, so that the sharded run
+    reproduces the single-process samples bit for bit."""
+    g = torch.Generator().manual_seed(seed * 1000003 + stream_id)
+    full = torch.randn(shape, generator=g)
+    lo, hi = shard_bounds(shape[0], world_size, rank)
+    return full[lo:hi].to(device)
+
+
+def quant_state_tensors(qnn):
+    """Every device tensor the integer engine reads at run time, in a deterministic order: packed
+    int4/int8 weights, per-channel scales / zero-point corrections, activation (delta, zp) pairs."""
+    from .quant_layer import QuantModule
+    out = []
+    for _, m in sorted(qnn.model.named_modules(), key=lambda kv: kv[0]):
+        if isinstance(m, QuantModule) and m._plan is not None:
+            pk = m._plan.pack
+            out.append(pk.wq)
+            for sg in pk.segs:
+                out += [t for t in (sg["wsum"], sg["delta_w"], sg["zw"], sg["wzp"]) if t is not None]
+            for sg, qp in zip(m._plan.segs, m._plan.qparams):
+                out += [t for t in (sg["scale"], sg["zc"], sg["zfill"], qp) if t is not None]
+            if m._plan.bias is not None:
+                out.append(m._plan.bias)
+        cache = m.__dict__.get("_attn_plan_cache")
+        if cache and cache[1] is not None:
+            out.append(cache[1].prm)
+    return out
+
+
+def broadcast_quant_state(qnn, src=0, group=None):
+    """ONE collective at start-up: rank `src` owns the calibrated/packed quantisation state, every
+    other rank receives it in place (SD W4: ~0.43 GB of nibbles + a few MB of scales; over xGMI this is
+    milliseconds and the sampling loop itself has no communication).  Tensors are coalesced per dtype
+    into flat arenas so the wire sees a handful of large messages, not thousands of small ones."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    tensors = quant_state_tensors(qnn)
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    total = 0
+    for dtype, ts in sorted(by_dtype.items(), key=lambda kv: str(kv[0])):
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+        total += flat.numel() * flat.element_size()
+    return total
+
+
+def gather_samples(x_local, global_batch, group=None):
+    """all_gather of the final latents (4 MB for [64,4,64,64] fp32); ragged shards are padded."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return x_local
+    ws = dist.get_world_size(group)
+    per = math.ceil(global_batch / ws)
+    pad = torch.zeros((per,) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
+    pad[: x_local.shape[0]] = x_local
+    parts = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(parts, pad, group=group)
+    out = []
+    for r, p in enumerate(parts):
+        lo, hi = shard_bounds(global_batch, ws, r)
+        out.append(p[: hi - lo])
+    return torch.cat(out, dim=0)

@@ -1,0 +1,133 @@
+"""Whole-UNet parity of the HIP engine (through qdiff.QuantModel, the drop-in boundary) against the
+real reference's outputs (tests/golden/model_*.pt) and against the CPU oracle.
+
+Tolerance (tier T2, SURVEY.md §7 "Parity definition"): the engine accumulates exact integers where
+the reference accumulates fp32 products, so activations entering the NEXT quantiser differ by ~1e-7
+relative and occasionally flip a round() tie (one code, i.e. one delta, on isolated elements).
+Stated bound for (weight+act) quantised UNets on these random-init weights:
+    max|diff| <= 2e-2 * max|ref|   and   cosine >= 0.9995 ;
+weights-only and fp states run plain fp32 library convolutions: max|diff| <= 1e-3 * max|ref|.
+"""
+import os
+import tempfile
+
+import pytest
+import torch
+
+from golden_util import build_ckpt, build_engine_model, fixture_inputs, load_fixture, quant_params
+
+pytestmark = pytest.mark.gpu
+
+TINY = ["cifar_tiny", "ldm_tiny", "sd_tiny"]
+FULL = ["cifar_full", "ldm_full", "sd_full"]
+
+
+def _resume(fx, dev):
+    import qdiff
+    from qdiff.utils import resume_cali_model
+    spec = fx["spec"]
+    wq, aq = quant_params(spec)
+    model = build_engine_model(spec).to(dev)
+    qnn = qdiff.QuantModel(model, wq, aq, sm_abit=spec["sm_abit"]).to(dev).eval()
+    cal = tuple(a for a in fixture_inputs(fx, "cal") if a is not None)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "ckpt.pth")
+        torch.save(build_ckpt(fx), path)
+        resume_cali_model(qnn, path, cal, quant_act=True, cond=spec["ctx"] is not None)
+    return qnn
+
+
+def _run(qnn, fx, dev):
+    x, t, c = fixture_inputs(fx, "test")
+    with torch.no_grad():
+        y = qnn(x.to(dev), t.to(dev), c.to(dev)) if c is not None else qnn(x.to(dev), t.to(dev))
+    torch.cuda.synchronize()
+    return y.float().cpu()
+
+
+def _oracle64(fx):
+    """fp64 evaluation of the same fake-quant network (oracle tier T2x), or a stored copy."""
+    if "out_wa_oracle64" in fx:
+        return fx["out_wa_oracle64"].double()
+    if fx["name"].endswith("_full") and fx["name"] != "cifar_full":
+        return None
+    from golden_util import oracle_cfg
+    from oracle import unet_ref as U
+    spec = fx["spec"]
+    Q = U.QuantCkpt64(build_ckpt(fx), spec["w_bits"], spec["a_bits"], spec["a_sym"], spec["sm_abit"])
+    x, t, c = fixture_inputs(fx, "test")
+    with torch.no_grad():
+        if spec["family"] == "cifar":
+            return U.cifar_forward(Q, oracle_cfg(spec), x.double(), t, split_shortcut=spec["split"])
+        return U.ldm_forward(Q, oracle_cfg(spec), x.double(), t, None if c is None else c.double(), split=spec["split"])
+
+
+def _metrics(y, ref):
+    d = (y - ref).abs().max().item()
+    cos = torch.nn.functional.cosine_similarity(y.flatten(), ref.flatten(), dim=0).item()
+    return d, cos, ref.abs().max().item()
+
+
+@pytest.mark.parametrize("name", TINY + FULL)
+def test_quantised_unet_matches_reference(cuda, name):
+    fx = load_fixture(f"model_{name}.pt")
+    qnn = _resume(fx, cuda)
+    # every QuantModule must actually be on the integer path
+    import qdiff
+    mods = [m for m in qnn.modules() if isinstance(m, qdiff.QuantModule)]
+    assert len(mods) == fx["n_quant_modules"]
+    assert all(m.int_ready() for m in mods)
+    y = _run(qnn, fx, cuda)
+    assert all(m._plan is not None for m in mods), "a QuantModule did not run the integer kernel"
+    d, cos, mx = _metrics(y, fx["out_wa"])
+    print(f"\n[{name}] W+A vs reference fp32: max|diff|={d:.3e} ({d / mx:.2e} of range), cosine={cos:.7f}")
+    y64 = _oracle64(fx)
+    if y64 is not None:
+        d64, cos64, _ = _metrics(y.double(), y64)
+        dself, cosself, _ = _metrics(fx["out_wa"].double(), y64)
+        print(f"[{name}] engine vs fp64 oracle: {d64 / mx:.2e} (cos {cos64:.7f}) | reference fp32 vs fp64 oracle: "
+              f"{dself / mx:.2e} (cos {cosself:.7f})")
+    if name in TINY + ["cifar_full"]:
+        qnn.set_quant_state(True, False)
+        d, cos, mx = _metrics(_run(qnn, fx, cuda), fx["out_w"])
+        print(f"[{name}] W-only: max|diff|={d:.3e}")
+        assert d <= 1e-3 * mx
+        qnn.set_quant_state(False, False)
+        d, cos, mx = _metrics(_run(qnn, fx, cuda), fx["out_fp"])
+        print(f"[{name}] fp: max|diff|={d:.3e}")
+        assert d <= 1e-3 * mx
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_state_dict_schema_matches_reference(cuda, name):
+    """Key names and shapes of the saved checkpoint are the reference's."""
+    from qdiff.utils import export_cali_state_dict
+    fx = load_fixture(f"model_{name}.pt")
+    qnn = _resume(fx, cuda)
+    sd = export_cali_state_dict(qnn)
+    want = {k: tuple(s) for k, s in fx["keys"]}
+    got = {k: tuple(v.shape) for k, v in sd.items()}
+    assert got == want
+    # and the values survived the resume round trip
+    ck = build_ckpt(fx)
+    for k, v in sd.items():
+        assert torch.equal(v.cpu().float(), ck[k].float()), k
+    # attribute types after resume (reference utils.py:443-457)
+    from qdiff.adaptive_rounding import AdaRoundQuantizer
+    from qdiff.quant_layer import UniformAffineQuantizer
+    for m in qnn.modules():
+        if isinstance(m, AdaRoundQuantizer):
+            assert torch.is_tensor(m.delta) and not isinstance(m.delta, torch.nn.Parameter)
+        elif isinstance(m, UniformAffineQuantizer) and m.inited:
+            assert isinstance(m.zero_point, int) and isinstance(m.delta, torch.nn.Parameter)
+
+
+def test_quant_state_can_flip_between_forwards(cuda):
+    """set_quant_state may be toggled at any time: results are stable."""
+    fx = load_fixture("model_cifar_tiny.pt")
+    qnn = _resume(fx, cuda)
+    y1 = _run(qnn, fx, cuda)
+    qnn.set_quant_state(False, False)
+    _run(qnn, fx, cuda)
+    qnn.set_quant_state(True, True)
+    assert torch.equal(_run(qnn, fx, cuda), y1)
