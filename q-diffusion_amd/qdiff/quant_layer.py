@@ -327,6 +327,13 @@ class QuantModule(nn.Module):
         return self._wdq
 
     # -- integer plan -------------------------------------------------------------------------
+    def invalidate(self):
+        """Drop the packed weights / epilogue constants.  The caches below notice re-assigned
+        quantiser attributes and in-place updates that bump a tensor's version counter
+        (optimizer steps, load_state_dict, `p.mul_()` ...); writes through `.data` bypass version
+        tracking, so call this (or QuantModel.invalidate_plans()) after such an edit."""
+        self._pack_key = self._plan_key = self._wdq_key = None
+
     def conv_plan(self):
         """Packed weights + epilogue constants for the current quantiser state (lazy, cached)."""
         wqs, aqs = self._weight_quantizers(), self._act_quantizers()

@@ -78,6 +78,15 @@ class QuantModel(nn.Module):
             return g(x, timesteps, context).clone()
         return self.model(x, timesteps, context)
 
+    def invalidate_plans(self):
+        """Forget every packed weight / epilogue constant / captured graph (see QuantModule.invalidate)."""
+        for m in self.model.modules():
+            if isinstance(m, QuantModule):
+                m.invalidate()
+            m.__dict__.pop("_attn_plan_cache", None)
+        if self._graphs is not None:
+            self._graphs = {}
+
     def enable_hip_graphs(self, on: bool = True):
         """Replay each (shape, quant-state) UNet evaluation as one HIP graph (qdiff/graph.py).
         Quantiser parameters are baked into device tensors at capture; call again (or toggle the

@@ -54,12 +54,14 @@ class StepTable:
     x0 = (x - sqrt(1-a_t)*e)/sqrt(a_t)  (plms.py:203-218, ddim.py:196-219)."""
 
     def __init__(self, betas, num_steps, eta=0.0, method="uniform"):
-        alphacums = np.cumprod(1.0 - betas, axis=0)
+        # the reference keeps alphas_cumprod as an fp32 buffer (ddpm.py register_schedule) and derives every
+        # sampler coefficient from those fp32 values (plms.py:29-55): do the same
+        alphacums = np.cumprod(1.0 - betas, axis=0).astype(np.float32)
         self.timesteps = ddim_timesteps(method, num_steps, betas.shape[0])
-        sig, a, ap = ddim_parameters(alphacums, self.timesteps, eta)
+        sig, a, ap = ddim_parameters(alphacums.astype(np.float64), self.timesteps, eta)
         f32 = lambda v: torch.tensor(np.asarray(v), dtype=torch.float32)
         a_t, a_prev, s_t = f32(a), f32(ap), f32(sig)
-        self.sqrt_one_minus_at = f32(np.sqrt(1.0 - a)).tolist()        # the reference takes this sqrt in fp64
+        self.sqrt_one_minus_at = (1.0 - a_t).sqrt().tolist()
         self.sqrt_at = a_t.sqrt().tolist()
         self.sqrt_aprev = a_prev.sqrt().tolist()
         self.dir_coef = (1.0 - a_prev - s_t ** 2).sqrt().tolist()

@@ -1,0 +1,187 @@
+"""CPU emulation of the libqdiff_hip.so entry points, at the level of qdiff.hip's Python wrappers.
+
+TEST INFRASTRUCTURE.  The product never uses this: on a machine without the HIP library / GPU the
+`qdiff` integer path raises.  Tests that exercise *host logic* (plans, packing decisions, fused block
+wiring, checkpoint resume, sharding) on CPU install these functions over `qdiff.hip.*` with
+monkeypatch.  Each function follows the contract of include/qdiff_hip.h literally (packed weight
+layouts, stored-byte conventions, the zero-point restoration formula), using exact integer
+arithmetic (fp64 convolutions of integer-valued tensors) — so it doubles as an executable statement of
+the ABI.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _codes(x, qp, grid):
+    d, z = qp[0], qp[1]
+    return torch.clamp(torch.round(x / d) + z, grid.qmin, grid.qmax)
+
+
+def quantize_act(x, B, C, S, strides, qparams, grid, out, ldo, c0=0, clen=None, oc0=0):
+    clen = C - c0 if clen is None else clen
+    sb, sc, ss = strides
+    v = torch.as_strided(x, (B, C, S), (sb, sc, ss))[:, c0:c0 + clen].float()
+    q = (_codes(v, qparams, grid) - grid.off).to(torch.int8)            # [B, clen, S]
+    rows = out.view(-1, ldo)
+    pad = (clen + 15) // 16 * 16
+    rows[:, oc0:oc0 + clen] = q.permute(0, 2, 1).reshape(B * S, clen)
+    rows[:, oc0 + clen:oc0 + pad] = (qparams[1] - grid.off).round().to(torch.int8)
+
+
+def pack_weights(w, alpha, delta, zp, Cout, Cin_total, taps, c0, clen, n_levels, mode, wq, ldk, kofs, wsum, codes=None):
+    wv = w.reshape(Cout, Cin_total, taps)[:, c0:c0 + clen].float()
+    d, z = delta.view(-1, 1, 1), zp.view(-1, 1, 1)
+    if alpha is not None:
+        q = torch.floor(wv / d) + (alpha.reshape(Cout, clen, taps) >= 0).float()
+    else:
+        q = torch.round(wv / d)
+    code = torch.clamp(q + z, 0, n_levels - 1).to(torch.int64)
+    if codes is not None:
+        codes.copy_(code.to(torch.int32))
+    zi = z.to(torch.int64)
+    pad = (clen + 15) // 16 * 16
+    if mode == 4:
+        nib = torch.zeros(Cout, taps, pad, dtype=torch.int64)
+        nib[:, :, :clen] = code.permute(0, 2, 1)
+        ch = nib.view(Cout, taps, pad // 16, 16)
+        by = torch.empty(Cout, taps, pad // 16, 8, dtype=torch.int64)
+        for b in range(4):
+            by[..., b] = ch[..., b] | (ch[..., 4 + b] << 4)
+            by[..., 4 + b] = ch[..., 8 + b] | (ch[..., 12 + b] << 4)
+        rows = wq.view(Cout, taps, ldk // 2)
+        rows[:, :, kofs // 2:(kofs + pad) // 2] = by.view(Cout, taps, pad // 2).to(torch.uint8)
+        s = (code - zi).sum(dim=(1, 2)) - zi.view(-1) * (pad - clen) * taps
+    else:
+        stored = code - 128 if mode == 8 else code - zi
+        rows = wq.view(torch.int8).view(Cout, taps, ldk)
+        rows[:, :, kofs:kofs + pad] = 0
+        rows[:, :, kofs:kofs + clen] = stored.permute(0, 2, 1).to(torch.int8)
+        s = stored.sum(dim=(1, 2))
+    wsum += s.to(torch.int32)
+
+
+def _unpack_rows(c, seg):
+    """stored int64 weight bytes [Cout, taps, clen] of one segment (after the nibble unpack)."""
+    taps = c.kh * c.kw
+    if c.wbits == 4:
+        raw = c.w.view(c.Cout, taps, c.ldk // 2)[:, :, seg["kofs"] // 2:(seg["kofs"] + seg["clen"]) // 2].to(torch.int64)
+        lo, hi = raw & 15, raw >> 4
+        ch = torch.empty(c.Cout, taps, seg["clen"] // 16, 16, dtype=torch.int64)
+        lo, hi = lo.view(c.Cout, taps, -1, 8), hi.view(c.Cout, taps, -1, 8)
+        for b in range(4):
+            ch[..., b], ch[..., 4 + b] = lo[..., b], hi[..., b]
+            ch[..., 8 + b], ch[..., 12 + b] = lo[..., 4 + b], hi[..., 4 + b]
+        wz = seg.get("wzp")
+        z = wz.to(torch.int64).view(-1, 1, 1) if wz is not None else 0
+        return ch.view(c.Cout, taps, seg["clen"]) - z
+    return c.w.view(torch.int8).view(c.Cout, taps, c.ldk)[:, :, seg["kofs"]:seg["kofs"] + seg["clen"]].to(torch.int64)
+
+
+def conv2d_i8(c, acc_out=None):
+    B, H, W, Ho, Wo = c.B, c.H, c.W, c.Ho, c.Wo
+    x = c.x.view(B, H, W, c.ldx).to(torch.int64)
+    total = None
+    for seg in c.segs:
+        zf = seg.get("zfill")
+        zprime, kz = (int(zf[0]), int(zf[1])) if zf is not None else (0, 0)
+        xs = x[..., seg["c0"]:seg["c0"] + seg["clen"]].permute(0, 3, 1, 2).double()       # stored bytes, NCHW
+        pb = max((Ho - 1) * c.stride + c.kh - c.pad_t - H, 0)
+        pr = max((Wo - 1) * c.stride + c.kw - c.pad_l - W, 0)
+        xs = F.pad(xs, (c.pad_l, pr, c.pad_t, pb), value=float(zprime))                    # padded taps hold z'
+        ws = _unpack_rows(c, seg).view(c.Cout, c.kh, c.kw, seg["clen"]).permute(0, 3, 1, 2).double()
+        acc = F.conv2d(xs, ws, stride=c.stride)[:, :, :Ho, :Wo]
+        asum = F.conv2d(xs, torch.ones(1, seg["clen"], c.kh, c.kw, dtype=torch.float64), stride=c.stride)[:, :, :Ho, :Wo]
+        I = acc
+        if seg.get("zc") is not None:
+            I = I - seg["zc"].double().view(1, -1, 1, 1)
+        if seg.get("zw") is not None:
+            I = I - seg["zw"].double().view(1, -1, 1, 1) * (asum - kz)
+        if acc_out is not None:
+            acc_out.copy_(I.permute(0, 2, 3, 1).reshape(-1, c.Cout).round().to(torch.int32))
+            return
+        part = I.float() * seg["scale"].view(1, -1, 1, 1)
+        total = part if total is None else total + part
+    if c.bias is not None:
+        total = total + c.bias.view(1, -1, 1, 1)
+    if c.rowbias is not None:
+        total = total + c.rowbias[:, :c.Cout].view(B, c.Cout, 1, 1)
+    rows = total.permute(0, 2, 3, 1).reshape(-1, c.Cout)
+    if c.residual is not None:
+        rows = rows + c.residual[:, :c.Cout].float()
+    c.out[:, :c.Cout] = rows.to(c.out.dtype)
+
+
+def groupnorm_ws_bytes(B, C, S):
+    return 64
+
+
+def groupnorm_silu_quant(x, B, S, C, ldx, groups, eps, gamma, beta, silu, qparams, grid, out, ldo, ws, yout=None, ldy=0):
+    v = x[:, :C].float().view(B, S, C).permute(0, 2, 1)
+    y = F.group_norm(v, groups, gamma, beta, eps)
+    if silu:
+        y = y * torch.sigmoid(y)
+    rows = y.permute(0, 2, 1).reshape(B * S, C)
+    if yout is not None:
+        yout[:, :C] = rows
+    if out is not None:
+        out[:, :C] = (_codes(rows, qparams, grid) - grid.off).to(torch.int8)
+
+
+def layernorm_quant(x, M, C, ldx, eps, gamma, beta, qparams_list, grids, outs, ldo):
+    y = F.layer_norm(x[:, :C].float(), (C,), gamma, beta, eps)
+    for qp, g, o in zip(qparams_list, grids, outs):
+        o[:, :C] = (_codes(y, qp, g) - g.off).to(torch.int8)
+
+
+def geglu_quant(h, M, F_, ldh, qparams, grid, out, ldo):
+    y = h[:, :F_].float() * F.gelu(h[:, F_:2 * F_].float())
+    out[:, :F_] = (_codes(y, qparams, grid) - grid.off).to(torch.int8)
+
+
+def _perm_index(Tpad):
+    idx = torch.empty(Tpad, dtype=torch.long)
+    for p in range(Tpad):
+        tile, pp = divmod(p, 32)
+        half, r = divmod(pp, 16)
+        idx[p] = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half
+    return idx
+
+
+def quantize_heads(x, B, T, H, d, strides, prescale, qparams, grid, transpose, out, rsum, Tpad, dpad):
+    v = torch.as_strided(x, (B, T, H, d), strides).float() * prescale
+    q = (_codes(v, qparams, grid) - grid.off).to(torch.int64).permute(0, 2, 1, 3).reshape(B * H, T, d)
+    buf = torch.zeros(B * H, Tpad, dpad, dtype=torch.int64)
+    buf[:, :T, :d] = q
+    if not transpose:
+        out.copy_(buf.to(torch.int8))
+        if rsum is not None:
+            rsum.copy_(buf.sum(-1).to(torch.int32))
+    else:
+        out.copy_(buf.permute(0, 2, 1)[:, :, _perm_index(Tpad)].to(torch.int8))
+        if rsum is not None:
+            rsum.copy_(buf.sum(1).to(torch.int32))
+
+
+def attn_i8(q, k, vt, qsum, ksum, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, wmax, out, ldo):
+    cs, zq, zk, dw, zpw, osc, zv = (float(prm[i]) for i in range(7))
+    inv = torch.empty(Spad, dtype=torch.long)
+    inv[_perm_index(Spad)] = torch.arange(Spad)
+    qi = q.to(torch.int64)[:, :T, :d] - int(zq)
+    ki = k.to(torch.int64)[:, :S, :d] - int(zk)
+    vi = vt.to(torch.int64)[:, :, inv].permute(0, 2, 1)[:, :S, :d] - int(zv)
+    s = torch.einsum("bid,bjd->bij", qi.double(), ki.double()).float() * cs
+    p = torch.softmax(s, dim=-1)
+    u = torch.clamp(torch.round(p / dw) + zpw, wmin, wmax) - zpw
+    o = torch.einsum("bij,bjd->bid", u.double(), vi.double()).float() * osc
+    B = BH // H
+    out[:, :H * d] = o.view(B, H, T, d).permute(0, 2, 1, 3).reshape(B * T, H * d)
+
+
+def install(monkeypatch):
+    """Replace qdiff.hip's device entry points by the emulation (CPU tensors only)."""
+    from qdiff import hip
+    for name in ("quantize_act", "pack_weights", "conv2d_i8", "groupnorm_ws_bytes", "groupnorm_silu_quant",
+                 "layernorm_quant", "geglu_quant", "quantize_heads", "attn_i8"):
+        monkeypatch.setattr(hip, name, globals()[name])

@@ -315,5 +315,77 @@ if __name__ == "__main__":
     for w in what:
         if w == "ops":
             make_op_fixtures()
+        elif w == "samplers":
+            pass                     # handled at the end of the file (defined below this block)
         else:
             make_model_fixture(w)
+
+
+# -------------------------------------------------------------------------------------------------
+# sampler trajectories of the reference's own samplers driven by a stub eps-model
+# -------------------------------------------------------------------------------------------------
+def stub_eps(x, t, c=None):
+    """Deterministic stand-in for the UNet: smooth, t- and context-dependent, batch-independent."""
+    tt = t.float().view(-1, 1, 1, 1)
+    out = torch.tanh(0.3 * x + 1e-3 * tt) + 0.1 * torch.roll(x, 1, dims=-1)
+    if c is not None:
+        out = out + 0.05 * c.mean(dim=(1, 2)).view(-1, 1, 1, 1)
+    return out
+
+
+def make_sampler_fixtures():
+    import numpy as np
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.models.diffusion.plms import PLMSSampler
+    from ldm.modules.diffusionmodules.util import make_beta_schedule
+    from ddim.functions.denoising import generalized_steps
+    real_to = torch.Tensor.to
+
+    def to_shim(self, *a, **k):       # hard-coded 'cuda' in ddim.py:21-22, plms.py:20-21, denoising.py:21
+        a = tuple(torch.device("cpu") if (isinstance(x, str) and x.startswith("cuda")) or
+                  (isinstance(x, torch.device) and x.type == "cuda") else x for x in a)
+        return real_to(self, *a, **k)
+    torch.Tensor.to = to_shim
+
+    class Stub:
+        def __init__(self, ls, le):
+            betas = make_beta_schedule("linear", 1000, linear_start=ls, linear_end=le)
+            ac = np.cumprod(1. - betas, axis=0)
+            self.num_timesteps = 1000
+            self.betas = torch.tensor(betas, dtype=torch.float32)
+            self.alphas_cumprod = torch.tensor(ac, dtype=torch.float32)
+            self.alphas_cumprod_prev = torch.tensor(np.append(1., ac[:-1]), dtype=torch.float32)
+            self.device = torch.device("cpu")
+            self.calls = 0
+
+        def apply_model(self, x, t, c):
+            self.calls += 1
+            return stub_eps(x, t, c)
+
+    fx = {}
+    g = torch.Generator().manual_seed(11)
+    xT = torch.randn(3, 4, 8, 8, generator=g)
+    c, uc = torch.randn(3, 5, 6, generator=g), torch.randn(3, 5, 6, generator=g)
+    m = Stub(0.00085, 0.0120)
+    s = PLMSSampler(m)
+    out, _ = s.sample(S=50, conditioning=c, batch_size=3, shape=[4, 8, 8], verbose=False, unconditional_guidance_scale=7.5,
+                      unconditional_conditioning=uc, eta=0.0, x_T=xT)
+    fx["plms"] = dict(xT=xT, c=c, uc=uc, scale=7.5, steps=50, ls=0.00085, le=0.0120, out=out, calls=m.calls)
+    m = Stub(0.0015, 0.0195)
+    s = DDIMSampler(m)
+    xT3 = torch.randn(2, 3, 8, 8, generator=g)
+    out, _ = s.sample(S=20, batch_size=2, shape=[3, 8, 8], verbose=False, eta=0.0, x_T=xT3)
+    fx["ddim"] = dict(xT=xT3, steps=20, ls=0.0015, le=0.0195, out=out, calls=m.calls)
+    # pixel-space generalized steps, quad skip, eta = 0 (sample_diffusion_ddim.py:294-306)
+    betas = torch.from_numpy(np.linspace(0.0001, 0.02, 1000, dtype=np.float64)).float()
+    seq = [int(v) for v in list(np.linspace(0, np.sqrt(1000 * 0.8), 20) ** 2)]
+    x0 = torch.randn(2, 3, 8, 8, generator=g)
+    xs, _ = generalized_steps(x0, seq, lambda xx, tt: stub_eps(xx, tt), betas, eta=0.0)
+    fx["generalized"] = dict(x=x0, seq=seq, out=xs[-1])
+    torch.Tensor.to = real_to
+    torch.save(fx, os.path.join(OUT, "samplers.pt"))
+    print("[golden] samplers.pt", {k: tuple(v["out"].shape) for k, v in fx.items()}, "plms calls", fx["plms"]["calls"])
+
+
+if __name__ == "__main__" and "samplers" in sys.argv:
+    make_sampler_fixtures()
