@@ -1,11 +1,13 @@
 """Whole-UNet parity of the HIP engine (through qdiff.QuantModel, the drop-in boundary) against the
 real reference's outputs (tests/golden/model_*.pt) and against the CPU oracle.
 
-Tolerance (tier T2, SURVEY.md §7 "Parity definition"): the engine accumulates exact integers where
-the reference accumulates fp32 products, so activations entering the NEXT quantiser differ by ~1e-7
-relative and occasionally flip a round() tie (one code, i.e. one delta, on isolated elements).
-Stated bound for (weight+act) quantised UNets on these random-init weights:
-    max|diff| <= 2e-2 * max|ref|   and   cosine >= 0.9995 ;
+Tolerance (tier T2, SURVEY.md §7 "Parity definition"): the engine accumulates exact
+integers where the reference accumulates fp32 products, so activations entering the NEXT quantiser
+differ by ~1e-7 relative and occasionally flip a round() tie; a quantised network amplifies such
+flips.  The reference is subject to the same effect: evaluating the SAME fake-quant network in fp64
+(oracle tier T2x, QuantCkpt64) moves its output by 2.5e-2 .. 7e-2 of range.  Stated bound for
+(weight+act) quantised UNets:
+    max|engine - ref_fp32| <= 2 * max|ref_fp32 - ref_fp64| + 1e-3 * range   and   cosine >= 0.995 ;
 weights-only and fp states run plain fp32 library convolutions: max|diff| <= 1e-3 * max|ref|.
 """
 import os
@@ -82,11 +84,14 @@ def test_quantised_unet_matches_reference(cuda, name):
     d, cos, mx = _metrics(y, fx["out_wa"])
     print(f"\n[{name}] W+A vs reference fp32: max|diff|={d:.3e} ({d / mx:.2e} of range), cosine={cos:.7f}")
     y64 = _oracle64(fx)
-    if y64 is not None:
-        d64, cos64, _ = _metrics(y.double(), y64)
-        dself, cosself, _ = _metrics(fx["out_wa"].double(), y64)
-        print(f"[{name}] engine vs fp64 oracle: {d64 / mx:.2e} (cos {cos64:.7f}) | reference fp32 vs fp64 oracle: "
-              f"{dself / mx:.2e} (cos {cosself:.7f})")
+    assert y64 is not None, "fixture lacks the fp64-oracle envelope (tools/add_oracle64.py)"
+    d64, cos64, _ = _metrics(y.double(), y64)
+    dself, cosself, _ = _metrics(fx["out_wa"].double(), y64)
+    print(f"[{name}] engine vs fp64 oracle: {d64 / mx:.2e} (cos {cos64:.7f}) | reference fp32 vs fp64 oracle: "
+          f"{dself / mx:.2e} (cos {cosself:.7f})")
+    # bound relative to the reference's own rounding-noise envelope (module docstring)
+    assert d <= 2.0 * dself + 1e-3 * mx, f"{name}: {d / mx:.3e} of range vs envelope {dself / mx:.3e}"
+    assert cos >= 0.995
     if name in TINY + ["cifar_full"]:
         qnn.set_quant_state(True, False)
         d, cos, mx = _metrics(_run(qnn, fx, cuda), fx["out_w"])
