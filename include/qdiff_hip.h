@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 1
+#define QD_ABI_VERSION 2
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -94,12 +94,14 @@ typedef struct {
     int32_t        c0;       /* first channel of the segment inside an x row (bytes)              */
     int32_t        clen;     /* channel count, multiple of 16 (padded)                            */
     int32_t        kofs;     /* offset of the segment inside a weight tap row (elements)          */
-    int32_t        _pad;
-    const int8_t*  wzp;      /* [Cout] weight zero point subtracted at nibble unpack (wbits=4), or NULL */
+    int32_t        kstep0;   /* w_tiled: index of the segment's first 64-wide K-step in the tiled weight array */
+    const int8_t*  wzp;     /* [Cout] weight zero point subtracted at nibble unpack (wbits=4), or NULL */
     const float*   scale;    /* [Cout]  delta_x * delta_w[n]                                       */
     const int32_t* zc;       /* [Cout]  z' * Wsum[n]            or NULL (symmetric activations)    */
-    const int32_t* zw;       /* [Cout]  zw[n]-128               or NULL (int4 / direct-s8 weights) */
+    const int32_t* zw;       /* [Cout]  zw[n]-128 (int8 rows) | zw[n] (w_tiled int4) | NULL (row-major int4 / direct s8) */
     const int32_t* zfill;    /* [2] {z', K_seg*z'} device scalars or NULL (= 0)                    */
+    const int8_t*  fill16;   /* w_tiled: 16 bytes of z' — the source of out-of-image taps for the
+                                LDS-DMA loader — or NULL (= zeros)                                 */
 } qd_conv_seg;
 
 typedef struct {
@@ -115,10 +117,23 @@ typedef struct {
     int32_t        wbits;    /* 8 or 4                                                             */
     int32_t        out_dtype;/* QD_F32 / QD_F16                                                    */
     int32_t        nseg;     /* 1 or 2                                                             */
+    int32_t        w_tiled;  /* 1: w is the MFMA-tile-ordered nibble array of qd_pack_weights_t4   */
+    int32_t        _reserved;
     qd_conv_seg    seg[2];
 } qd_conv_desc;
 
 int qd_conv2d_i8(const qd_conv_desc* d, void* stream);
+
+/* K2b  tile-ordered int4 packer for the LDS-DMA contraction kernel (csrc/igemm_dma.hip).  Same code
+ *     formula as qd_pack_weights (adaptive_rounding.py:49-59).  Output wt[kstep][ntile][1024 B]:
+ *     kstep enumerates (tap, 64-channel step) of the slice starting at kstep0, ntile = n/32, and each
+ *     1-KB block is [ksub(2)][half(2)][n%32][8 B] = the 16 nibbles of row n for
+ *     K = ksub*32 + half*16 + 0..15 (nibble order inside the 8 bytes as in qd_pack_weights mode 4).
+ *     The stored operand is the RAW code W (0..15); its zero point is restored in the epilogue
+ *     through qd_conv_seg.zw[n] = zw[n] and activation row sums.  wsum[n] += sum W over the slice. */
+int qd_pack_weights_t4(const float* w, const float* alpha, const float* delta, const float* zp,
+                       int Cout, int Cin_total, int taps, int c0, int clen, int clen_pad, int n_levels,
+                       uint8_t* wt, int kstep0, int ntiles, int32_t* wsum, void* stream);
 
 /* Test hook: same contraction, but writes the raw int32 I_s[m][n] of segment 0 (after zero-point
  * restoration) to iout[M][Cout].  Used for the bit-exact accumulator tests (oracle tier T0). */

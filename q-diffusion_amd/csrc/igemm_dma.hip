@@ -1,0 +1,482 @@
+// igemm_dma.hip — second-generation K3/K4 kernel for int4 weights: LDS-DMA fed, 3-stage ring.
+//
+// Same contraction and epilogue as igemm_i8.hip (reference qdiff/quant_layer.py:256-276), different
+// data path.  What limited the first kernel was latency, not the matrix pipe: one K-step of
+// register-staged prefetch and a barrier per step.  Here
+//   * both operands are copied global -> LDS by the DMA path (global_load_lds, 16 B/lane, no VGPR
+//     round trip): activations per (tap, 64-channel step) with the im2col gather expressed in the
+//     per-lane SOURCE address — out-of-image taps read a 16-byte buffer of the "true zero" byte z',
+//     K-tail / M-tail lanes read zeros — and the LDS destination is lane-linear, so the XOR bank
+//     swizzle of the A tile is applied to the source chunk index instead;
+//   * weights are pre-tiled at pack time (qd_pack_weights_t4): one K-step x 32 output channels is a
+//     contiguous 1-KB block already in fragment order, so the B copy is a straight memcpy and the
+//     fragment read is a conflict-free ds_read_b64; nibbles are unpacked (and their zero point
+//     subtracted) at fragment-read time, which keeps 4-bit weights 4-bit all the way into LDS;
+//   * a 3-deep LDS ring keeps two K-steps in flight across the single barrier per step
+//     (counted s_waitcnt vmcnt(N), raw s_barrier: cdna_hip_programming.md §5 "Pipelining across
+//     barriers").
+// Block = 4 waves stacked along M; wave tile = (32*MT) x (32*NT) of 32x32x32 MFMAs, BN = 32*NT
+// (NT=5 -> 160 divides every SD-v1 width 320/640/1280/..., NT=7 -> 224 for LDM-4).
+#include "common.h"
+#include <type_traits>
+
+typedef __attribute__((address_space(3))) void* qd_lds_ptr;
+typedef const __attribute__((address_space(1))) void* qd_gbl_ptr;
+
+namespace {
+
+__device__ __attribute__((aligned(16))) const int qd_zero16[4] = {0, 0, 0, 0};
+
+struct SegD {
+    int c0, clen, kstep0, nsteps_tap;
+    const float*  scale;
+    const int*    zc;
+    const int*    zw;       // [Cout] weight zero point (raw nibbles are the stored operand)
+    const int*    zfill;
+    const int8_t* fill16;
+};
+
+struct ConvD {
+    const int8_t*  x;
+    const uint8_t* wt;
+    void*          out;
+    int32_t*       iout;
+    const float*   bias;
+    const float*   rowbias;
+    const void*    residual;
+    long ldx, ldo, ldr, ldrb;
+    int B, H, W, Ho, Wo, Cout, kh, kw, stride, pad_t, pad_l;
+    int M, taps, nseg, nblk_m, nblk_n, ntiles;
+    SegD seg[2];
+};
+
+enum { O_F32 = 0, O_F16 = 1, O_I32 = 2 };
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// 16-byte-per-lane global -> LDS DMA, issued through inline asm ON PURPOSE: with the builtin, hipcc
+// cannot prove that the pending LDS writes do not alias the next ds_read and inserts
+// `s_waitcnt vmcnt(0)` in front of every K-step's first LDS read, which drains the whole ring
+// (seen in the ISA of the first version of this kernel).  An asm DMA is invisible to the compiler's
+// waitcnt bookkeeping; completion is tracked by hand (wait_vmcnt<N> + s_barrier below).
+// LDS destination = lds_base (wave-uniform, bytes) + lane*16; M0 is written in the same statement
+// that reads it and restored (cdna_hip_programming.md §5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
+    // M0 is not live across statements in this kernel (no movrel / GWS / sendmsg / builtin LDS-DMA), so it is
+    // written and consumed inside the one statement and not restored.
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, off"
+        :
+        : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_base))
+        : "memory");
+}
+
+__device__ __forceinline__ int bytesum16(const v4i& v) {
+    int s = __builtin_amdgcn_sdot4(v.x, 0x01010101, 0, false);
+    s = __builtin_amdgcn_sdot4(v.y, 0x01010101, s, false);
+    s = __builtin_amdgcn_sdot4(v.z, 0x01010101, s, false);
+    return __builtin_amdgcn_sdot4(v.w, 0x01010101, s, false);
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(qd_lds_ptr)(p);
+}
+
+template <int MT, int NT, bool SPLIT, int OUT>
+__global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const ConvD p) {
+    constexpr int BM = 128 * MT, BN = 32 * NT;
+    constexpr int A_BYTES = BM * 64, B_BYTES = NT * 1024;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = 2 * MT;                    // A DMA instructions per wave per stage (16 rows each)
+    constexpr int NB = (NT * 16 + 63) / 64;       // B DMA instructions per wave per stage (NT*256 B per wave)
+    constexpr int PER = NA + NB;
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE + 2 * BM * 4];
+    int* sRowB = reinterpret_cast<int*>(smem + 3 * STAGE);
+    int* sAsum = sRowB + BM;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int frow = lane & 31, fhalf = lane >> 5;
+
+    const int nblk    = p.nblk_m * p.nblk_n;
+    const int logical = qd_xcd_remap(blockIdx.x, nblk);
+    const int mb = logical / p.nblk_n, nb = logical % p.nblk_n;
+    const int m0 = mb * BM, n0 = nb * BN;
+
+    // ---- loader rows: DMA instruction q covers tile rows q*16 .. q*16+15, lane -> (row, slot) ----
+    const int lr16 = lane >> 2, slot = lane & 3;
+    const int8_t* a_img[NA];                      // image origin (b, 0, 0, 0) of the row this lane feeds
+    int  a_ih0[NA], a_iw0[NA], a_chunk[NA];
+    bool a_valid[NA];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int r = (wave + 4 * i) * 16 + lr16;
+        const int m = m0 + r;
+        a_valid[i] = m < p.M;
+        const int mm = a_valid[i] ? m : 0;
+        const int b  = mm / HoWo;
+        const int rem = mm - b * HoWo;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        a_img[i]   = p.x + (long)b * p.H * p.W * p.ldx;
+        a_ih0[i]   = ho * p.stride - p.pad_t;
+        a_iw0[i]   = wo * p.stride - p.pad_l;
+        a_chunk[i] = (slot ^ ((r >> 2) & 3)) * 16;   // source byte offset (within a 64-B K-step) landing in this lane's LDS slot
+        if (slot == 0) sRowB[r] = b;
+    }
+
+    // ---- loader state (uniform) + per-lane running source pointers ------------------------------
+    int ls = 0, ltap = 0, lrr = 0, lq = 0, lc = 0;
+    const int8_t* a_cur[NA];                      // source of the NEXT K-step for DMA instruction i
+    int           a_inc[NA];                      // 64 for real pixels, 0 for fill / zero sources
+    const uint8_t* b_cur = p.wt + ((long)p.seg[0].kstep0 * p.ntiles + (long)nb * NT) * 1024 + wave * (NT * 256) + lane * 16;
+    const long b_inc = (long)p.ntiles * 1024;
+    const int8_t* zero16 = reinterpret_cast<const int8_t*>(qd_zero16);
+    bool b_ok[NB];                                // the last N-block may cover n-tiles that do not exist
+#pragma unroll
+    for (int r = 0; r < NB; ++r) b_ok[r] = nb * NT + (wave * (NT * 256) + r * 1024 + lane * 16) / 1024 < p.ntiles;
+
+    auto set_tap = [&]() __attribute__((always_inline)) {
+        const SegD& sg = p.seg[ls];
+        const int8_t* fill = sg.fill16 ? sg.fill16 : zero16;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int ih = a_ih0[i] + lrr, iw = a_iw0[i] + lq;
+            const bool inb = a_valid[i] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            a_cur[i] = inb ? a_img[i] + ((long)ih * p.W + iw) * p.ldx + sg.c0 + a_chunk[i] : (a_valid[i] ? fill : zero16);
+            a_inc[i] = inb ? 64 : 0;
+        }
+    };
+    set_tap();
+
+    // issue DMA instruction d of the current loader step into ring stage ST (compile-time LDS addresses)
+    auto issue_one = [&](unsigned stage_base, int d) __attribute__((always_inline)) {
+        if (d < NA) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                if (i == d) {
+                    const int8_t* src = a_cur[i];
+                    // K tail: the last 64-wide step of a tap may run past the segment's channels
+                    if (lc * 64 + a_chunk[i] >= p.seg[ls].clen) src = zero16;
+                    glds16(src, stage_base + (wave + 4 * i) * 1024);
+                    a_cur[i] += a_inc[i];
+                }
+        } else {
+            const int r = d - NA;
+#pragma unroll
+            for (int rr = 0; rr < NB; ++rr)
+                if (rr == r && rr * 64 + lane < NT * 16)
+                    glds16(b_ok[rr] ? (const void*)(b_cur + rr * 1024) : (const void*)zero16,
+                           stage_base + A_BYTES + wave * (NT * 256) + rr * 1024);
+        }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        b_cur += b_inc;
+        ++lc;
+        if (lc == p.seg[ls].nsteps_tap) {
+            lc = 0; ++ltap; ++lq;
+            if (lq == p.kw) { lq = 0; ++lrr; }
+            if (ltap == p.taps) { ltap = 0; lrr = 0; lq = 0; ++ls; }
+            if (ls < p.nseg) set_tap();
+        }
+    };
+
+    // ---- accumulators ---------------------------------------------------------------------------
+    v16i acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+    float facc[SPLIT ? MT : 1][SPLIT ? NT : 1][16];
+    if (SPLIT) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) facc[SPLIT ? i : 0][SPLIT ? j : 0][r] = 0.f;
+    }
+    int asum[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) asum[i] = 0;
+
+    auto publish_asum = [&]() __attribute__((always_inline)) {                 // row sums of this wave's rows -> LDS (both k-halves combined)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            int v = asum[i] + __shfl_xor(asum[i], 32);
+            if (fhalf == 0) sAsum[wave * (32 * MT) + i * 32 + frow] = v;
+            asum[i] = 0;
+        }
+    };
+
+    const int nst0  = p.taps * p.seg[0].nsteps_tap;
+    const int total = nst0 + (p.nseg == 2 ? p.taps * p.seg[1].nsteps_tap : 0);
+    const unsigned lds0 = lds_addr(smem);
+
+    // lane-invariant fragment offsets inside a stage
+    int a_off[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row = wave * (32 * MT) + i * 32 + frow;
+            a_off[i][ks] = row * 64 + (((ks * 2 + fhalf) ^ ((row >> 2) & 3)) * 16);
+        }
+    const int b_off = (fhalf * 32 + frow) * 8;   // + ks*512 + j*1024
+
+    // ---- prologue: two stages in flight ----------------------------------------------------------
+#pragma unroll
+    for (int d = 0; d < PER; ++d) issue_one(lds0, d);
+    advance();
+    if (total > 1) {
+#pragma unroll
+        for (int d = 0; d < PER; ++d) issue_one(lds0 + STAGE, d);
+        advance();
+    }
+
+    auto flush_segment0 = [&]() __attribute__((always_inline)) {
+        publish_asum();
+        __syncthreads();
+        const SegD& sg = p.seg[0];
+        const int kz = sg.zfill ? sg.zfill[1] : 0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + j * 32 + frow;
+            const bool nok = n < p.Cout;
+            const float sc = nok ? sg.scale[n] : 0.f;
+            const int zc_n = (nok && sg.zc) ? sg.zc[n] : 0;
+            const int zw_n = (nok && sg.zw) ? sg.zw[n] : 0;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rowl = wave * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                    const int I = acc[i][j][r] - zc_n - zw_n * (sAsum[rowl] - kz);
+                    facc[SPLIT ? i : 0][SPLIT ? j : 0][r] = (float)I * sc;
+                    acc[i][j][r] = 0;
+                }
+        }
+        __syncthreads();                               // sAsum is reused by the second segment
+    };
+
+    // one K-step on ring stage ST (compile-time), prefetching step it+2 into stage (ST+2)%3
+    auto step = [&](auto st_tag, int it) __attribute__((always_inline)) {
+        constexpr int ST = decltype(st_tag)::value;
+        constexpr int PST = (ST + 2) % 3;
+        if (it + 1 < total) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                  // stage ST landed for every wave; stage ST-1 fully consumed
+        const bool prefetch = it + 2 < total;
+        const unsigned char* cA = smem + ST * STAGE;
+        const unsigned char* cB = cA + A_BYTES;
+        int dslot = 0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v4i af[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                af[i] = *reinterpret_cast<const v4i*>(cA + a_off[i][ks]);
+                asum[i] += bytesum16(af[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const uint2 pk = *reinterpret_cast<const uint2*>(cB + b_off + ks * 512 + j * 1024);
+                const v4i bf = {(int)(pk.x & 0x0F0F0F0Fu), (int)((pk.x >> 4) & 0x0F0F0F0Fu),
+                                (int)(pk.y & 0x0F0F0F0Fu), (int)((pk.y >> 4) & 0x0F0F0F0Fu)};
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf, acc[i][j], 0, 0, 0);
+                if (dslot < PER) { if (prefetch) issue_one(lds0 + PST * STAGE, dslot); }
+                ++dslot;
+            }
+        }
+        if (prefetch) {
+#pragma unroll
+            for (int d = 2 * NT; d < PER; ++d) issue_one(lds0 + PST * STAGE, d);
+            advance();
+        }
+        if (SPLIT && p.nseg == 2 && it == nst0 - 1) flush_segment0();
+    };
+
+    for (int it = 0; it < total; it += 3) {
+        step(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < total) step(std::integral_constant<int, 1>{}, it + 1);
+        if (it + 2 < total) step(std::integral_constant<int, 2>{}, it + 2);
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------
+    publish_asum();
+    __syncthreads();                                   // sAsum / sRowB visible to every wave
+    const SegD& sg = p.seg[p.nseg - 1];
+    const int kz = sg.zfill ? sg.zfill[1] : 0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 32 + frow;
+        const bool nok = n < p.Cout;
+        const float sc = nok ? sg.scale[n] : 0.f;
+        const int zc_n = (nok && sg.zc) ? sg.zc[n] : 0;
+        const int zw_n = (nok && sg.zw) ? sg.zw[n] : 0;
+        const float bias_n = (nok && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowl = wave * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                const int m = m0 + rowl;
+                if (!nok || m >= p.M) continue;
+                const int I = acc[i][j][r] - zc_n - zw_n * (sAsum[rowl] - kz);
+                if (OUT == O_I32) {
+                    p.iout[(long)m * p.Cout + n] = I;
+                    continue;
+                }
+                float v = (float)I * sc;
+                if (SPLIT) v += facc[SPLIT ? i : 0][SPLIT ? j : 0][r];
+                v += bias_n;
+                if (p.rowbias) v += p.rowbias[(long)sRowB[rowl] * p.ldrb + n];
+                if (OUT == O_F32) {
+                    if (p.residual) v += reinterpret_cast<const float*>(p.residual)[(long)m * p.ldr + n];
+                    reinterpret_cast<float*>(p.out)[(long)m * p.ldo + n] = v;
+                } else {
+                    if (p.residual) v += __half2float(reinterpret_cast<const __half*>(p.residual)[(long)m * p.ldr + n]);
+                    reinterpret_cast<__half*>(p.out)[(long)m * p.ldo + n] = __float2half(v);
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tile-ordered nibble packer: thread = one 8-byte unit (row n, 16 consecutive K)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_t4_kernel(const float* __restrict__ w, const float* __restrict__ alpha,
+                                                      const float* __restrict__ delta, const float* __restrict__ zp,
+                                                      int Cout, int Cin_total, int taps, int c0, int clen, int clen_pad,
+                                                      int n_levels, uint8_t* __restrict__ wt, int kstep0, int ntiles,
+                                                      int nsteps_tap, int32_t* __restrict__ wsum) {
+    // unit index: (((tap*nsteps_tap + cs) * ntiles + jt) * 4 + (ksub*2+half)) * 32 + nn
+    long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)taps * nsteps_tap * ntiles * 128;
+    if (gid >= total) return;
+    const int nn = (int)(gid & 31);
+    const int kh4 = (int)((gid >> 5) & 3);
+    long rest = gid >> 7;
+    const int jt = (int)(rest % ntiles);
+    rest /= ntiles;
+    const int cs = (int)(rest % nsteps_tap);
+    const int t = (int)(rest / nsteps_tap);
+    const int n = jt * 32 + nn;
+    const int cbase = cs * 64 + kh4 * 16;
+    int vals[16];
+    int sum = 0;
+    float d = 1.f, z = 0.f;
+    if (n < Cout) { d = delta[n]; z = zp[n]; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = cbase + j;
+        int code = 0;
+        if (n < Cout && c < clen) {
+            const float wv = w[((long)n * Cin_total + c0 + c) * taps + t];
+            float q;
+            if (alpha) q = floorf(wv / d) + (alpha[((long)n * clen + c) * taps + t] >= 0.f ? 1.f : 0.f);
+            else q = rintf(wv / d);
+            q = fminf(fmaxf(q + z, 0.f), (float)(n_levels - 1));
+            code = (int)q;
+            sum += code;                       // raw nibble sum: the zero point is restored in the epilogue
+        }
+        vals[j] = code;
+    }
+    unsigned w0 = 0, w1 = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        w0 |= (unsigned)((vals[b] & 15) | ((vals[4 + b] & 15) << 4)) << (8 * b);
+        w1 |= (unsigned)((vals[8 + b] & 15) | ((vals[12 + b] & 15) << 4)) << (8 * b);
+    }
+    const long kstep = kstep0 + (long)t * nsteps_tap + cs;
+    uint2 pk = {w0, w1};
+    *reinterpret_cast<uint2*>(wt + (kstep * ntiles + jt) * 1024 + (kh4 * 32 + nn) * 8) = pk;
+    if (wsum && sum != 0) atomicAdd(&wsum[n], sum);
+}
+
+template <int MT, int NT>
+int dispatch(ConvD& k, bool split, int out, hipStream_t st) {
+    constexpr int BM = 128 * MT, BN = 32 * NT;
+    k.nblk_m = (k.M + BM - 1) / BM;
+    k.nblk_n = (k.Cout + BN - 1) / BN;
+    dim3 grid(k.nblk_m * k.nblk_n), block(256);
+#define QD_CASE(SP, O)                                                                      \
+    if (split == SP && out == O) {                                                          \
+        hipLaunchKernelGGL((igemm_dma_kernel<MT, NT, SP, O>), grid, block, 0, st, k);       \
+        return 0;                                                                           \
+    }
+    QD_CASE(false, O_F32) QD_CASE(false, O_F16) QD_CASE(false, O_I32)
+    if constexpr (MT == 1) { QD_CASE(true, O_F32) QD_CASE(true, O_F16) }
+#undef QD_CASE
+    qd_set_error("qd_conv2d_i8 (tiled): unsupported variant split=%d out=%d MT=%d", (int)split, out, MT);
+    return 1;
+}
+
+}  // namespace
+
+int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
+    QD_REQUIRE(d->wbits == 4, "tiled weights are int4 only");
+    QD_REQUIRE(d->ldx % 16 == 0 && qd_aligned(d->x, 16) && qd_aligned(d->w, 16), "qd_conv2d_i8 (tiled): x/w must be 16-byte aligned, ldx %% 16 == 0");
+    ConvD k{};
+    k.x = d->x; k.wt = d->w; k.out = d->out; k.iout = iout;
+    k.bias = d->bias; k.rowbias = d->rowbias; k.residual = d->residual;
+    k.ldx = d->ldx; k.ldo = d->ldo; k.ldr = d->ldr; k.ldrb = d->ld_rowbias;
+    k.B = d->B; k.H = d->H; k.W = d->W; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout;
+    k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad_t = d->pad_t; k.pad_l = d->pad_l;
+    k.M = d->B * d->Ho * d->Wo; k.taps = d->kh * d->kw; k.nseg = d->nseg;
+    k.ntiles = (d->Cout + 31) / 32;
+    for (int s = 0; s < d->nseg; ++s) {
+        const qd_conv_seg& g = d->seg[s];
+        QD_REQUIRE(g.clen > 0 && g.clen % 16 == 0 && g.c0 % 16 == 0, "qd_conv2d_i8 (tiled): segment %d c0/clen must be multiples of 16", s);
+        QD_REQUIRE(g.scale != nullptr, "qd_conv2d_i8 (tiled): segment %d has no scale vector", s);
+        QD_REQUIRE(!g.fill16 || qd_aligned(g.fill16, 16), "qd_conv2d_i8 (tiled): fill16 must be 16-byte aligned");
+        k.seg[s] = SegD{g.c0, g.clen, g.kstep0, (g.clen + 63) / 64, g.scale, g.zc, g.zw, g.zfill, g.fill16};
+    }
+    const bool split = d->nseg == 2;
+    const int out = iout ? O_I32 : (d->out_dtype == QD_F16 ? O_F16 : O_F32);
+    QD_REQUIRE(!(iout && split), "qd_conv2d_i8_acc: single segment only");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int N = d->Cout;
+    const long M = k.M;
+    int rc;
+    auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    if (N % 160 == 0) {
+        if (!split && blocks(256, 160) >= 512) rc = dispatch<2, 5>(k, split, out, st);      // >= 2 blocks per CU
+        else rc = dispatch<1, 5>(k, split, out, st);
+    } else if (N % 224 == 0) {
+        rc = dispatch<1, 7>(k, split, out, st);
+    } else if (N > 64) {
+        if (!split && blocks(256, 128) >= 512) rc = dispatch<2, 4>(k, split, out, st);
+        else rc = dispatch<1, 4>(k, split, out, st);
+    } else {
+        rc = dispatch<1, 2>(k, split, out, st);
+    }
+    if (rc) return rc;
+    QD_LAUNCH_CHECK("qd_conv2d_i8 (tiled)");
+    return 0;
+}
+
+extern "C" int qd_pack_weights_t4(const float* w, const float* alpha, const float* delta, const float* zp, int Cout,
+                                  int Cin_total, int taps, int c0, int clen, int clen_pad, int n_levels, uint8_t* wt,
+                                  int kstep0, int ntiles, int32_t* wsum, void* stream) {
+    QD_REQUIRE(w && delta && zp && wt, "qd_pack_weights_t4: null pointer");
+    QD_REQUIRE(Cout > 0 && taps > 0 && clen > 0 && c0 >= 0 && c0 + clen <= Cin_total, "qd_pack_weights_t4: bad shape");
+    QD_REQUIRE(clen_pad % 16 == 0 && clen_pad >= clen, "qd_pack_weights_t4: clen_pad must be a multiple of 16");
+    QD_REQUIRE(n_levels >= 2 && n_levels <= 16, "qd_pack_weights_t4: n_levels %d does not fit a nibble", n_levels);
+    QD_REQUIRE(ntiles == (Cout + 31) / 32 && qd_aligned(wt, 16), "qd_pack_weights_t4: bad tile layout");
+    const int nsteps_tap = (clen_pad + 63) / 64;
+    const long total = (long)taps * nsteps_tap * ntiles * 128;
+    hipLaunchKernelGGL(pack_t4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       w, alpha, delta, zp, Cout, Cin_total, taps, c0, clen, clen_pad, n_levels, wt, kstep0, ntiles, nsteps_tap, wsum);
+    QD_LAUNCH_CHECK("qd_pack_weights_t4");
+    return 0;
+}

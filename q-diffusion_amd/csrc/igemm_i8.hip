@@ -393,6 +393,12 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
     QD_REQUIRE(d != nullptr, "qd_conv2d_i8: null descriptor");
     QD_REQUIRE(d->x && d->w && (d->out || iout), "qd_conv2d_i8: null tensor pointer");
     QD_REQUIRE(d->wbits == 8 || d->wbits == 4, "qd_conv2d_i8: wbits must be 4 or 8 (got %d)", d->wbits);
+    QD_REQUIRE(d->out_dtype == QD_F32 || d->out_dtype == QD_F16, "qd_conv2d_i8: out_dtype must be f32/f16");
+    QD_REQUIRE(d->nseg == 1 || d->nseg == 2, "qd_conv2d_i8: nseg must be 1 or 2");
+    QD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, "qd_conv2d_i8: bad shape");
+    QD_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0, "qd_conv2d_i8: bad kernel/stride");
+    QD_REQUIRE((long)d->B * d->Ho * d->Wo < (1L << 31), "qd_conv2d_i8: M overflows int32");
+    if (d->w_tiled) return qd_conv2d_i8_tiled(d, iout, stream);
     QD_REQUIRE(d->nseg == 1 || d->nseg == 2, "qd_conv2d_i8: nseg must be 1 or 2");
     QD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, "qd_conv2d_i8: bad shape");
     QD_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0, "qd_conv2d_i8: bad kernel/stride");

@@ -11,8 +11,14 @@ import math
 
 import torch
 
+import os
+
 from . import hip
 from .hip import Grid, pad16, pad32
+
+# int4 weight layout: "tiled" (MFMA-tile order, LDS-DMA kernel csrc/igemm_dma.hip) or "rows"
+# (row-major nibbles, register-staged kernel csrc/igemm_i8.hip; kept for A/B measurements)
+W4_LAYOUT = os.environ.get("QDIFF_W4_LAYOUT", "tiled")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -59,7 +65,7 @@ def quantizer_key(q):
 # weight packing (K2)
 # ------------------------------------------------------------------------------------------------
 class WeightPack:
-    __slots__ = ("wq", "ldk", "wbits", "mode", "segs", "Cout", "taps", "Cin")
+    __slots__ = ("wq", "ldk", "wbits", "mode", "segs", "Cout", "taps", "Cin", "tiled")
 
 
 def _w_levels(q):
@@ -98,8 +104,17 @@ def pack_module_weights(weight, quantizers, split):
         segs.append(dict(c0w=c0, clen=clen, clen_pad=pad16(clen), kofs=kofs))
         kofs += pad16(clen)
     pk.ldk = max(pad32(kofs), 32)
-    nbytes = Cout * taps * pk.ldk // (2 if mode == 4 else 1)
-    pk.wq = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    pk.tiled = mode == 4 and W4_LAYOUT == "tiled"
+    if pk.tiled:
+        # MFMA-tile-ordered nibbles for the LDS-DMA kernel: [kstep][n/32][1 KB], kstep = (segment, tap, 64-ch step)
+        ntiles, kstep = (Cout + 31) // 32, 0
+        for sg in segs:
+            sg["kstep0"] = kstep
+            kstep += taps * ((sg["clen_pad"] + 63) // 64)
+        pk.wq = torch.zeros(kstep * ntiles * 1024, dtype=torch.uint8, device=dev)
+    else:
+        nbytes = Cout * taps * pk.ldk // (2 if mode == 4 else 1)
+        pk.wq = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     for sg, q, z in zip(segs, quantizers, zps):
         delta = q.delta.detach().float().reshape(-1).to(dev).contiguous()
         if delta.numel() != Cout:
@@ -110,12 +125,17 @@ def pack_module_weights(weight, quantizers, split):
                 raise hip.HipEngineError("AdaRound soft targets are a calibration-time mode; the integer engine packs hard rounding only")
             alpha = alpha.detach().to(device=dev, dtype=torch.float32).contiguous()
         wsum = torch.zeros(Cout, dtype=torch.int32, device=dev)
-        hip.pack_weights(w, alpha, delta, z.contiguous(), Cout, Cin, taps, sg["c0w"], sg["clen"], levels, mode,
-                         pk.wq, pk.ldk, sg["kofs"], wsum)
+        if pk.tiled:
+            hip.pack_weights_t4(w, alpha, delta, z.contiguous(), Cout, Cin, taps, sg["c0w"], sg["clen"], levels,
+                                pk.wq, sg["kstep0"], (Cout + 31) // 32, wsum)
+        else:
+            hip.pack_weights(w, alpha, delta, z.contiguous(), Cout, Cin, taps, sg["c0w"], sg["clen"], levels, mode,
+                             pk.wq, pk.ldk, sg["kofs"], wsum)
         sg["wsum"] = wsum
         sg["delta_w"] = delta
-        sg["zw"] = (z.to(torch.int32) - 128).contiguous() if mode == 8 else None
-        sg["wzp"] = z.to(torch.int8).contiguous() if mode == 4 else None
+        # epilogue-side weight zero point: stored operand is W-128 (mode 8) or the raw nibble W (tiled int4)
+        sg["zw"] = (z.to(torch.int32) - 128).contiguous() if mode == 8 else (z.to(torch.int32).contiguous() if pk.tiled else None)
+        sg["wzp"] = z.to(torch.int8).contiguous() if (mode == 4 and not pk.tiled) else None
     pk.segs = segs
     return pk
 
@@ -140,11 +160,12 @@ def build_conv_plan(pack, act_quantizers, kh, kw, stride, pad, bias):
         qp = qparams_of(aq, dev)
         K = pack.taps * sg["clen_pad"]
         d = dict(c0=sg["kofs"], clen=sg["clen_pad"], kofs=sg["kofs"], scale=(qp[0] * sg["delta_w"]).contiguous(),
-                 zw=sg["zw"], wzp=sg["wzp"], zc=None, zfill=None)
+                 zw=sg["zw"], wzp=sg["wzp"], zc=None, zfill=None, fill16=None, kstep0=sg.get("kstep0", 0))
         if not aq.sym:
             zprime = (qp[1] - grid.off).round().to(torch.int32)          # device scalar z'
             d["zc"] = (zprime * sg["wsum"]).to(torch.int32).contiguous()
             d["zfill"] = torch.stack([zprime, zprime * K]).to(torch.int32).contiguous()
+            d["fill16"] = zprime.to(torch.int8).repeat(16).contiguous()  # source of out-of-image taps (DMA loader)
         plan.segs.append(d)
         plan.grids.append(grid)
         plan.qparams.append(qp)
@@ -186,7 +207,7 @@ def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, re
                         ldr=(residual.stride(0) if residual is not None else 0),
                         ld_rowbias=(rowbias.stride(0) if rowbias is not None else 0),
                         B=B, H=H, W=W, Ho=Ho, Wo=Wo, Cout=plan.Cout, kh=plan.kh, kw=plan.kw, stride=plan.stride,
-                        pad_t=pad, pad_l=pad, wbits=plan.pack.wbits, segs=plan.segs)
+                        pad_t=pad, pad_l=pad, wbits=plan.pack.wbits, w_tiled=plan.pack.tiled, segs=plan.segs)
     hip.conv2d_i8(call, acc_out=acc_out)
     return out if acc_out is None else acc_out
 

@@ -21,8 +21,9 @@ class HipEngineError(RuntimeError):
 
 
 class ConvSeg(ctypes.Structure):
-    _fields_ = [("c0", ctypes.c_int32), ("clen", ctypes.c_int32), ("kofs", ctypes.c_int32), ("_pad", ctypes.c_int32),
-                ("wzp", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("zc", ctypes.c_void_p), ("zw", ctypes.c_void_p), ("zfill", ctypes.c_void_p)]
+    _fields_ = [("c0", ctypes.c_int32), ("clen", ctypes.c_int32), ("kofs", ctypes.c_int32), ("kstep0", ctypes.c_int32),
+                ("wzp", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("zc", ctypes.c_void_p), ("zw", ctypes.c_void_p), ("zfill", ctypes.c_void_p),
+                ("fill16", ctypes.c_void_p)]
 
 
 class ConvDesc(ctypes.Structure):
@@ -35,10 +36,12 @@ class ConvDesc(ctypes.Structure):
                 ("kh", ctypes.c_int32), ("kw", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad_t", ctypes.c_int32),
                 ("pad_l", ctypes.c_int32),
                 ("wbits", ctypes.c_int32), ("out_dtype", ctypes.c_int32), ("nseg", ctypes.c_int32),
+                ("w_tiled", ctypes.c_int32), ("_reserved", ctypes.c_int32),
                 ("seg", ConvSeg * 2)]
 
 
-EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_quantize_act", "qd_pack_weights", "qd_conv2d_i8",
+EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_quantize_act", "qd_pack_weights", "qd_pack_weights_t4",
+           "qd_conv2d_i8",
            "qd_conv2d_i8_acc", "qd_groupnorm_ws_bytes", "qd_groupnorm_silu_quant", "qd_layernorm_quant",
            "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8"]
 
@@ -60,6 +63,7 @@ def load():
     i64, i32, vp, f32 = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_float
     lib.qd_quantize_act.argtypes = [vp, i32, i64, i64, i64, i64, i64, i64, i32, i32, i32, vp, i32, i32, i32, vp, i64, i32, vp]
     lib.qd_pack_weights.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp, vp, vp]
+    lib.qd_pack_weights_t4.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]
     lib.qd_conv2d_i8.argtypes = [ctypes.POINTER(ConvDesc), vp]
     lib.qd_conv2d_i8_acc.argtypes = [ctypes.POINTER(ConvDesc), vp, vp]
     lib.qd_groupnorm_silu_quant.argtypes = [vp, i32, i64, i64, i32, i64, i32, f32, vp, vp, i32, vp, i32, i32, i32, vp,
@@ -72,7 +76,7 @@ def load():
                                       vp, vp, i32, i32, vp]
     lib.qd_attn_i8.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp,
                                i64, vp]
-    if lib.qd_abi_version() != 1:
+    if lib.qd_abi_version() != 2:
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -140,10 +144,16 @@ def pack_weights(w, alpha, delta, zp, Cout, Cin_total, taps, c0, clen, n_levels,
            "qd_pack_weights")
 
 
+def pack_weights_t4(w, alpha, delta, zp, Cout, Cin_total, taps, c0, clen, n_levels, wt, kstep0, ntiles, wsum):
+    _check(load().qd_pack_weights_t4(_ptr(w), _ptr(alpha), _ptr(delta), _ptr(zp), Cout, Cin_total, taps, c0, clen,
+                                     pad16(clen), n_levels, _ptr(wt), kstep0, ntiles, _ptr(wsum), _stream()),
+           "qd_pack_weights_t4")
+
+
 class ConvCall:
     """Python-side description of one qd_conv2d_i8 launch (tensors, not pointers)."""
     __slots__ = ("x", "w", "out", "bias", "rowbias", "residual", "ldx", "ldk", "ldo", "ldr", "ld_rowbias",
-                 "B", "H", "W", "Ho", "Wo", "Cout", "kh", "kw", "stride", "pad_t", "pad_l", "wbits", "segs")
+                 "B", "H", "W", "Ho", "Wo", "Cout", "kh", "kw", "stride", "pad_t", "pad_l", "wbits", "w_tiled", "segs")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -161,12 +171,13 @@ def conv2d_i8(c, acc_out=None):
     d.B, d.H, d.W, d.Ho, d.Wo, d.Cout = c.B, c.H, c.W, c.Ho, c.Wo, c.Cout
     d.kh, d.kw, d.stride, d.pad_t, d.pad_l = c.kh, c.kw, c.stride, c.pad_t, c.pad_l
     d.wbits = c.wbits
+    d.w_tiled = 1 if c.w_tiled else 0
     d.out_dtype = _dtype(c.out) if c.out is not None else F32
     d.nseg = len(c.segs)
     for i, s in enumerate(c.segs):
         g = d.seg[i]
-        g.c0, g.clen, g.kofs = s["c0"], s["clen"], s["kofs"]
-        g.wzp = _ptr(s.get("wzp"), "wzp")
+        g.c0, g.clen, g.kofs, g.kstep0 = s["c0"], s["clen"], s["kofs"], s.get("kstep0", 0)
+        g.wzp, g.fill16 = _ptr(s.get("wzp"), "wzp"), _ptr(s.get("fill16"), "fill16")
         g.scale, g.zc, g.zw, g.zfill = _ptr(s["scale"], "scale"), _ptr(s.get("zc")), _ptr(s.get("zw")), _ptr(s.get("zfill"))
     if acc_out is None:
         _check(load().qd_conv2d_i8(ctypes.byref(d), _stream()), "qd_conv2d_i8")

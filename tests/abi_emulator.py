@@ -62,9 +62,51 @@ def pack_weights(w, alpha, delta, zp, Cout, Cin_total, taps, c0, clen, n_levels,
     wsum += s.to(torch.int32)
 
 
+def _nibble_bytes(ch):
+    """[..., 16] nibble values -> [..., 8] bytes in the ABI's nibble order."""
+    by = torch.empty(ch.shape[:-1] + (8,), dtype=torch.int64)
+    for b in range(4):
+        by[..., b] = ch[..., b] | (ch[..., 4 + b] << 4)
+        by[..., 4 + b] = ch[..., 8 + b] | (ch[..., 12 + b] << 4)
+    return by
+
+
+def _nibble_values(by):
+    """inverse of _nibble_bytes: [..., 8] bytes -> [..., 16] nibble values."""
+    lo, hi = by & 15, by >> 4
+    ch = torch.empty(by.shape[:-1] + (16,), dtype=torch.int64)
+    for b in range(4):
+        ch[..., b], ch[..., 4 + b] = lo[..., b], hi[..., b]
+        ch[..., 8 + b], ch[..., 12 + b] = lo[..., 4 + b], hi[..., 4 + b]
+    return ch
+
+
+def pack_weights_t4(w, alpha, delta, zp, Cout, Cin_total, taps, c0, clen, n_levels, wt, kstep0, ntiles, wsum):
+    """qd_pack_weights_t4: wt[kstep][ntile][ksub*2+half][n%32][8 B]."""
+    wv = w.reshape(Cout, Cin_total, taps)[:, c0:c0 + clen].float()
+    d, z = delta.view(-1, 1, 1), zp.view(-1, 1, 1)
+    q = (torch.floor(wv / d) + (alpha.reshape(Cout, clen, taps) >= 0).float()) if alpha is not None else torch.round(wv / d)
+    code = torch.clamp(q + z, 0, n_levels - 1).to(torch.int64)                 # [Cout, clen, taps]
+    pad = (clen + 15) // 16 * 16
+    nst = (pad + 63) // 64
+    full = torch.zeros(ntiles * 32, taps, nst * 64, dtype=torch.int64)
+    full[:Cout, :, :clen] = code.permute(0, 2, 1)
+    units = full.view(ntiles, 32, taps, nst, 4, 16)                             # [jt, nn, t, cs, kh4, 16]
+    by = _nibble_bytes(units).permute(2, 3, 0, 4, 1, 5).contiguous()          # [t, cs, jt, kh4, nn, 8]
+    view = wt.view(-1, ntiles, 4, 32, 8)
+    view[kstep0:kstep0 + taps * nst] = by.view(taps * nst, ntiles, 4, 32, 8).to(torch.uint8)
+    wsum += code.sum(dim=(1, 2)).to(torch.int32)          # raw nibble sums; zero point restored via zw in the epilogue
+
+
 def _unpack_rows(c, seg):
     """stored int64 weight bytes [Cout, taps, clen] of one segment (after the nibble unpack)."""
     taps = c.kh * c.kw
+    if getattr(c, "w_tiled", False):
+        ntiles, nst = (c.Cout + 31) // 32, (seg["clen"] + 63) // 64
+        k0 = seg.get("kstep0", 0)
+        blk = c.w.view(-1, ntiles, 4, 32, 8)[k0:k0 + taps * nst].to(torch.int64)   # [t*cs, jt, kh4, nn, 8]
+        vals = _nibble_values(blk).view(taps, nst, ntiles, 4, 32, 16)
+        return vals.permute(2, 4, 0, 1, 3, 5).reshape(ntiles * 32, taps, nst * 64)[:c.Cout, :, :seg["clen"]]
     if c.wbits == 4:
         raw = c.w.view(c.Cout, taps, c.ldk // 2)[:, :, seg["kofs"] // 2:(seg["kofs"] + seg["clen"]) // 2].to(torch.int64)
         lo, hi = raw & 15, raw >> 4
@@ -182,6 +224,6 @@ def attn_i8(q, k, vt, qsum, ksum, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, w
 def install(monkeypatch):
     """Replace qdiff.hip's device entry points by the emulation (CPU tensors only)."""
     from qdiff import hip
-    for name in ("quantize_act", "pack_weights", "conv2d_i8", "groupnorm_ws_bytes", "groupnorm_silu_quant",
+    for name in ("quantize_act", "pack_weights", "pack_weights_t4", "conv2d_i8", "groupnorm_ws_bytes", "groupnorm_silu_quant",
                  "layernorm_quant", "geglu_quant", "quantize_heads", "attn_i8"):
         monkeypatch.setattr(hip, name, globals()[name])

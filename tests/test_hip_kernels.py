@@ -149,6 +149,9 @@ CONV_CASES = [
     ("stem_c3",        2, 3, 16, 16, 32, 3, 1, 1, False),
     ("out_c4",         2, 64, 16, 16, 4, 3, 1, 1, False),
     ("k224",           2, 224, 8, 8, 64, 3, 1, 1, False),      # K-step tail masking (224 = 3.5 * 64)
+    ("n96_tail",       2, 64, 8, 8, 96, 1, 1, 0, False),       # N tail: 3 n-tiles under a 4-tile block
+    ("n224_m_tail",    3, 96, 7, 7, 224, 3, 1, 1, False),      # LDM width (NT=7), ragged M (147 rows)
+    ("n320_big",       8, 320, 32, 32, 320, 3, 1, 1, False),   # 256x160 tile of the DMA kernel
 ]
 
 

@@ -33,15 +33,15 @@ def test_library_exports_every_declared_symbol():
     from qdiff import hip
     assert sorted(hip.EXPORTS) == declared
     lib.qd_abi_version.restype = ctypes.c_int
-    assert lib.qd_abi_version() == 1
+    assert lib.qd_abi_version() == 2
     assert lib.qd_device_ok() in (0, 1)                  # no compute calls without a GPU
 
 
 def test_conv_desc_layout_matches_header():
     """ctypes mirror of qd_conv_desc / qd_conv_seg has the C layout (sizes from the header's field list)."""
     from qdiff import hip
-    assert ctypes.sizeof(hip.ConvSeg) == 4 * 4 + 5 * 8
-    assert ctypes.sizeof(hip.ConvDesc) == 6 * 8 + 5 * 8 + 14 * 4 + 2 * ctypes.sizeof(hip.ConvSeg)
+    assert ctypes.sizeof(hip.ConvSeg) == 4 * 4 + 6 * 8
+    assert ctypes.sizeof(hip.ConvDesc) == 6 * 8 + 5 * 8 + 16 * 4 + 2 * ctypes.sizeof(hip.ConvSeg)
 
 
 def test_integer_path_refuses_to_run_on_the_host():

@@ -40,7 +40,10 @@ def main():
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
     tot_ops = tot_us = 0.0
+    only = os.environ.get("IGEMM_ONLY")
     for name, B, Cin, H, Cout, k, stride in SHAPES:
+        if only and only not in name:
+            continue
         w = torch.randn(Cout, Cin, k, k, device=dev, generator=g) * 0.05
         mx, mn = w.flatten(1).max(1)[0], w.flatten(1).min(1)[0]
         lv = 2 ** w_bits
