@@ -38,6 +38,8 @@ extern "C" {
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
+/* epilogues of qd_conv2d_i8 */
+enum { QD_EPI_LINEAR = 0, QD_EPI_GEGLU_I8 = 1 };
 
 int         qd_abi_version(void);
 const char* qd_last_error(void);
@@ -118,8 +120,13 @@ typedef struct {
     int32_t        out_dtype;/* QD_F32 / QD_F16                                                    */
     int32_t        nseg;     /* 1 or 2                                                             */
     int32_t        w_tiled;  /* 1: w is the MFMA-tile-ordered nibble array of qd_pack_weights_t4   */
-    int32_t        _reserved;
+    int32_t        epilogue; /* QD_EPI_LINEAR, or QD_EPI_GEGLU_I8 (w_tiled only): the weight rows were packed
+                                interleaved per 32 (value tile, gate tile, value tile, ...); the epilogue computes
+                                value*gelu(gate) (ldm/modules/attention.py:42-44) and writes it QUANTISED with
+                                oq_* (the act quantiser of the following Linear) as int8 rows out[M][ldo]        */
     qd_conv_seg    seg[2];
+    const float*   oq_params;/* QD_EPI_GEGLU_I8: {delta, zero_point} of the output quantiser (device)             */
+    int32_t        oq_min, oq_max, oq_off, _pad2;
 } qd_conv_desc;
 
 int qd_conv2d_i8(const qd_conv_desc* d, void* stream);

@@ -48,9 +48,12 @@ struct ConvD {
     int B, H, W, Ho, Wo, Cout, kh, kw, stride, pad_t, pad_l;
     int M, taps, nseg, nblk_m, nblk_n, ntiles;
     SegD seg[2];
+    const float* oq;          // O_GEGLU: {delta, zero_point} of the output quantiser
+    float oqmin, oqmax;
+    int   oqoff;
 };
 
-enum { O_F32 = 0, O_F16 = 1, O_I32 = 2 };
+enum { O_F32 = 0, O_F16 = 1, O_I32 = 2, O_GEGLU = 3 };
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -316,6 +319,39 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
     __syncthreads();                                   // sAsum / sRowB visible to every wave
     const SegD& sg = p.seg[p.nseg - 1];
     const int kz = sg.zfill ? sg.zfill[1] : 0;
+    if constexpr (OUT == O_GEGLU) {
+        // weight rows were packed (value tile, gate tile) interleaved: tiles 2jp / 2jp+1 of this lane hold
+        // the value and the gate of output feature nb*(BN/2) + jp*32 + frow.  y = value * gelu(gate)
+        // (erf GELU, ldm/modules/attention.py:42-44), then the next Linear's act quantiser, 1 byte out.
+        static_assert(NT % 2 == 0, "GEGLU epilogue pairs n-tiles");
+        const float od = p.oq[0], oz = p.oq[1];
+        int8_t* o8 = reinterpret_cast<int8_t*>(p.out);
+        const int Fout = p.Cout >> 1;
+#pragma unroll
+        for (int jp = 0; jp < NT / 2; ++jp) {
+            const int nv = n0 + (2 * jp) * 32 + frow, ng = nv + 32;
+            const int col = nb * (BN / 2) + jp * 32 + frow;
+            const bool ok = col < Fout && ng < p.Cout;
+            const float sv = ok ? sg.scale[nv] : 0.f, sgt = ok ? sg.scale[ng] : 0.f;
+            const int zcv = (ok && sg.zc) ? sg.zc[nv] : 0, zcg = (ok && sg.zc) ? sg.zc[ng] : 0;
+            const int zwv = (ok && sg.zw) ? sg.zw[nv] : 0, zwg = (ok && sg.zw) ? sg.zw[ng] : 0;
+            const float bv = (ok && p.bias) ? p.bias[nv] : 0.f, bg = (ok && p.bias) ? p.bias[ng] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rowl = wave * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                    const int m = m0 + rowl;
+                    if (!ok || m >= p.M) continue;
+                    const int as = sAsum[rowl] - kz;
+                    const float val = (float)(acc[i][2 * jp][r] - zcv - zwv * as) * sv + bv;
+                    const float gate = (float)(acc[i][2 * jp + 1][r] - zcg - zwg * as) * sgt + bg;
+                    const float y = val * (0.5f * gate * (1.0f + erff(gate * 0.70710678118654752440f)));
+                    o8[(long)m * p.ldo + col] = (int8_t)(qd_code(y, od, oz, p.oqmin, p.oqmax) - p.oqoff);
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + j * 32 + frow;
@@ -416,6 +452,7 @@ int dispatch(ConvD& k, bool split, int out, hipStream_t st) {
     }
     QD_CASE(false, O_F32) QD_CASE(false, O_F16) QD_CASE(false, O_I32)
     if constexpr (MT == 1) { QD_CASE(true, O_F32) QD_CASE(true, O_F16) }
+    if constexpr (NT == 4) { QD_CASE(false, O_GEGLU) }
 #undef QD_CASE
     qd_set_error("qd_conv2d_i8 (tiled): unsupported variant split=%d out=%d MT=%d", (int)split, out, MT);
     return 1;
@@ -442,14 +479,23 @@ int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
         k.seg[s] = SegD{g.c0, g.clen, g.kstep0, (g.clen + 63) / 64, g.scale, g.zc, g.zw, g.zfill, g.fill16};
     }
     const bool split = d->nseg == 2;
-    const int out = iout ? O_I32 : (d->out_dtype == QD_F16 ? O_F16 : O_F32);
+    const bool geglu = d->epilogue == QD_EPI_GEGLU_I8;
+    const int out = geglu ? O_GEGLU : (iout ? O_I32 : (d->out_dtype == QD_F16 ? O_F16 : O_F32));
+    if (geglu) {
+        QD_REQUIRE(!iout && d->nseg == 1 && d->oq_params && d->Cout % 64 == 0, "qd_conv2d_i8 (tiled): GEGLU epilogue needs one segment, oq_params and Cout %% 64 == 0");
+        QD_REQUIRE(d->oq_max - d->oq_off <= 127 && d->oq_min - d->oq_off >= -128, "qd_conv2d_i8 (tiled): GEGLU output grid does not fit int8");
+        k.oq = d->oq_params; k.oqmin = (float)d->oq_min; k.oqmax = (float)d->oq_max; k.oqoff = d->oq_off;
+    }
     QD_REQUIRE(!(iout && split), "qd_conv2d_i8_acc: single segment only");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int N = d->Cout;
     const long M = k.M;
     int rc;
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-    if (N % 160 == 0) {
+    if (geglu) {
+        if (blocks(256, 128) >= 512) rc = dispatch<2, 4>(k, split, out, st);
+        else rc = dispatch<1, 4>(k, split, out, st);
+    } else if (N % 160 == 0) {
         if (!split && blocks(256, 160) >= 512) rc = dispatch<2, 5>(k, split, out, st);      // >= 2 blocks per CU
         else rc = dispatch<1, 5>(k, split, out, st);
     } else if (N % 224 == 0) {

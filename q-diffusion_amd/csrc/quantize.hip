@@ -10,34 +10,56 @@ namespace {
 // write per element.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
+__device__ __forceinline__ void qd_ld4(const T* p, bool vec, float (&v)[4]) {
+    if (vec) {
+        if constexpr (sizeof(T) == 4) {
+            const float4 f = *reinterpret_cast<const float4*>(p);
+            v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+        } else {
+            const uint2 u = *reinterpret_cast<const uint2*>(p);
+            const __half2 a = *reinterpret_cast<const __half2*>(&u.x), b = *reinterpret_cast<const __half2*>(&u.y);
+            v[0] = __low2float(a); v[1] = __high2float(a); v[2] = __low2float(b); v[3] = __high2float(b);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = qd_ld(p + j);
+    }
+}
+
+// lane = 4 consecutive channels of one row: a wave reads 1 KB contiguous (fp32) and writes 256 B
+// contiguous — fully coalesced on both sides (the first version gave each lane 16 channels, i.e. a
+// 64-byte lane stride on the read side, 1/4 of the TA rate).
+template <typename T>
 __global__ __launch_bounds__(256) void quant_rows_kernel(const T* __restrict__ x, long rows, long row_stride,
                                                          long S, long sb, int c0, int clen, int clen_pad,
                                                          const float* __restrict__ qp, float qmin, float qmax,
-                                                         int off, int8_t* __restrict__ out, long ldo, int oc0) {
-    const int chunks = clen_pad >> 4;
+                                                         int off, int8_t* __restrict__ out, long ldo, int oc0, int vec) {
+    const int groups = clen_pad >> 2;
     long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= rows * chunks) return;
-    long row = gid / chunks;
-    int  ch  = (int)(gid - row * chunks);
+    if (gid >= rows * groups) return;
+    long row = gid / groups;
+    int  g   = (int)(gid - row * groups);
     const float delta = qp[0], zp = qp[1];
     const int ztrue = (int)zp - off;
     long b = row / S, s = row - b * S;
-    const T* src = x + b * sb + s * row_stride + c0 + ch * 16;
-    int bytes[16];
+    const int c = g * 4;
+    unsigned u;
+    if (c + 4 <= clen) {
+        float v[4];
+        qd_ld4(x + b * sb + s * row_stride + c0 + c, vec != 0, v);
+        u = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        int c = ch * 16 + j;
-        bytes[j] = (c < clen) ? qd_code(qd_ld(src + j), delta, zp, qmin, qmax) - off : ztrue;
+        for (int j = 0; j < 4; ++j) u |= (unsigned)((qd_code(v[j], delta, zp, qmin, qmax) - off) & 0xff) << (8 * j);
+    } else {
+        u = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int code = ztrue;
+            if (c + j < clen) code = qd_code(qd_ld(x + b * sb + s * row_stride + c0 + c + j), delta, zp, qmin, qmax) - off;
+            u |= (unsigned)(code & 0xff) << (8 * j);
+        }
     }
-    v4i v;
-#pragma unroll
-    for (int wd = 0; wd < 4; ++wd) {
-        unsigned u = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) u |= (unsigned)(bytes[wd * 4 + j] & 0xff) << (8 * j);
-        v[wd] = (int)u;
-    }
-    *reinterpret_cast<v4i*>(out + row * ldo + oc0 + ch * 16) = v;
+    *reinterpret_cast<unsigned*>(out + row * ldo + oc0 + c) = u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -188,44 +210,55 @@ __global__ __launch_bounds__(256) void geglu_quant_kernel(const T* __restrict__ 
 //   transpose=1: thread = (bh, 16 permuted key slots, dd); out[bh][dd][Tpad], rsum[bh][dd] (atomics)
 // key permutation inside a 32-key tile: slot p=half*16+r  <->  key (r&3)+8*(r>>2)+4*half
 // ---------------------------------------------------------------------------------------------
+// rows layout: a block owns `tpb` whole tokens; lane = 4 consecutive features (d % 4 == 0, so a group
+// never straddles two heads): reads are contiguous float4s along the token's feature axis, writes are
+// 4-byte pieces of the head rows, row sums are accumulated with LDS atomics (integer, deterministic)
+// and stored once.  Pad rows / pad features are zeroed by a memset node ahead of the launch.
 template <typename T>
 __global__ __launch_bounds__(256) void quant_heads_rows_kernel(const T* __restrict__ x, int B, int Tn, int H, int d,
                                                                long sb, long st, long sh, long sd, float prescale,
                                                                const float* __restrict__ qp, float qmin, float qmax,
                                                                int off, int8_t* __restrict__ out,
-                                                               int32_t* __restrict__ rsum, int Tpad, int dpad) {
-    long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    long total = (long)B * H * Tpad;
-    if (gid >= total) return;
-    int t = (int)(gid % Tpad);
-    long bh = gid / Tpad;
-    int hh = (int)(bh % H), b = (int)(bh / H);
+                                                               int32_t* __restrict__ rsum, int Tpad, int dpad, int tpb, int vec) {
+    __shared__ int ssum[256];
+    const int gpr = (H * d) >> 2;                       // float4 groups per token
+    const long tok0 = (long)blockIdx.x * tpb;            // first token (b*T + t) of this block
+    const long ntok = (long)B * Tn;
+    for (int i = threadIdx.x; i < tpb * H; i += 256) ssum[i] = 0;
+    __syncthreads();
     const float delta = qp[0], zp = qp[1];
-    int8_t* dst = out + gid * dpad;
-    int sum = 0;
-    for (int ch = 0; ch < dpad / 16; ++ch) {
-        v4i v = {0, 0, 0, 0};
-        if (t < Tn) {
+    for (int idx = threadIdx.x; idx < tpb * gpr; idx += 256) {
+        const int lt = idx / gpr, g = idx - lt * gpr;
+        const long tok = tok0 + lt;
+        if (tok >= ntok) break;
+        const int b = (int)(tok / Tn), t = (int)(tok - (long)b * Tn);
+        const int f = g * 4, hh = f / d, dd = f - hh * d;
+        float v[4];
+        const T* src = x + b * sb + (long)t * st + hh * sh + dd * sd;
+        if (sd == 1) qd_ld4(src, vec != 0, v);
+        else {
 #pragma unroll
-            for (int wd = 0; wd < 4; ++wd) {
-                unsigned u = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int dd = ch * 16 + wd * 4 + j;
-                    int code = 0;
-                    if (dd < d) {
-                        float xv = qd_ld(x + b * sb + (long)t * st + hh * sh + dd * sd) * prescale;
-                        code = qd_code(xv, delta, zp, qmin, qmax) - off;
-                        sum += code;
-                    }
-                    u |= (unsigned)(code & 0xff) << (8 * j);
-                }
-                v[wd] = (int)u;
-            }
+            for (int j = 0; j < 4; ++j) v[j] = qd_ld(src + j * sd);
         }
-        *reinterpret_cast<v4i*>(dst + ch * 16) = v;
+        unsigned u = 0;
+        int sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int code = qd_code(v[j] * prescale, delta, zp, qmin, qmax) - off;
+            sum += code;
+            u |= (unsigned)(code & 0xff) << (8 * j);
+        }
+        *reinterpret_cast<unsigned*>(out + (((long)b * H + hh) * Tpad + t) * dpad + dd) = u;
+        if (rsum) atomicAdd(&ssum[lt * H + hh], sum);
     }
-    if (rsum) rsum[gid] = sum;
+    if (!rsum) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < tpb * H; i += 256) {
+        const long tok = tok0 + i / H;
+        if (tok >= ntok) continue;
+        const int b = (int)(tok / Tn), t = (int)(tok - (long)b * Tn);
+        rsum[((long)b * H + (i % H)) * Tpad + t] = ssum[i];
+    }
 }
 
 template <typename T>
@@ -278,12 +311,14 @@ extern "C" int qd_quantize_act(const void* x, int x_dtype, int64_t B, int64_t C,
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (sc == 1) {
         long rows = B * S;
-        long total = rows * (clen_pad / 16);
+        long total = rows * (clen_pad / 4);
         dim3 grid((unsigned)((total + 255) / 256));
+        const size_t esz = x_dtype == QD_F32 ? 4 : 2;
+        const int vec = qd_aligned(x, 4 * esz) && (ss % 4 == 0) && (sb % 4 == 0) && (c0 % 4 == 0);
         if (x_dtype == QD_F32)
-            hipLaunchKernelGGL(quant_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)x, rows, (long)ss, (long)S, (long)sb, c0, clen, clen_pad, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, oc0);
+            hipLaunchKernelGGL(quant_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)x, rows, (long)ss, (long)S, (long)sb, c0, clen, clen_pad, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, oc0, vec);
         else
-            hipLaunchKernelGGL(quant_rows_kernel<__half>, grid, dim3(256), 0, st, (const __half*)x, rows, (long)ss, (long)S, (long)sb, c0, clen, clen_pad, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, oc0);
+            hipLaunchKernelGGL(quant_rows_kernel<__half>, grid, dim3(256), 0, st, (const __half*)x, rows, (long)ss, (long)S, (long)sb, c0, clen, clen_pad, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, oc0, vec);
     } else {
         QD_REQUIRE(B < 65536, "qd_quantize_act: batch too large for strided kernel");
         dim3 grid((unsigned)((S + 63) / 64), (unsigned)((clen_pad + 63) / 64), (unsigned)B);
@@ -337,12 +372,21 @@ extern "C" int qd_quantize_heads(const void* x, int x_dtype, int B, int T, int H
     QD_REQUIRE(Tpad % 32 == 0 && Tpad >= T && dpad % 32 == 0 && dpad >= d && qd_aligned(out, 16), "qd_quantize_heads: Tpad/dpad must be multiples of 32 covering T/d");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (!transpose) {
-        long total = (long)B * H * Tpad;
-        dim3 grid((unsigned)((total + 255) / 256));
+        QD_REQUIRE(d % 4 == 0 && H <= 256, "qd_quantize_heads: head dim must be a multiple of 4 and H <= 256 (d=%d H=%d)", d, H);
+        hipError_t e1 = hipMemsetAsync(out, 0, (size_t)B * H * Tpad * dpad, st);
+        hipError_t e2 = rsum ? hipMemsetAsync(rsum, 0, sizeof(int32_t) * (size_t)B * H * Tpad, st) : hipSuccess;
+        QD_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, "qd_quantize_heads: memset failed");
+        const int gpr = (H * d) / 4;
+        int tpb = 1024 / gpr;                                   // ~4 float4 groups per thread
+        if (tpb < 1) tpb = 1;
+        while (tpb * H > 256) --tpb;
+        const size_t esz = x_dtype == QD_F32 ? 4 : 2;
+        const int vec = qd_aligned(x, 4 * esz) && sb % 4 == 0 && st_ % 4 == 0 && sh % 4 == 0 && sd == 1;
+        dim3 grid((unsigned)(((long)B * T + tpb - 1) / tpb));
         if (x_dtype == QD_F32)
-            hipLaunchKernelGGL(quant_heads_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)x, B, T, H, d, (long)sb, (long)st_, (long)sh, (long)sd, prescale, qparams, (float)qmin, (float)qmax, off, out, rsum, Tpad, dpad);
+            hipLaunchKernelGGL(quant_heads_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)x, B, T, H, d, (long)sb, (long)st_, (long)sh, (long)sd, prescale, qparams, (float)qmin, (float)qmax, off, out, rsum, Tpad, dpad, tpb, vec);
         else
-            hipLaunchKernelGGL(quant_heads_rows_kernel<__half>, grid, dim3(256), 0, st, (const __half*)x, B, T, H, d, (long)sb, (long)st_, (long)sh, (long)sd, prescale, qparams, (float)qmin, (float)qmax, off, out, rsum, Tpad, dpad);
+            hipLaunchKernelGGL(quant_heads_rows_kernel<__half>, grid, dim3(256), 0, st, (const __half*)x, B, T, H, d, (long)sb, (long)st_, (long)sh, (long)sd, prescale, qparams, (float)qmin, (float)qmax, off, out, rsum, Tpad, dpad, tpb, vec);
     } else {
         QD_REQUIRE((long)B * H < 65536, "qd_quantize_heads: too many heads for grid.y");
         if (rsum) {

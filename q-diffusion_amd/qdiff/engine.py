@@ -65,18 +65,30 @@ def quantizer_key(q):
 # weight packing (K2)
 # ------------------------------------------------------------------------------------------------
 class WeightPack:
-    __slots__ = ("wq", "ldk", "wbits", "mode", "segs", "Cout", "taps", "Cin", "tiled")
+    __slots__ = ("wq", "ldk", "wbits", "mode", "segs", "Cout", "taps", "Cin", "tiled", "row_perm")
 
 
 def _w_levels(q):
     return int(q.n_levels)
 
 
-def pack_module_weights(weight, quantizers, split):
+def geglu_row_perm(F, device):
+    """Row order that interleaves 32-wide tiles of the GEGLU projection's value rows [0,F) and gate
+    rows [F,2F) — (v0, g0, v1, g1, ...) — so that one lane of the contraction kernel holds the value and
+    the gate of the same output feature (QD_EPI_GEGLU_I8 epilogue)."""
+    assert F % 32 == 0
+    t = torch.arange(F, device=device).view(F // 32, 1, 32)
+    return torch.cat([t, t + F], dim=1).reshape(-1)
+
+
+def pack_module_weights(weight, quantizers, split, row_perm=None):
     """weight: fp32 [Cout, Cin, *k] on the GPU; quantizers: [wq] or [wq, wq_0] (UniformAffine- or
-    AdaRound-like objects with delta/zero_point[/alpha]/n_levels).  Returns a WeightPack."""
+    AdaRound-like objects with delta/zero_point[/alpha]/n_levels).  row_perm: optional output-row
+    permutation applied to the weight and to every per-row quantity.  Returns a WeightPack."""
     dev = weight.device
     w = weight.detach().float().contiguous()
+    if row_perm is not None:
+        w = w.index_select(0, row_perm).contiguous()
     Cout, Cin = w.shape[0], w.shape[1]
     taps = 1
     for s in w.shape[2:]:
@@ -87,6 +99,8 @@ def pack_module_weights(weight, quantizers, split):
     levels = _w_levels(quantizers[0])
     zps = [q.zero_point.detach().float().reshape(-1).to(dev) if torch.is_tensor(q.zero_point)
            else torch.full((Cout,), float(q.zero_point), device=dev) for q in quantizers]
+    if row_perm is not None:
+        zps = [z.index_select(0, row_perm) for z in zps]
     zall = torch.cat(zps)
     zmin, zmax = int(zall.min().item()), int(zall.max().item())  # one-time host read at pack time
     if levels <= 16 and zmin >= 0 and zmax <= 127:
@@ -124,6 +138,9 @@ def pack_module_weights(weight, quantizers, split):
             if getattr(q, "soft_targets", False):
                 raise hip.HipEngineError("AdaRound soft targets are a calibration-time mode; the integer engine packs hard rounding only")
             alpha = alpha.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if row_perm is not None:
+            delta = delta.index_select(0, row_perm).contiguous()
+            alpha = alpha.index_select(0, row_perm).contiguous() if alpha is not None else None
         wsum = torch.zeros(Cout, dtype=torch.int32, device=dev)
         if pk.tiled:
             hip.pack_weights_t4(w, alpha, delta, z.contiguous(), Cout, Cin, taps, sg["c0w"], sg["clen"], levels,
@@ -137,6 +154,7 @@ def pack_module_weights(weight, quantizers, split):
         sg["zw"] = (z.to(torch.int32) - 128).contiguous() if mode == 8 else (z.to(torch.int32).contiguous() if pk.tiled else None)
         sg["wzp"] = z.to(torch.int8).contiguous() if (mode == 4 and not pk.tiled) else None
     pk.segs = segs
+    pk.row_perm = row_perm
     return pk
 
 
@@ -153,6 +171,8 @@ def build_conv_plan(pack, act_quantizers, kh, kw, stride, pad, bias):
     plan = ConvPlan()
     plan.pack, plan.kh, plan.kw, plan.stride, plan.pad = pack, kh, kw, stride, pad
     plan.bias = bias.detach().float().contiguous() if bias is not None else None
+    if plan.bias is not None and pack.row_perm is not None:
+        plan.bias = plan.bias.index_select(0, pack.row_perm).contiguous()
     plan.Cout, plan.Cin = pack.Cout, pack.Cin
     plan.segs, plan.grids, plan.qparams = [], [], []
     for sg, aq in zip(pack.segs, act_quantizers):
@@ -210,6 +230,20 @@ def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, re
                         pad_t=pad, pad_l=pad, wbits=plan.pack.wbits, w_tiled=plan.pack.tiled, segs=plan.segs)
     hip.conv2d_i8(call, acc_out=acc_out)
     return out if acc_out is None else acc_out
+
+
+def conv_forward_geglu(plan, xq, M, next_plan):
+    """GEGLU projection (plan packed with geglu_row_perm) with the fused value*gelu(gate) -> quantise
+    epilogue: returns the int8 rows [M][next_plan.ldx] that `next_plan` (the FF output Linear) consumes."""
+    if not plan.pack.tiled or plan.pack.row_perm is None or len(plan.segs) != 1 or len(next_plan.segs) != 1:
+        raise hip.HipEngineError("fused GEGLU epilogue needs a tile-ordered int4 projection packed with geglu_row_perm")
+    out = torch.empty((M, next_plan.ldx), dtype=torch.int8, device=xq.device)
+    call = hip.ConvCall(x=xq, w=plan.pack.wq, out=out, bias=plan.bias, ldx=plan.ldx, ldk=plan.pack.ldk, ldo=next_plan.ldx,
+                        B=1, H=1, W=M, Ho=1, Wo=M, Cout=plan.Cout, kh=1, kw=1, stride=1, pad_t=0, pad_l=0,
+                        wbits=plan.pack.wbits, w_tiled=True, segs=plan.segs, epilogue=hip.EPI_GEGLU_I8,
+                        oq_params=next_plan.qparams[0], oq_grid=next_plan.grids[0])
+    hip.conv2d_i8(call)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -36,8 +36,13 @@ class ConvDesc(ctypes.Structure):
                 ("kh", ctypes.c_int32), ("kw", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad_t", ctypes.c_int32),
                 ("pad_l", ctypes.c_int32),
                 ("wbits", ctypes.c_int32), ("out_dtype", ctypes.c_int32), ("nseg", ctypes.c_int32),
-                ("w_tiled", ctypes.c_int32), ("_reserved", ctypes.c_int32),
-                ("seg", ConvSeg * 2)]
+                ("w_tiled", ctypes.c_int32), ("epilogue", ctypes.c_int32),
+                ("seg", ConvSeg * 2),
+                ("oq_params", ctypes.c_void_p), ("oq_min", ctypes.c_int32), ("oq_max", ctypes.c_int32),
+                ("oq_off", ctypes.c_int32), ("_pad2", ctypes.c_int32)]
+
+
+EPI_LINEAR, EPI_GEGLU_I8 = 0, 1
 
 
 EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_quantize_act", "qd_pack_weights", "qd_pack_weights_t4",
@@ -153,7 +158,8 @@ def pack_weights_t4(w, alpha, delta, zp, Cout, Cin_total, taps, c0, clen, n_leve
 class ConvCall:
     """Python-side description of one qd_conv2d_i8 launch (tensors, not pointers)."""
     __slots__ = ("x", "w", "out", "bias", "rowbias", "residual", "ldx", "ldk", "ldo", "ldr", "ld_rowbias",
-                 "B", "H", "W", "Ho", "Wo", "Cout", "kh", "kw", "stride", "pad_t", "pad_l", "wbits", "w_tiled", "segs")
+                 "B", "H", "W", "Ho", "Wo", "Cout", "kh", "kw", "stride", "pad_t", "pad_l", "wbits", "w_tiled", "segs",
+                 "epilogue", "oq_params", "oq_grid")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -172,7 +178,13 @@ def conv2d_i8(c, acc_out=None):
     d.kh, d.kw, d.stride, d.pad_t, d.pad_l = c.kh, c.kw, c.stride, c.pad_t, c.pad_l
     d.wbits = c.wbits
     d.w_tiled = 1 if c.w_tiled else 0
-    d.out_dtype = _dtype(c.out) if c.out is not None else F32
+    d.epilogue = c.epilogue or EPI_LINEAR
+    if d.epilogue == EPI_GEGLU_I8:
+        d.oq_params = _ptr(c.oq_params, "oq_params")
+        d.oq_min, d.oq_max, d.oq_off = c.oq_grid.qmin, c.oq_grid.qmax, c.oq_grid.off
+        d.out_dtype = F32                           # unused: the output is int8 rows
+    else:
+        d.out_dtype = _dtype(c.out) if c.out is not None else F32
     d.nseg = len(c.segs)
     for i, s in enumerate(c.segs):
         g = d.seg[i]

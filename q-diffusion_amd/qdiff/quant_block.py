@@ -418,11 +418,16 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
             rows = self._attn_int(self.attn2, rows, B, T, C, self.norm2, ctx, S)
         proj, ff_out = self.ff.net[0].proj, self.ff.net[-1]
         (h8,) = _ln_to([proj], rows, B * T, C, self.norm3)
-        hcat = proj.forward_codes(h8, 1, 1, B * T)                    # [M, 2F]
-        Fdim = hcat.shape[1] // 2
-        if not ff_out.act_quantizer.inited:
-            ff_out._init_act_quantizers(hcat[:, :Fdim] * F.gelu(hcat[:, Fdim:]))
-        g8 = engine.geglu_quant(hcat, B * T, Fdim, ff_out.conv_plan())
+        gplan = proj.geglu_plan() if ff_out.act_quantizer.inited else None
+        if gplan is not None:
+            # fused epilogue: value*gelu(gate) is quantised for ff_out inside the projection kernel
+            g8 = engine.conv_forward_geglu(gplan, h8, B * T, ff_out.conv_plan())
+        else:
+            hcat = proj.forward_codes(h8, 1, 1, B * T)                # [M, 2F]
+            Fdim = hcat.shape[1] // 2
+            if not ff_out.act_quantizer.inited:
+                ff_out._init_act_quantizers(hcat[:, :Fdim] * F.gelu(hcat[:, Fdim:]))
+            g8 = engine.geglu_quant(hcat, B * T, Fdim, ff_out.conv_plan())
         rows = ff_out.forward_codes(g8, 1, 1, B * T, residual=rows)
         return rows.view(B, T, C)
 

@@ -333,6 +333,7 @@ class QuantModule(nn.Module):
         (optimizer steps, load_state_dict, `p.mul_()` ...); writes through `.data` bypass version
         tracking, so call this (or QuantModel.invalidate_plans()) after such an edit."""
         self._pack_key = self._plan_key = self._wdq_key = None
+        self.__dict__.pop('_geglu_cache', None)
 
     def conv_plan(self):
         """Packed weights + epilogue constants for the current quantiser state (lazy, cached)."""
@@ -386,6 +387,25 @@ class QuantModule(nn.Module):
         xq = engine.quantize_rows(rows, plan, 1, K, M, (0, 1, rows.stride(0)))
         out = engine.conv_forward(plan, xq, 1, 1, M, 1, M)
         return out.view(*lead, plan.Cout)
+
+    def geglu_plan(self):
+        """Second plan of a GEGLU projection: rows packed (value tile, gate tile) interleaved for the fused
+        value*gelu(gate)->quantise epilogue (engine.conv_forward_geglu).  None if the layer does not
+        qualify (needs tile-ordered int4 weights and an even split into 32-row tiles)."""
+        F = self.weight.shape[0] // 2
+        if self.kind != 'linear' or self.split != 0 or F % 32 != 0:
+            return None
+        wq, aq = self.weight_quantizer, self.act_quantizer
+        if hasattr(wq, 'ensure_init'):
+            wq.ensure_init(self.weight)
+        key = (engine.quantizer_key(wq), engine.quantizer_key(aq), self.weight._version, self.weight.data_ptr(),
+               None if self.bias is None else (self.bias._version, self.bias.data_ptr()))
+        cache = self.__dict__.setdefault('_geglu_cache', [None, None])
+        if cache[0] != key:
+            pack = engine.pack_module_weights(self.weight, [wq], 0, row_perm=engine.geglu_row_perm(F, self.weight.device))
+            cache[1] = engine.build_conv_plan(pack, [aq], 1, 1, 1, 0, self.bias) if pack.tiled else None
+            cache[0] = key
+        return cache[1]
 
     def forward_codes(self, xq, B, H, W, Ho=None, Wo=None, rowbias=None, residual=None, pad_tl=None):
         """Integer path for a producer that already emitted this module's int8 rows (fused blocks)."""

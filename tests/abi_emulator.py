@@ -152,6 +152,12 @@ def conv2d_i8(c, acc_out=None):
     rows = total.permute(0, 2, 3, 1).reshape(-1, c.Cout)
     if c.residual is not None:
         rows = rows + c.residual[:, :c.Cout].float()
+    if getattr(c, "epilogue", 0) == 1:
+        # QD_EPI_GEGLU_I8: packed rows are (value tile, gate tile) interleaved per 32
+        t = rows.view(rows.shape[0], c.Cout // 64, 2, 32)
+        y = (t[:, :, 0] * F.gelu(t[:, :, 1])).reshape(rows.shape[0], c.Cout // 2)
+        c.out[:, :c.Cout // 2] = (_codes(y, c.oq_params, c.oq_grid) - c.oq_grid.off).to(torch.int8)
+        return
     c.out[:, :c.Cout] = rows.to(c.out.dtype)
 
 

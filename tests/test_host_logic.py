@@ -41,7 +41,35 @@ def test_conv_desc_layout_matches_header():
     """ctypes mirror of qd_conv_desc / qd_conv_seg has the C layout (sizes from the header's field list)."""
     from qdiff import hip
     assert ctypes.sizeof(hip.ConvSeg) == 4 * 4 + 6 * 8
-    assert ctypes.sizeof(hip.ConvDesc) == 6 * 8 + 5 * 8 + 16 * 4 + 2 * ctypes.sizeof(hip.ConvSeg)
+    assert ctypes.sizeof(hip.ConvDesc) == 6 * 8 + 5 * 8 + 16 * 4 + 2 * ctypes.sizeof(hip.ConvSeg) + 8 + 4 * 4
+
+
+def test_conv_desc_offsets_match_the_compiled_header(tmp_path):
+    """Compile include/qdiff_hip.h with gcc and compare sizeof/offsetof of every field with the ctypes mirror."""
+    import shutil
+    import subprocess
+    from qdiff import hip
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "qdiff_hip.h"', 'int main(void){',
+             'printf("qd_conv_seg %zu\\n", sizeof(qd_conv_seg));', 'printf("qd_conv_desc %zu\\n", sizeof(qd_conv_desc));']
+    for name, _ in hip.ConvSeg._fields_:
+        lines.append(f'printf("seg.{name} %zu\\n", offsetof(qd_conv_seg, {name}));')
+    for name, _ in hip.ConvDesc._fields_:
+        lines.append(f'printf("desc.{name} %zu\\n", offsetof(qd_conv_desc, {name}));')
+    lines.append('return 0;}')
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    assert int(got["qd_conv_seg"]) == ctypes.sizeof(hip.ConvSeg)
+    assert int(got["qd_conv_desc"]) == ctypes.sizeof(hip.ConvDesc)
+    for name, _ in hip.ConvSeg._fields_:
+        assert int(got[f"seg.{name}"]) == getattr(hip.ConvSeg, name).offset, name
+    for name, _ in hip.ConvDesc._fields_:
+        assert int(got[f"desc.{name}"]) == getattr(hip.ConvDesc, name).offset, name
 
 
 def test_integer_path_refuses_to_run_on_the_host():
