@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 2
+#define QD_ABI_VERSION 3
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -127,9 +127,18 @@ typedef struct {
     qd_conv_seg    seg[2];
     const float*   oq_params;/* QD_EPI_GEGLU_I8: {delta, zero_point} of the output quantiser (device)             */
     int32_t        oq_min, oq_max, oq_off, _pad2;
+    void*          splitk_ws;      /* optional scratch of >= qd_conv2d_i8_splitk_ws_bytes(d) bytes (16-B aligned); when
+                                      given, layers too small to fill the chip are contracted split-K: int32 partials
+                                      per K range (exact), then one pass that sums them and applies the epilogue.
+                                      NULL = never split.  Results do not depend on it (integer partial sums).       */
+    int64_t        splitk_ws_bytes;
 } qd_conv_desc;
 
 int qd_conv2d_i8(const qd_conv_desc* d, void* stream);
+
+/* Scratch bytes qd_conv2d_i8 would use for a split-K contraction of this descriptor (shape fields only are
+ * read); 0 when the layer is launched unsplit. */
+int64_t qd_conv2d_i8_splitk_ws_bytes(const qd_conv_desc* d);
 
 /* K2b  tile-ordered int4 packer for the LDS-DMA contraction kernel (csrc/igemm_dma.hip).  Same code
  *     formula as qd_pack_weights (adaptive_rounding.py:49-59).  Output wt[kstep][ntile][1024 B]:

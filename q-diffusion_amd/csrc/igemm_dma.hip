@@ -51,9 +51,13 @@ struct ConvD {
     const float* oq;          // O_GEGLU: {delta, zero_point} of the output quantiser
     float oqmin, oqmax;
     int   oqoff;
+    int   it_per;             // O_PART: K-steps per split (blockIdx.y = split index)
 };
 
-enum { O_F32 = 0, O_F16 = 1, O_I32 = 2, O_GEGLU = 3 };
+// O_PART: split-K partial.  The block contracts K-steps [y*it_per, (y+1)*it_per) only and stores
+// acc - zw[n]*Asum_part[m] (int32, exact) into slice y of the workspace; splitk_finalize_kernel sums
+// the slices, restores the K-independent constants and applies the float epilogue.
+enum { O_F32 = 0, O_F16 = 1, O_I32 = 2, O_GEGLU = 3, O_PART = 4 };
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -135,10 +139,14 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
     }
 
     // ---- loader state (uniform) + per-lane running source pointers ------------------------------
-    int ls = 0, ltap = 0, lrr = 0, lq = 0, lc = 0;
+    int it_begin = 0;                             // first K-step of this block (split-K partials only)
+    if constexpr (OUT == O_PART) it_begin = blockIdx.y * p.it_per;
+    int ls = 0;
+    int ltap = it_begin / p.seg[0].nsteps_tap, lc = it_begin - ltap * p.seg[0].nsteps_tap;
+    int lrr = ltap / p.kw, lq = ltap - lrr * p.kw;
     const int8_t* a_cur[NA];                      // source of the NEXT K-step for DMA instruction i
     int           a_inc[NA];                      // 64 for real pixels, 0 for fill / zero sources
-    const uint8_t* b_cur = p.wt + ((long)p.seg[0].kstep0 * p.ntiles + (long)nb * NT) * 1024 + wave * (NT * 256) + lane * 16;
+    const uint8_t* b_cur = p.wt + ((long)(p.seg[0].kstep0 + it_begin) * p.ntiles + (long)nb * NT) * 1024 + wave * (NT * 256) + lane * 16;
     const long b_inc = (long)p.ntiles * 1024;
     const int8_t* zero16 = reinterpret_cast<const int8_t*>(qd_zero16);
     bool b_ok[NB];                                // the last N-block may cover n-tiles that do not exist
@@ -157,6 +165,10 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
         }
     };
     set_tap();
+    if constexpr (OUT == O_PART) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a_cur[i] += lc * a_inc[i];
+    }
 
     // issue DMA instruction d of the current loader step into ring stage ST (compile-time LDS addresses)
     auto issue_one = [&](unsigned stage_base, int d) __attribute__((always_inline)) {
@@ -221,7 +233,8 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
     };
 
     const int nst0  = p.taps * p.seg[0].nsteps_tap;
-    const int total = nst0 + (p.nseg == 2 ? p.taps * p.seg[1].nsteps_tap : 0);
+    const int total_all = nst0 + (p.nseg == 2 ? p.taps * p.seg[1].nsteps_tap : 0);
+    const int total = OUT == O_PART ? min(p.it_per, total_all - it_begin) : total_all;
     const unsigned lds0 = lds_addr(smem);
 
     // lane-invariant fragment offsets inside a stage
@@ -367,6 +380,10 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
                 const int rowl = wave * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
                 const int m = m0 + rowl;
                 if (!nok || m >= p.M) continue;
+                if (OUT == O_PART) {
+                    p.iout[((long)blockIdx.y * p.M + m) * p.Cout + n] = acc[i][j][r] - zw_n * sAsum[rowl];
+                    continue;
+                }
                 const int I = acc[i][j][r] - zc_n - zw_n * (sAsum[rowl] - kz);
                 if (OUT == O_I32) {
                     p.iout[(long)m * p.Cout + n] = I;
@@ -439,26 +456,83 @@ __global__ __launch_bounds__(256) void pack_t4_kernel(const float* __restrict__ 
     if (wsum && sum != 0) atomicAdd(&wsum[n], sum);
 }
 
+// split-K second pass: thread = one output element (n fastest).  Same float sequence as the fused epilogue.
+template <typename TO>
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const int32_t* __restrict__ part, int nsplit, long MN, int Cout, int HoWo,
+                                                              const float* __restrict__ scale, const int* __restrict__ zc,
+                                                              const int* __restrict__ zw, const int* __restrict__ zfill,
+                                                              const float* __restrict__ bias, const float* __restrict__ rowbias, long ldrb,
+                                                              const TO* __restrict__ residual, long ldr, TO* __restrict__ out, long ldo) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= MN) return;
+    const long m = e / Cout;
+    const int  n = (int)(e - m * Cout);
+    int I = 0;
+    for (int s = 0; s < nsplit; ++s) I += part[(long)s * MN + e];
+    const int kz = zfill ? zfill[1] : 0;
+    I = I - (zc ? zc[n] : 0) + (zw ? zw[n] : 0) * kz;
+    float v = (float)I * scale[n];
+    v += bias ? bias[n] : 0.f;
+    if (rowbias) v += rowbias[(m / HoWo) * ldrb + n];
+    if constexpr (std::is_same<TO, float>::value) {
+        if (residual) v += residual[m * ldr + n];
+        out[m * ldo + n] = v;
+    } else {
+        if (residual) v += __half2float(residual[m * ldr + n]);
+        out[m * ldo + n] = __float2half(v);
+    }
+}
+
 template <int MT, int NT>
-int dispatch(ConvD& k, bool split, int out, hipStream_t st) {
+int dispatch(ConvD& k, bool split, int out, hipStream_t st, int nsplit = 1) {
     constexpr int BM = 128 * MT, BN = 32 * NT;
     k.nblk_m = (k.M + BM - 1) / BM;
     k.nblk_n = (k.Cout + BN - 1) / BN;
-    dim3 grid(k.nblk_m * k.nblk_n), block(256);
+    dim3 grid(k.nblk_m * k.nblk_n, nsplit), block(256);
 #define QD_CASE(SP, O)                                                                      \
     if (split == SP && out == O) {                                                          \
         hipLaunchKernelGGL((igemm_dma_kernel<MT, NT, SP, O>), grid, block, 0, st, k);       \
         return 0;                                                                           \
     }
     QD_CASE(false, O_F32) QD_CASE(false, O_F16) QD_CASE(false, O_I32)
-    if constexpr (MT == 1) { QD_CASE(true, O_F32) QD_CASE(true, O_F16) }
+    if constexpr (MT == 1) { QD_CASE(true, O_F32) QD_CASE(true, O_F16) QD_CASE(false, O_PART) }
     if constexpr (NT == 4) { QD_CASE(false, O_GEGLU) }
 #undef QD_CASE
     qd_set_error("qd_conv2d_i8 (tiled): unsupported variant split=%d out=%d MT=%d", (int)split, out, MT);
     return 1;
 }
 
+// N-tile count of the MT=1 kernel the dispatcher would pick for this width
+int nt_for(int N) { return N % 160 == 0 ? 5 : (N % 224 == 0 ? 7 : (N > 64 ? 4 : 2)); }
+
+// Split-K policy.  Worth it only when the plain launch cannot fill the chip (<= 1 block per CU) AND the
+// K loop is long enough that the extra int32 partial traffic (2 * 4 * M * N bytes per split) is paid back.
+int choose_splitk(const qd_conv_desc* d, int* it_per) {
+    *it_per = 0;
+    if (!d->w_tiled || d->nseg != 1 || d->epilogue != QD_EPI_LINEAR) return 1;
+    const long M = (long)d->B * d->Ho * d->Wo;
+    const int  N = d->Cout, bn = 32 * nt_for(N);
+    const long blocks0 = ((M + 127) / 128) * ((N + bn - 1) / bn);
+    const int  total = d->kh * d->kw * ((d->seg[0].clen + 63) / 64);
+    if (blocks0 > 256) return 1;
+    const long mn = M * N;
+    const int min_steps = mn <= (1L << 18) ? 2 : (mn <= (3L << 19) ? 4 : 16);
+    long S = 512 / blocks0;
+    if (S > total / min_steps) S = total / min_steps;
+    if (S > 32) S = 32;
+    if (S < 2) return 1;
+    *it_per = (int)((total + S - 1) / S);
+    return (total + *it_per - 1) / *it_per;
+}
+
 }  // namespace
+
+extern "C" int64_t qd_conv2d_i8_splitk_ws_bytes(const qd_conv_desc* d) {
+    if (!d) return 0;
+    int it_per;
+    const int S = choose_splitk(d, &it_per);
+    return S < 2 ? 0 : (int64_t)S * d->B * d->Ho * d->Wo * d->Cout * 4;
+}
 
 int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
     QD_REQUIRE(d->wbits == 4, "tiled weights are int4 only");
@@ -492,6 +566,31 @@ int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
     const long M = k.M;
     int rc;
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    int it_per = 0;
+    const int nsplit = (iout || !d->splitk_ws) ? 1 : choose_splitk(d, &it_per);
+    if (nsplit >= 2 && d->splitk_ws_bytes >= (int64_t)nsplit * M * N * 4) {
+        QD_REQUIRE(qd_aligned(d->splitk_ws, 16), "qd_conv2d_i8 (tiled): splitk_ws must be 16-byte aligned");
+        k.iout = reinterpret_cast<int32_t*>(d->splitk_ws);
+        k.it_per = it_per;
+        switch (nt_for(N)) {
+            case 5:  rc = dispatch<1, 5>(k, false, O_PART, st, nsplit); break;
+            case 7:  rc = dispatch<1, 7>(k, false, O_PART, st, nsplit); break;
+            case 4:  rc = dispatch<1, 4>(k, false, O_PART, st, nsplit); break;
+            default: rc = dispatch<1, 2>(k, false, O_PART, st, nsplit); break;
+        }
+        if (rc) return rc;
+        const SegD& sg = k.seg[0];
+        const long MN = M * N;
+        dim3 grid((unsigned)((MN + 255) / 256)), block(256);
+        if (d->out_dtype == QD_F16)
+            hipLaunchKernelGGL(splitk_finalize_kernel<__half>, grid, block, 0, st, k.iout, nsplit, MN, N, d->Ho * d->Wo, sg.scale, sg.zc, sg.zw,
+                               sg.zfill, k.bias, k.rowbias, k.ldrb, (const __half*)k.residual, k.ldr, (__half*)k.out, k.ldo);
+        else
+            hipLaunchKernelGGL(splitk_finalize_kernel<float>, grid, block, 0, st, k.iout, nsplit, MN, N, d->Ho * d->Wo, sg.scale, sg.zc, sg.zw,
+                               sg.zfill, k.bias, k.rowbias, k.ldrb, (const float*)k.residual, k.ldr, (float*)k.out, k.ldo);
+        QD_LAUNCH_CHECK("qd_conv2d_i8 (tiled, split-K)");
+        return 0;
+    }
     if (geglu) {
         if (blocks(256, 128) >= 512) rc = dispatch<2, 4>(k, split, out, st);
         else rc = dispatch<1, 4>(k, split, out, st);

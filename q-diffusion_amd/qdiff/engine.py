@@ -213,8 +213,9 @@ def conv_out_hw(H, W, plan, pad_br=None):
 
 
 def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, residual=None, acc_out=None,
-                 out_dtype=torch.float32, pad_tl=None):
-    """Run K3/K4 on quantised rows xq [B*H*W][ldx].  Returns out [B*Ho*Wo][Cout] (row-major)."""
+                 out_dtype=torch.float32, pad_tl=None, splitk=None):
+    """Run K3/K4 on quantised rows xq [B*H*W][ldx].  Returns out [B*Ho*Wo][Cout] (row-major).
+    splitk=False forbids the split-K schedule (tests compare it with the default, which lets the library decide)."""
     if Ho is None:
         Ho, Wo = conv_out_hw(H, W, plan)
     M = B * Ho * Wo
@@ -227,7 +228,8 @@ def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, re
                         ldr=(residual.stride(0) if residual is not None else 0),
                         ld_rowbias=(rowbias.stride(0) if rowbias is not None else 0),
                         B=B, H=H, W=W, Ho=Ho, Wo=Wo, Cout=plan.Cout, kh=plan.kh, kw=plan.kw, stride=plan.stride,
-                        pad_t=pad, pad_l=pad, wbits=plan.pack.wbits, w_tiled=plan.pack.tiled, segs=plan.segs)
+                        pad_t=pad, pad_l=pad, wbits=plan.pack.wbits, w_tiled=plan.pack.tiled, segs=plan.segs,
+                        splitk=splitk)
     hip.conv2d_i8(call, acc_out=acc_out)
     return out if acc_out is None else acc_out
 

@@ -39,14 +39,15 @@ class ConvDesc(ctypes.Structure):
                 ("w_tiled", ctypes.c_int32), ("epilogue", ctypes.c_int32),
                 ("seg", ConvSeg * 2),
                 ("oq_params", ctypes.c_void_p), ("oq_min", ctypes.c_int32), ("oq_max", ctypes.c_int32),
-                ("oq_off", ctypes.c_int32), ("_pad2", ctypes.c_int32)]
+                ("oq_off", ctypes.c_int32), ("_pad2", ctypes.c_int32),
+                ("splitk_ws", ctypes.c_void_p), ("splitk_ws_bytes", ctypes.c_int64)]
 
 
 EPI_LINEAR, EPI_GEGLU_I8 = 0, 1
 
 
 EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_quantize_act", "qd_pack_weights", "qd_pack_weights_t4",
-           "qd_conv2d_i8",
+           "qd_conv2d_i8", "qd_conv2d_i8_splitk_ws_bytes",
            "qd_conv2d_i8_acc", "qd_groupnorm_ws_bytes", "qd_groupnorm_silu_quant", "qd_layernorm_quant",
            "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8"]
 
@@ -71,6 +72,8 @@ def load():
     lib.qd_pack_weights_t4.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]
     lib.qd_conv2d_i8.argtypes = [ctypes.POINTER(ConvDesc), vp]
     lib.qd_conv2d_i8_acc.argtypes = [ctypes.POINTER(ConvDesc), vp, vp]
+    lib.qd_conv2d_i8_splitk_ws_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
+    lib.qd_conv2d_i8_splitk_ws_bytes.restype = ctypes.c_int64
     lib.qd_groupnorm_silu_quant.argtypes = [vp, i32, i64, i64, i32, i64, i32, f32, vp, vp, i32, vp, i32, i32, i32, vp,
                                             i64, vp, i64, vp, vp]
     lib.qd_layernorm_quant.argtypes = [vp, i32, i64, i32, i64, f32, vp, vp, i32, ctypes.POINTER(vp),
@@ -81,7 +84,7 @@ def load():
                                       vp, vp, i32, i32, vp]
     lib.qd_attn_i8.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp,
                                i64, vp]
-    if lib.qd_abi_version() != 2:
+    if lib.qd_abi_version() != 3:
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -159,15 +162,45 @@ class ConvCall:
     """Python-side description of one qd_conv2d_i8 launch (tensors, not pointers)."""
     __slots__ = ("x", "w", "out", "bias", "rowbias", "residual", "ldx", "ldk", "ldo", "ldr", "ld_rowbias",
                  "B", "H", "W", "Ho", "Wo", "Cout", "kh", "kw", "stride", "pad_t", "pad_l", "wbits", "w_tiled", "segs",
-                 "epilogue", "oq_params", "oq_grid")
+                 "epilogue", "oq_params", "oq_grid", "splitk")
 
     def __init__(self, **kw):
         for k in self.__slots__:
             setattr(self, k, kw.get(k))
 
 
+_SPLITK_WS = {}          # device -> list of scratch buffers, newest last; old ones stay alive for captured graphs
+
+
+def _splitk_scratch(device, nbytes):
+    """Stream-ordered scratch shared by every split-K launch on `device` (grows, never shrinks or moves:
+    a HIP graph captured earlier keeps pointing at the buffer it was captured with)."""
+    bufs = _SPLITK_WS.setdefault(device, [])
+    if not bufs or bufs[-1].numel() < nbytes:
+        bufs.append(torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device))
+    return bufs[-1]
+
+
+def splitk_ws_bytes(c):
+    """Scratch bytes the library would use to contract ConvCall `c` split-K (0 = launched unsplit)."""
+    return int(load().qd_conv2d_i8_splitk_ws_bytes(ctypes.byref(_conv_desc(c))))
+
+
 def conv2d_i8(c, acc_out=None):
     """c: ConvCall.  segs: list of dicts {c0, clen, kofs, wzp, scale, zc, zw, zfill} (tensors or None)."""
+    d = _conv_desc(c)
+    if acc_out is None:
+        if c.w_tiled and c.splitk is not False:
+            need = int(load().qd_conv2d_i8_splitk_ws_bytes(ctypes.byref(d)))
+            if need:
+                ws = _splitk_scratch(c.x.device, need)
+                d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
+        _check(load().qd_conv2d_i8(ctypes.byref(d), _stream()), "qd_conv2d_i8")
+    else:
+        _check(load().qd_conv2d_i8_acc(ctypes.byref(d), _ptr(acc_out), _stream()), "qd_conv2d_i8_acc")
+
+
+def _conv_desc(c):
     d = ConvDesc()
     d.x, d.w = _ptr(c.x, "x"), _ptr(c.w, "w")
     d.out = _ptr(c.out, "out")
@@ -191,10 +224,7 @@ def conv2d_i8(c, acc_out=None):
         g.c0, g.clen, g.kofs, g.kstep0 = s["c0"], s["clen"], s["kofs"], s.get("kstep0", 0)
         g.wzp, g.fill16 = _ptr(s.get("wzp"), "wzp"), _ptr(s.get("fill16"), "fill16")
         g.scale, g.zc, g.zw, g.zfill = _ptr(s["scale"], "scale"), _ptr(s.get("zc")), _ptr(s.get("zw")), _ptr(s.get("zfill"))
-    if acc_out is None:
-        _check(load().qd_conv2d_i8(ctypes.byref(d), _stream()), "qd_conv2d_i8")
-    else:
-        _check(load().qd_conv2d_i8_acc(ctypes.byref(d), _ptr(acc_out), _stream()), "qd_conv2d_i8_acc")
+    return d
 
 
 def groupnorm_ws_bytes(B, C, S):

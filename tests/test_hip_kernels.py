@@ -251,6 +251,49 @@ def test_conv_split_two_segments(cuda):
         assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
 
 
+SPLITK_CASES = [
+    # name, B, Cin, H, W, Cout, k     (M = B*H*W small, K long: the layers the library contracts split-K)
+    ("emb_m16",      16, 1280, 1, 1, 1280, 1),     # time-embedding Linear: M=16
+    ("mid_8x8",       4, 640, 8, 8, 1280, 3),      # 8x8 middle-block conv: M=256, K=5760
+    ("ctx_kv",        2, 768, 1, 77, 320, 1),      # cross-attention k/v projection of 77 context tokens
+    ("m1024_ragged",  1, 352, 30, 33, 224, 3),     # ragged M (990), K tail (352 = 5.5 * 64), NT=7
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_CASES, ids=[c[0] for c in SPLITK_CASES])
+def test_conv_splitk_is_bit_identical_to_unsplit(cuda, case):
+    """Split-K partials are int32 (exact) and the finalise pass runs the same float sequence as the fused
+    epilogue, so the schedule must not change a single output bit; both also match the fp32 fake-quant."""
+    from qdiff import engine, hip
+    _, B, Cin, H, W, Cout, k = case
+    g = torch.Generator().manual_seed(21)
+    x = F.silu(torch.randn(B, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
+    bias = torch.randn(Cout, generator=g)
+    q = _weight_quantizer(w, 4, True, g)
+    d, z = R.uaq_init_scale(x, 8, False, False, "max")
+    aq = _aq(d, z)
+    pack = engine.pack_module_weights(w.to(cuda), [q], 0)
+    plan = engine.build_conv_plan(pack, [aq], k, k, 1, k // 2, bias.to(cuda))
+    xq = engine.quantize_rows(x.to(cuda), plan, B, Cin, H * W, (Cin * H * W, H * W, 1))
+    rowbias = torch.randn(B, Cout, generator=g).to(cuda)
+    residual = torch.randn(B * H * W, Cout, generator=g).to(cuda)
+    desc_probe = hip.ConvCall(x=xq, w=pack.wq, ldx=plan.ldx, ldk=pack.ldk, B=B, H=H, W=W, Ho=H, Wo=W, Cout=Cout, kh=k, kw=k,
+                              stride=1, pad_t=k // 2, pad_l=k // 2, wbits=4, w_tiled=pack.tiled, segs=plan.segs)
+    if pack.tiled:
+        assert hip.splitk_ws_bytes(desc_probe) > 0, "case is meant to take the split-K schedule"
+    a = engine.conv_forward(plan, xq, B, H, W, rowbias=rowbias, residual=residual)
+    b = engine.conv_forward(plan, xq, B, H, W, rowbias=rowbias, residual=residual, splitk=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b), f"max |diff| = {(a - b).abs().max().item()}"
+    want = R.quant_module_forward(x, w, bias, "conv2d", dict(stride=1, padding=k // 2),
+                                  [dict(delta=q.delta, zero_point=q.zero_point, alpha=q.alpha, n_levels=q.n_levels)],
+                                  [dict(delta=aq.delta, zero_point=z, n_bits=8, sym=False)])
+    want = want + rowbias.cpu()[:, :, None, None] + residual.cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
+    got = a.cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
+    assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+
+
 def test_linear_tokens(cuda):
     from qdiff import engine
     g = torch.Generator().manual_seed(6)
