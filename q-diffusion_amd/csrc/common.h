@@ -47,6 +47,24 @@ template <typename T> __device__ __forceinline__ float qd_ld(const T* p);
 template <> __device__ __forceinline__ float qd_ld<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float qd_ld<__half>(const __half* p) { return __half2float(*p); }
 
+// 4 consecutive elements; `vec` = the caller proved 4-element alignment (one 16-/8-byte load)
+template <typename T>
+__device__ __forceinline__ void qd_ld4(const T* p, bool vec, float (&v)[4]) {
+    if (vec) {
+        if constexpr (sizeof(T) == 4) {
+            const float4 f = *reinterpret_cast<const float4*>(p);
+            v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+        } else {
+            const uint2 u = *reinterpret_cast<const uint2*>(p);
+            const __half2 a = *reinterpret_cast<const __half2*>(&u.x), b = *reinterpret_cast<const __half2*>(&u.y);
+            v[0] = __low2float(a); v[1] = __high2float(a); v[2] = __low2float(b); v[3] = __high2float(b);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = qd_ld(p + j);
+    }
+}
+
 // quantise one value to its stored byte: clamp(rint(x/delta)+zp, qmin, qmax) - off
 // (true IEEE division + round-half-even, as torch.round(x / delta): quant_layer.py:82)
 __device__ __forceinline__ int qd_code(float x, float delta, float zp, float qmin, float qmax) {

@@ -10,28 +10,30 @@ namespace {
 
 constexpr int GN_ROWS = 32;  // rows per partial-sum block
 
-// partial sums: grid (nchunk, B); thread owns 4 consecutive channels (float4), loops over rows.
+// partial sums: grid (nchunk, B); thread owns 4 consecutive channels (one float4 load per row), loops over rows.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, long S, int C, long ldx,
-                                                         float* __restrict__ part, int nchunk) {
+                                                         float* __restrict__ part, int nchunk, int vec) {
     const int chunk = blockIdx.x;
     const long b = blockIdx.y;
     const long r0 = (long)chunk * GN_ROWS;
     const long r1 = (r0 + GN_ROWS < S) ? r0 + GN_ROWS : S;
     for (int c4 = threadIdx.x; c4 < C / 4; c4 += 256) {
         float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-        for (long r = r0; r < r1; ++r) {
-            const T* p = x + (b * S + r) * ldx + c4 * 4;
+        const T* p = x + (b * S + r0) * ldx + c4 * 4;
+#pragma unroll 4
+        for (long r = r0; r < r1; ++r, p += ldx) {
+            float v[4];
+            qd_ld4(p, vec != 0, v);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v = qd_ld(p + j);
-                s[j] += v;
-                q[j] += v * v;
+                s[j] += v[j];
+                q[j] += v[j] * v[j];
             }
         }
         float* dst = part + (((b * nchunk + chunk) * (long)C) + c4 * 4) * 2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { dst[2 * j] = s[j]; dst[2 * j + 1] = q[j]; }
+        *reinterpret_cast<float4*>(dst)     = make_float4(s[0], q[0], s[1], q[1]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(s[2], q[2], s[3], q[3]);
     }
 }
 
@@ -70,37 +72,35 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     }
 }
 
+// apply: lane = 4 consecutive channels of one row (float4 in, 4 bytes out; both sides fully coalesced).
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, long rows, long S, int C, long ldx,
                                                        const float* __restrict__ ab, int apply_silu,
                                                        const float* __restrict__ qp, float qmin, float qmax, int off,
                                                        int8_t* __restrict__ out, long ldo, float* __restrict__ yout,
-                                                       long ldy) {
-    const int chunks = C >> 4;
+                                                       long ldy, int vec) {
+    const int chunks = C >> 2;
     long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= rows * chunks) return;
     long row = gid / chunks;
-    int ch = (int)(gid - row * chunks);
+    int c = (int)(gid - row * chunks) * 4;
     long b = row / S;
-    const T* src = x + row * ldx + ch * 16;
-    const float* pab = ab + (b * C + ch * 16) * 2;
+    float v[4];
+    qd_ld4(x + row * ldx + c, vec != 0, v);
+    const float4 ab0 = *reinterpret_cast<const float4*>(ab + (b * C + c) * 2);
+    const float4 ab1 = *reinterpret_cast<const float4*>(ab + (b * C + c) * 2 + 4);
+    const float a4[4] = {ab0.x, ab0.z, ab1.x, ab1.z}, s4[4] = {ab0.y, ab0.w, ab1.y, ab1.w};
     float delta = 1.f, zp = 0.f;
     if (out) { delta = qp[0]; zp = qp[1]; }
-    v4i v;
+    unsigned u = 0;
 #pragma unroll
-    for (int wd = 0; wd < 4; ++wd) {
-        unsigned u = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int e = wd * 4 + j;
-            float y = qd_ld(src + e) * pab[2 * e] + pab[2 * e + 1];
-            if (apply_silu) y = y * (1.0f / (1.0f + expf(-y)));
-            if (yout) yout[row * ldy + ch * 16 + e] = y;
-            if (out) u |= (unsigned)((qd_code(y, delta, zp, qmin, qmax) - off) & 0xff) << (8 * j);
-        }
-        v[wd] = (int)u;
+    for (int j = 0; j < 4; ++j) {
+        float y = v[j] * a4[j] + s4[j];
+        if (apply_silu) y = y * (1.0f / (1.0f + expf(-y)));
+        if (yout) yout[row * ldy + c + j] = y;
+        if (out) u |= (unsigned)((qd_code(y, delta, zp, qmin, qmax) - off) & 0xff) << (8 * j);
     }
-    if (out) *reinterpret_cast<v4i*>(out + row * ldo + ch * 16) = v;
+    if (out) *reinterpret_cast<unsigned*>(out + row * ldo + c) = u;
 }
 
 // LayerNorm: one wave per row, row held in registers (C <= 64*4*MAXV).
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int nout, const float* qp0, const float* qp1, const float* qp2,
                                                        float3 qmin, float3 qmax, int3 off, int8_t* o0, int8_t* o1,
-                                                       int8_t* o2, long ldo) {
+                                                       int8_t* o2, long ldo, int vec) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -122,8 +122,9 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(const T* __restrict__ x, 
     for (int k = 0; k < LN_MAXV; ++k) {
         int idx = lane + 64 * k;
         if (idx < nv) {
+            qd_ld4(src + idx * 4, vec != 0, v[k]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { v[k][j] = qd_ld(src + idx * 4 + j); s += v[k][j]; }
+            for (int j = 0; j < 4; ++j) s += v[k][j];
         }
     }
 #pragma unroll
@@ -183,20 +184,21 @@ extern "C" int qd_groupnorm_silu_quant(const void* x, int x_dtype, int64_t B, in
     QD_REQUIRE(B < 65536, "qd_groupnorm_silu_quant: batch too large");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nchunk = (int)((S + GN_ROWS - 1) / GN_ROWS);
+    const int vec = qd_aligned(x, x_dtype == QD_F32 ? 16 : 8) && ldx % 4 == 0;
     float* part = reinterpret_cast<float*>(ws);
     float* ab = part + (size_t)B * nchunk * C * 2;
     if (x_dtype == QD_F32)
-        hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, (const float*)x, (long)S, C, (long)ldx, part, nchunk);
+        hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, (const float*)x, (long)S, C, (long)ldx, part, nchunk, vec);
     else
-        hipLaunchKernelGGL(gn_partial_kernel<__half>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, (const __half*)x, (long)S, C, (long)ldx, part, nchunk);
+        hipLaunchKernelGGL(gn_partial_kernel<__half>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, (const __half*)x, (long)S, C, (long)ldx, part, nchunk, vec);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, (unsigned)B), dim3(64), 0, st, part, nchunk, (long)S, C, groups, eps, gamma, beta, ab);
     long rows = B * S;
-    long total = rows * (C / 16);
+    long total = rows * (C / 4);
     dim3 grid((unsigned)((total + 255) / 256));
     if (x_dtype == QD_F32)
-        hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, rows, (long)S, C, (long)ldx, ab, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, yout, (long)ldy);
+        hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, rows, (long)S, C, (long)ldx, ab, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, yout, (long)ldy, vec);
     else
-        hipLaunchKernelGGL(gn_apply_kernel<__half>, grid, dim3(256), 0, st, (const __half*)x, rows, (long)S, C, (long)ldx, ab, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, yout, (long)ldy);
+        hipLaunchKernelGGL(gn_apply_kernel<__half>, grid, dim3(256), 0, st, (const __half*)x, rows, (long)S, C, (long)ldx, ab, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, yout, (long)ldy, vec);
     QD_LAUNCH_CHECK("qd_groupnorm_silu_quant");
     return 0;
 }
@@ -223,11 +225,12 @@ extern "C" int qd_layernorm_quant(const void* x, int x_dtype, int64_t M, int C, 
         (&of.x)[i] = off[i];
     }
     dim3 grid((unsigned)((M + 3) / 4));
+    const int vec = qd_aligned(x, x_dtype == QD_F32 ? 16 : 8) && ldx % 4 == 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (x_dtype == QD_F32)
-        hipLaunchKernelGGL(ln_quant_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp[0], qp[1], qp[2], mn, mx, of, o[0], o[1], o[2], (long)ldo);
+        hipLaunchKernelGGL(ln_quant_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp[0], qp[1], qp[2], mn, mx, of, o[0], o[1], o[2], (long)ldo, vec);
     else
-        hipLaunchKernelGGL(ln_quant_kernel<__half>, grid, dim3(256), 0, st, (const __half*)x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp[0], qp[1], qp[2], mn, mx, of, o[0], o[1], o[2], (long)ldo);
+        hipLaunchKernelGGL(ln_quant_kernel<__half>, grid, dim3(256), 0, st, (const __half*)x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp[0], qp[1], qp[2], mn, mx, of, o[0], o[1], o[2], (long)ldo, vec);
     QD_LAUNCH_CHECK("qd_layernorm_quant");
     return 0;
 }

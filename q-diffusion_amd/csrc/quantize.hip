@@ -9,23 +9,6 @@ namespace {
 // Replaces the 7-8 elementwise ATen passes of quant_layer.py:82-88 with one read + one 1-byte
 // write per element.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void qd_ld4(const T* p, bool vec, float (&v)[4]) {
-    if (vec) {
-        if constexpr (sizeof(T) == 4) {
-            const float4 f = *reinterpret_cast<const float4*>(p);
-            v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
-        } else {
-            const uint2 u = *reinterpret_cast<const uint2*>(p);
-            const __half2 a = *reinterpret_cast<const __half2*>(&u.x), b = *reinterpret_cast<const __half2*>(&u.y);
-            v[0] = __low2float(a); v[1] = __high2float(a); v[2] = __low2float(b); v[3] = __high2float(b);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = qd_ld(p + j);
-    }
-}
-
 // lane = 4 consecutive channels of one row: a wave reads 1 KB contiguous (fp32) and writes 256 B
 // contiguous — fully coalesced on both sides (the first version gave each lane 16 channels, i.e. a
 // 64-byte lane stride on the read side, 1/4 of the TA rate).

@@ -173,7 +173,18 @@ class SpatialTransformer(nn.Module):
         self.proj_out = zero_module(nn.Conv2d(inner, in_channels, kernel_size=1, stride=1, padding=0))
 
     def forward(self, x, context=None):
+        from .. import quant_block as qb            # lazy: quant_block imports this module's classes
         b, c, h, w = x.shape
+        if qb._int_mode(self.proj_in, self.proj_out) and not (self.proj_in.split or self.proj_out.split):
+            # quantised: GroupNorm emits proj_in's int8 rows directly (no SiLU here), the 1x1 projections are
+            # row GEMMs on the channels-last stream and the `+ x` rides in proj_out's epilogue.
+            rows = qb._nhwc_rows(x)
+            xq = qb._gn_silu_to(self.proj_in, rows, b, h * w, c, self.norm, silu=False)
+            t = self.proj_in.forward_codes(xq, b, h, w).view(b, h * w, -1)
+            for blk in self.transformer_blocks:
+                t = blk(t, context)
+            out = qb._linear_rows(self.proj_out, t.reshape(b * h * w, t.shape[-1]), residual=rows)
+            return qb._rows_to_nchw(out, b, h, w)
         t = self.proj_in(self.norm(x))
         t = t.permute(0, 2, 3, 1).reshape(b, h * w, t.shape[1])
         for blk in self.transformer_blocks:
