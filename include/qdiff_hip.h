@@ -209,6 +209,9 @@ int qd_geglu_quant(const void* h, int h_dtype, int64_t M, int F, int64_t ldh,
  *             O is written as out[b][t][h*d + c] (merged heads, ldo = row stride, fp32).
  *     prm: device float[16] = {cs (=dq*dk*scale), zq', zk', dw, zpw, dv_dw (=dw*dv), zv', ...}
  *          (layout in DESIGN.md §4.4); built once on device by the host, never read back.
+ *     ksum: row sums of the stored k bytes (rsum of step 1), or NULL when zq' == 0 (symmetric q).
+ *     qsum: ignored, may be NULL — the -zk'*qsum_i + d*zq'*zk' part of the zero-point restoration is
+ *           constant along a softmax row and cancels exactly.
  * ------------------------------------------------------------------------------------------ */
 int qd_quantize_heads(const void* x, int x_dtype, int B, int T, int H, int d,
                       int64_t sb, int64_t st, int64_t sh, int64_t sd, float prescale,

@@ -35,11 +35,19 @@ struct AttnK {
 
 // prm layout (device floats): 0 cs = dq*dk*scale | 1 zq' | 2 zk' | 3 dw | 4 zpw | 5 dw*dv | 6 zv'
 //
-// VALU budget (the kernel is VALU-bound: ~2x more vector ops than MFMA cycles): the softmax runs in
-// the exp2 domain with every constant folded (cs*log2e; inv_l/dw), the running max is taken on the
-// integer scores (monotone in the float score), probabilities are packed to MFMA operand bytes with
-// two v_perm_b32 per four values ((x-128)&0xff == x^0x80), and key masking exists only in the last
-// (ragged) tile.
+// VALU budget.  The kernel is VALU-bound (every score costs an int->float convert, an exp2 at quarter
+// rate and, in the second sweep, the quantisation of P), so the score path is kept to the minimum:
+//   * per-QUERY terms of the zero-point restoration (-zk*qsum_i + d*zq*zk) are dropped: a constant added
+//     to a softmax row cancels exactly.  Only the per-KEY term -zq*ksum_j is applied, as one 24-bit
+//     multiply-add (ksum <= d*128 and zq <= 255 fit v_mad_i32_i24; v_mul_lo_u32 is quarter rate);
+//   * the row maximum is subtracted in the INTEGER domain for free: the MFMA accumulator is initialised
+//     with -max instead of 0, so exp2 sees cs*log2e*(s - max) with an exact difference;
+//   * rounding to the probability grid is one float add of 1.5*2^23 (round-half-even lands in the low
+//     mantissa bits, which v_perm_b32 then scatters into the hi/lo operand bytes);
+//   * code sums come from v_dot4 on the packed operand bytes, not from per-score adds;
+//   * key masking exists only in the last (ragged) tile;
+// and the next K tile / this tile's V tile are prefetched into registers ahead of the softmax math, so
+// the L2 latency of the (tiny, shared) K/V stream hides behind ~1k VALU cycles.
 template <int DT, bool P16, bool ASYM>
 __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 4) ? 2 : 1) void attn_kernel(const AttnK p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -49,80 +57,102 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 4) ? 2 : 1) void attn_k
     if (q0 >= p.T) return;
 
     const float cs2 = p.prm[0] * 1.4426950408889634f;            // scores -> log2 domain
-    const int zq = (int)p.prm[1], zk = (int)p.prm[2];
+    const int nzq = -(int)p.prm[1];
     const float dw = p.prm[3], zpw = p.prm[4], oscale = p.prm[5];
     const int zv = (int)p.prm[6];
     const int izpw = (int)zpw;
     const float urange = p.wmax - p.wmin;                         // codes are handled as uu = u - wmin in [0, urange]
     const float ubias = zpw - p.wmin;
+    constexpr float MAGIC = 12582912.f;                           // 1.5 * 2^23: float add == round-half-even to integer
+    constexpr int   MASKED = -(1 << 30);
 
     v4i qf[DT];
     const int8_t* qrow = p.q + ((long)bh * p.Tpad + q0 + frow) * p.dpad + half * 16;
 #pragma unroll
     for (int kk = 0; kk < DT; ++kk) qf[kk] = *reinterpret_cast<const v4i*>(qrow + kk * 32);
-    int qs_term = 0;                                              // -zk*qsum[i] + d*zq*zk (per query)
-    if (ASYM) qs_term = -zk * p.qsum[(long)bh * p.Tpad + q0 + frow] + p.d * zq * zk;
 
     const int8_t* kbase = p.k + (long)bh * p.Spad * p.dpad + (long)frow * p.dpad + half * 16;
-    const int32_t* ksum = p.ksum + (long)bh * p.Spad + 4 * half;
+    const int32_t* ksum = ASYM ? p.ksum + (long)bh * p.Spad + 4 * half : nullptr;
     const int ntile = p.Spad >> 5;
     const int tail_tile = (p.S & 31) ? ntile - 1 : ntile;         // index of the ragged tile (or none)
 
-    // integer scores of key tile jt (zero points restored), C layout: si[4g+e] <-> key jt*32 + e + 8g + 4*half
-    auto int_scores = [&](int jt, int (&si)[16]) __attribute__((always_inline)) {
-        v16i acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0;
+    // K-tile registers (double-buffered by hand: `kf/ks` = current tile, loaded one iteration ahead)
+    auto load_k = [&](int jt, v4i (&kf)[DT], v4i (&ks)[4]) __attribute__((always_inline)) {
         const int8_t* kp = kbase + (long)jt * 32 * p.dpad;
 #pragma unroll
-        for (int kk = 0; kk < DT; ++kk) {
-            v4i kf = *reinterpret_cast<const v4i*>(kp + kk * 32);
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[kk], acc, 0, 0, 0);
-        }
+        for (int kk = 0; kk < DT; ++kk) kf[kk] = *reinterpret_cast<const v4i*>(kp + kk * 32);
+        if (ASYM) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            v4i ks = {0, 0, 0, 0};
-            if (ASYM) ks = *reinterpret_cast<const v4i*>(ksum + jt * 32 + 8 * g);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) si[g * 4 + e] = ASYM ? acc[g * 4 + e] + qs_term - zq * ks[e] : acc[g * 4 + e];
-        }
-        if (jt == tail_tile) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (j >= p.S) si[r] = INT_MIN;                    // masked: exp2(-inf) = 0
-            }
+            for (int g = 0; g < 4; ++g) ks[g] = *reinterpret_cast<const v4i*>(ksum + jt * 32 + 8 * g);
         }
     };
-    auto to_log2 = [&](int v) __attribute__((always_inline)) { return v == INT_MIN ? -INFINITY : (float)v * cs2; };
+    // d[4g+e] = (score of key jt*32 + e + 8g + 4*half) - base, per-query constants dropped
+    auto scores = [&](const v4i (&kf)[DT], const v4i (&ks)[4], int base, int (&d)[16]) __attribute__((always_inline)) {
+        v16i acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = -base;
+#pragma unroll
+        for (int kk = 0; kk < DT; ++kk) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], qf[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[g * 4 + e] = ASYM ? acc[g * 4 + e] + __mul24(nzq, ks[g][e]) : acc[g * 4 + e];
+    };
+    auto key_ok = [&](int jt, int r) __attribute__((always_inline)) { return jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half < p.S; };
 
-    // ---- sweep 1: row max and normaliser (online, log2 domain) ------------------------------------
-    float m = -INFINITY, l = 0.f;
-    for (int jt = 0; jt < ntile; ++jt) {
-        int si[16];
-        int_scores(jt, si);
-        int tmax = si[0];
+    // ---- sweep 1: row max (integer) and normaliser (online) ---------------------------------------
+    int mi;                                                       // running integer row max (shifted scores)
+    float l = 0.f;
+    {
+        v4i kf[DT], ks[4], kfn[DT], ksn[4];
+        load_k(0, kf, ks);
+        {   // seed the running max with tile 0's (so every later difference s - mi is small and exact in fp32)
+            int d[16];
+            scores(kf, ks, 0, d);
+            if (tail_tile == 0) {
 #pragma unroll
-        for (int r = 1; r < 16; ++r) tmax = max(tmax, si[r]);
-        const float mn = fmaxf(m, to_log2(tmax));
-        if (mn > -INFINITY) {
-            float a = 0.f;
-            if (jt == tail_tile) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a += __builtin_amdgcn_exp2f(to_log2(si[r]) - mn);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a += __builtin_amdgcn_exp2f(__builtin_fmaf((float)si[r], cs2, -mn));
+                for (int r = 0; r < 16; ++r) if (!key_ok(0, r)) d[r] = MASKED;
             }
-            l = l * __builtin_amdgcn_exp2f(m - mn) + a;
-            m = mn;
+            mi = d[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mi = max(mi, d[r]);
+        }
+        for (int jt = 0; jt < ntile; ++jt) {
+            if (jt + 1 < ntile) load_k(jt + 1, kfn, ksn);
+            int d[16];
+            scores(kf, ks, mi, d);                                // d = s - mi
+            const bool tail = jt == tail_tile;
+            if (tail) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (!key_ok(jt, r)) d[r] = MASKED;
+            }
+            int tmax = d[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = max(tmax, d[r]);
+            const int up = max(tmax, 0);                          // the row max moves up by `up`
+            const float shift = (float)up * cs2;
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf((float)d[r], cs2, -shift));
+                a += (tail && d[r] == MASKED) ? 0.f : e;
+            }
+            l = l * __builtin_amdgcn_exp2f(-shift) + a;           // first tile: l == 0, the factor is irrelevant
+            mi += up;
+            if (jt + 1 < ntile) {
+#pragma unroll
+                for (int kk = 0; kk < DT; ++kk) kf[kk] = kfn[kk];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ks[g] = ksn[g];
+            }
         }
     }
     {
-        const float mo = __shfl_xor(m, 32), lo = __shfl_xor(l, 32);
-        const float mf = fmaxf(m, mo);
-        l = (m > -INFINITY ? l * __builtin_amdgcn_exp2f(m - mf) : 0.f) + (mo > -INFINITY ? lo * __builtin_amdgcn_exp2f(mo - mf) : 0.f);
-        m = mf;
+        const int mo = __shfl_xor(mi, 32);
+        const float lo = __shfl_xor(l, 32);
+        const int mf = max(mi, mo);
+        l = l * __builtin_amdgcn_exp2f((float)(mi - mf) * cs2) + lo * __builtin_amdgcn_exp2f((float)(mo - mf) * cs2);
+        mi = mf;
     }
     const float inv = 1.0f / (l * dw);                            // p/dw = e * inv
 
@@ -135,48 +165,66 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 4) ? 2 : 1) void attn_k
             ol[t][r] = 0;
             if (P16) oh[P16 ? t : 0][r] = 0;
         }
-    int uusum = 0, nvalid = 0;
+    int dlo = 0, dhi = 0, nvalid = 0;                             // signed operand-byte sums, valid-key count
     const int8_t* vbase = p.vt + ((long)bh * p.dpad + frow) * p.Spad + half * 16;
-    for (int jt = 0; jt < ntile; ++jt) {
-        int si[16];
-        int_scores(jt, si);
-        int uu[16];
-        const bool tail = jt == tail_tile;
+    {
+        v4i kf[DT], ks[4], kfn[DT], ksn[4];
+        load_k(0, kf, ks);
+        for (int jt = 0; jt < ntile; ++jt) {
+            v4i vf[DT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float e = tail ? __builtin_amdgcn_exp2f(to_log2(si[r]) - m) : __builtin_amdgcn_exp2f(__builtin_fmaf((float)si[r], cs2, -m));
-            float t = __builtin_rintf(__builtin_fmaf(e, inv, ubias));
-            t = fminf(fmaxf(t, 0.f), urange);
-            uu[r] = (int)t;
-        }
-        if (tail) {
+            for (int t = 0; t < DT; ++t) vf[t] = *reinterpret_cast<const v4i*>(vbase + (long)t * 32 * p.Spad + jt * 32);
+            if (jt + 1 < ntile) load_k(jt + 1, kfn, ksn);
+            int d[16];
+            scores(kf, ks, mi, d);                                // d = s - rowmax <= 0
+            const bool tail = jt == tail_tile;
+            unsigned ub[16];                                      // float bits of uu + MAGIC: low 16 bits == uu
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const bool ok = si[r] != INT_MIN;
-                uusum += ok ? uu[r] : 0;
-                nvalid += ok ? 1 : 0;
-                if (!ok) uu[r] = 0x8080;                          // bytes that the ^0x80 below turns into 0
+                const float e = __builtin_amdgcn_exp2f((float)d[r] * cs2);
+                const float t = fminf(__builtin_fmaf(e, inv, ubias), urange) + MAGIC;   // e*inv + ubias >= 0 always
+                ub[r] = __float_as_uint(t);
             }
-        } else {
+            if (tail) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) uusum += uu[r];
-            nvalid += 16;
-        }
-        v4i plo, phi;
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = key_ok(jt, r);
+                    nvalid += ok ? 1 : 0;
+                    if (!ok) ub[r] = 0x8080u;                     // bytes that the ^0x80 below turns into 0
+                }
+            } else {
+                nvalid += 16;
+            }
+            v4i plo, phi;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const unsigned t01 = (unsigned)uu[4 * g] | ((unsigned)uu[4 * g + 1] << 16);
-            const unsigned t23 = (unsigned)uu[4 * g + 2] | ((unsigned)uu[4 * g + 3] << 16);
-            plo[g] = (int)(__builtin_amdgcn_perm(t23, t01, 0x06040200u) ^ 0x80808080u);
-            phi[g] = P16 ? (int)(__builtin_amdgcn_perm(t23, t01, 0x07050301u) ^ 0x80808080u) : 0;
-        }
+            for (int g = 0; g < 4; ++g) {
+                // bytes 0/1 of each word are the lo/hi byte of the code
+                const unsigned a01 = __builtin_amdgcn_perm(ub[4 * g + 1], ub[4 * g], 0x05010400u);      // lo0 lo1 hi0 hi1
+                const unsigned a23 = __builtin_amdgcn_perm(ub[4 * g + 3], ub[4 * g + 2], 0x05010400u);  // lo2 lo3 hi2 hi3
+                plo[g] = (int)(__builtin_amdgcn_perm(a23, a01, 0x05040100u) ^ 0x80808080u);
+                dlo = __builtin_amdgcn_sdot4(plo[g], 0x01010101, dlo, false);
+                if (P16) {
+                    phi[g] = (int)(__builtin_amdgcn_perm(a23, a01, 0x07060302u) ^ 0x80808080u);
+                    dhi = __builtin_amdgcn_sdot4(phi[g], 0x01010101, dhi, false);
+                } else {
+                    phi[g] = 0;
+                }
+            }
 #pragma unroll
-        for (int t = 0; t < DT; ++t) {
-            v4i vf = *reinterpret_cast<const v4i*>(vbase + (long)t * 32 * p.Spad + jt * 32);
-            ol[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(plo, vf, ol[t], 0, 0, 0);
-            if (P16) oh[P16 ? t : 0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(phi, vf, oh[P16 ? t : 0], 0, 0, 0);
+            for (int t = 0; t < DT; ++t) {
+                ol[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(plo, vf[t], ol[t], 0, 0, 0);
+                if (P16) oh[P16 ? t : 0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(phi, vf[t], oh[P16 ? t : 0], 0, 0, 0);
+            }
+            if (jt + 1 < ntile) {
+#pragma unroll
+                for (int kk = 0; kk < DT; ++kk) kf[kk] = kfn[kk];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ks[g] = ksn[g];
+            }
         }
     }
+    // sum over valid keys of uu = 256*hi + lo, from the signed operand bytes (masked keys hold 0)
+    int uusum = dlo + 128 * nvalid + (P16 ? 256 * (dhi + 128 * nvalid) : 0);
     uusum += __shfl_xor(uusum, 32);
     nvalid += __shfl_xor(nvalid, 32);
     const int usum = uusum + nvalid * p.iwmin;                     // sum over valid keys of the codes u = uu + wmin
@@ -223,8 +271,8 @@ extern "C" int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt, co
     QD_REQUIRE(wbits == 8 || wbits == 16, "qd_attn_i8: probability bits must be 8 or 16 (got %d)", wbits);
     QD_REQUIRE(wmax - wmin <= (wbits == 16 ? 65535 : 255), "qd_attn_i8: probability grid [%d,%d] wider than %d bits", wmin, wmax, wbits);
     QD_REQUIRE(qd_aligned(q, 16) && qd_aligned(k, 16) && qd_aligned(vt, 16), "qd_attn_i8: operands must be 16-byte aligned");
-    const bool asym = qsum != nullptr && ksum != nullptr;
-    QD_REQUIRE(asym || (qsum == nullptr && ksum == nullptr), "qd_attn_i8: pass both qsum and ksum or neither");
+    (void)qsum;                                  // per-query constants cancel in the softmax: never needed
+    const bool asym = ksum != nullptr;
     AttnK a{q, k, vt, qsum, ksum, vsum, prm, out, (long)ldo, BH, H, T, S, d, Tpad, Spad, dpad, (float)wmin, (float)wmax, wmin};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool p16 = wbits == 16;

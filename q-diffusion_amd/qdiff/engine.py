@@ -342,7 +342,7 @@ def attention(ap, q, k, v, B, T, S, H, d, q_strides, k_strides, v_strides, out=N
     q8 = torch.empty((BH, Tpad, dpad), dtype=torch.int8, device=dev)
     k8 = torch.empty((BH, Spad, dpad), dtype=torch.int8, device=dev)
     v8 = torch.empty((BH, dpad, Spad), dtype=torch.int8, device=dev)
-    qsum = torch.empty((BH, Tpad), dtype=torch.int32, device=dev) if ap.asym else None
+    qsum = None          # per-query zero-point terms are constant along a softmax row and cancel: not needed
     ksum = torch.empty((BH, Spad), dtype=torch.int32, device=dev) if ap.asym else None
     vsum = torch.empty((BH, dpad), dtype=torch.int32, device=dev)
     gq, gk, gv = ap.grids
