@@ -103,9 +103,15 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
     constexpr int NB = (NT * 16 + 63) / 64;       // B DMA instructions per wave per stage (NT*256 B per wave)
     constexpr int PER = NA + NB;
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE + 2 * BM * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE + 2 * BM * 4 + 4 * BN * 4];
     int* sRowB = reinterpret_cast<int*>(smem + 3 * STAGE);
     int* sAsum = sRowB + BM;
+    // per-output-channel epilogue constants of the LAST segment, fetched at kernel start so that their
+    // global-load latency overlaps the prologue DMA instead of serialising in front of the stores
+    float* sScale = reinterpret_cast<float*>(sAsum + BM);
+    int*   sZc    = reinterpret_cast<int*>(sScale + BN);
+    int*   sZw    = sZc + BN;
+    float* sBias  = reinterpret_cast<float*>(sZw + BN);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -248,6 +254,19 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
         }
     const int b_off = (fhalf * 32 + frow) * 8;   // + ks*512 + j*1024
 
+    float pr_scale = 0.f, pr_bias = 0.f;
+    int   pr_zc = 0, pr_zw = 0;
+    {
+        const SegD& sgl = p.seg[p.nseg - 1];
+        const int pn = n0 + (int)threadIdx.x;
+        if ((int)threadIdx.x < BN && pn < p.Cout) {
+            pr_scale = sgl.scale[pn];
+            if (sgl.zc) pr_zc = sgl.zc[pn];
+            if (sgl.zw) pr_zw = sgl.zw[pn];
+            if (p.bias) pr_bias = p.bias[pn];
+        }
+    }
+
     // ---- prologue: two stages in flight ----------------------------------------------------------
 #pragma unroll
     for (int d = 0; d < PER; ++d) issue_one(lds0, d);
@@ -256,6 +275,12 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
 #pragma unroll
         for (int d = 0; d < PER; ++d) issue_one(lds0 + STAGE, d);
         advance();
+    }
+    if ((int)threadIdx.x < BN) {                       // visible to every wave after the main loop's barriers
+        sScale[threadIdx.x] = pr_scale;
+        sZc[threadIdx.x]    = pr_zc;
+        sZw[threadIdx.x]    = pr_zw;
+        sBias[threadIdx.x]  = pr_bias;
     }
 
     auto flush_segment0 = [&]() __attribute__((always_inline)) {
@@ -345,10 +370,11 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
             const int nv = n0 + (2 * jp) * 32 + frow, ng = nv + 32;
             const int col = nb * (BN / 2) + jp * 32 + frow;
             const bool ok = col < Fout && ng < p.Cout;
-            const float sv = ok ? sg.scale[nv] : 0.f, sgt = ok ? sg.scale[ng] : 0.f;
-            const int zcv = (ok && sg.zc) ? sg.zc[nv] : 0, zcg = (ok && sg.zc) ? sg.zc[ng] : 0;
-            const int zwv = (ok && sg.zw) ? sg.zw[nv] : 0, zwg = (ok && sg.zw) ? sg.zw[ng] : 0;
-            const float bv = (ok && p.bias) ? p.bias[nv] : 0.f, bg = (ok && p.bias) ? p.bias[ng] : 0.f;
+            const int lv = (2 * jp) * 32 + frow, lg = lv + 32;            // tile-local channel of value / gate
+            const float sv = sScale[lv], sgt = sScale[lg];
+            const int zcv = sZc[lv], zcg = sZc[lg];
+            const int zwv = sZw[lv], zwg = sZw[lg];
+            const float bv = sBias[lv], bg = sBias[lg];
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -365,42 +391,64 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
         }
         return;
     }
+    // Branch-free per 32x32 tile: out-of-range rows/columns are handled by CLAMPING the addresses of the
+    // residual / row-bias loads (and predicating only the stores), so the 16 loads of a tile are issued
+    // back to back.  (With a per-element `if (...) continue;` every load sat in its own basic block and the
+    // epilogue paid one memory latency per element: layers with a residual ran 2-3x slower.)
+    const bool has_rb = p.rowbias != nullptr, has_res = p.residual != nullptr;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + j * 32 + frow;
         const bool nok = n < p.Cout;
-        const float sc = nok ? sg.scale[n] : 0.f;
-        const int zc_n = (nok && sg.zc) ? sg.zc[n] : 0;
-        const int zw_n = (nok && sg.zw) ? sg.zw[n] : 0;
-        const float bias_n = (nok && p.bias) ? p.bias[n] : 0.f;
+        const int nc = nok ? n : 0;
+        const float sc = sScale[j * 32 + frow];
+        const int zc_n = sZc[j * 32 + frow];
+        const int zw_n = sZw[j * 32 + frow];
+        const float bias_n = sBias[j * 32 + frow];
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i) {
+            const int rbase = wave * (32 * MT) + i * 32 + 4 * fhalf;        // rowl = rbase + (r&3) + 8*(r>>2)
+            if constexpr (OUT == O_PART || OUT == O_I32) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rowl = wave * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                const int m = m0 + rowl;
-                if (!nok || m >= p.M) continue;
-                if (OUT == O_PART) {
-                    p.iout[((long)blockIdx.y * p.M + m) * p.Cout + n] = acc[i][j][r] - zw_n * sAsum[rowl];
-                    continue;
+                for (int r = 0; r < 16; ++r) {
+                    const int rowl = rbase + (r & 3) + 8 * (r >> 2);
+                    const int m = m0 + rowl;
+                    if (!nok || m >= p.M) continue;
+                    if (OUT == O_PART) p.iout[((long)blockIdx.y * p.M + m) * p.Cout + n] = acc[i][j][r] - zw_n * sAsum[rowl];
+                    else p.iout[(long)m * p.Cout + n] = acc[i][j][r] - zc_n - zw_n * (sAsum[rowl] - kz);
                 }
-                const int I = acc[i][j][r] - zc_n - zw_n * (sAsum[rowl] - kz);
-                if (OUT == O_I32) {
-                    p.iout[(long)m * p.Cout + n] = I;
-                    continue;
+            } else {
+                float rb[16], rs[16];
+                if (has_rb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rb[r] = p.rowbias[(long)sRowB[rbase + (r & 3) + 8 * (r >> 2)] * p.ldrb + nc];
                 }
-                float v = (float)I * sc;
-                if (SPLIT) v += facc[SPLIT ? i : 0][SPLIT ? j : 0][r];
-                v += bias_n;
-                if (p.rowbias) v += p.rowbias[(long)sRowB[rowl] * p.ldrb + n];
-                if (OUT == O_F32) {
-                    if (p.residual) v += reinterpret_cast<const float*>(p.residual)[(long)m * p.ldr + n];
-                    reinterpret_cast<float*>(p.out)[(long)m * p.ldo + n] = v;
-                } else {
-                    if (p.residual) v += __half2float(reinterpret_cast<const __half*>(p.residual)[(long)m * p.ldr + n]);
-                    reinterpret_cast<__half*>(p.out)[(long)m * p.ldo + n] = __float2half(v);
+                if (has_res) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + rbase + (r & 3) + 8 * (r >> 2);
+                        const long off = (long)(m < p.M ? m : 0) * p.ldr + nc;
+                        if (OUT == O_F32) rs[r] = reinterpret_cast<const float*>(p.residual)[off];
+                        else rs[r] = __half2float(reinterpret_cast<const __half*>(p.residual)[off]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rowl = rbase + (r & 3) + 8 * (r >> 2);
+                    const int m = m0 + rowl;
+                    const int I = acc[i][j][r] - zc_n - zw_n * (sAsum[rowl] - kz);
+                    float v = (float)I * sc;
+                    if (SPLIT) v += facc[SPLIT ? i : 0][SPLIT ? j : 0][r];
+                    v += bias_n;
+                    if (has_rb) v += rb[r];
+                    if (has_res) v += rs[r];
+                    if (nok && m < p.M) {
+                        if (OUT == O_F32) reinterpret_cast<float*>(p.out)[(long)m * p.ldo + n] = v;
+                        else reinterpret_cast<__half*>(p.out)[(long)m * p.ldo + n] = __float2half(v);
+                    }
                 }
             }
+        }
     }
 }
 

@@ -41,7 +41,13 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     tot_ops = tot_us = 0.0
     only = os.environ.get("IGEMM_ONLY")
-    for name, B, Cin, H, Cout, k, stride in SHAPES:
+    shapes = SHAPES
+    if os.environ.get("IGEMM_SHAPES"):          # "B,Cin,H,Cout,k,stride;..." custom sweep
+        shapes = []
+        for spec in os.environ["IGEMM_SHAPES"].split(";"):
+            B, Cin, H, Cout, k, stride = (int(v) for v in spec.split(","))
+            shapes.append((f"custom {spec}", B, Cin, H, Cout, k, stride))
+    for name, B, Cin, H, Cout, k, stride in shapes:
         if only and only not in name:
             continue
         w = torch.randn(Cout, Cin, k, k, device=dev, generator=g) * 0.05
