@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rowl = wave * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                    const int I = acc[i][j][r] - zc_n - zw_n * (sAsum[rowl] - kz);
+                    const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rowl] - kz);
                     facc[SPLIT ? i : 0][SPLIT ? j : 0][r] = (float)I * sc;
                     acc[i][j][r] = 0;
                 }
@@ -357,94 +357,110 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
     __syncthreads();                                   // sAsum / sRowB visible to every wave
     const SegD& sg = p.seg[p.nseg - 1];
     const int kz = sg.zfill ? sg.zfill[1] : 0;
+    // Addressing: every global access of the epilogue is (uniform 64-bit base of this block) + (32-bit lane
+    // offset), and the 16 rows a lane owns differ by compile-time multiples of the row stride, so an element
+    // costs one v_add_u32 instead of a 64-bit multiply-add.  zw * Asum uses the 24-bit multiplier (both
+    // factors fit: |zw| <= 128, |Asum - kz| <= 2 * 128 * K < 2^23, checked on the host).
     if constexpr (OUT == O_GEGLU) {
         // weight rows were packed (value tile, gate tile) interleaved: tiles 2jp / 2jp+1 of this lane hold
         // the value and the gate of output feature nb*(BN/2) + jp*32 + frow.  y = value * gelu(gate)
         // (erf GELU, ldm/modules/attention.py:42-44), then the next Linear's act quantiser, 1 byte out.
         static_assert(NT % 2 == 0, "GEGLU epilogue pairs n-tiles");
         const float od = p.oq[0], oz = p.oq[1];
-        int8_t* o8 = reinterpret_cast<int8_t*>(p.out);
+        int8_t* o8 = reinterpret_cast<int8_t*>(p.out) + (long)m0 * p.ldo + nb * (BN / 2);
+        const unsigned ldo = (unsigned)p.ldo;
         const int Fout = p.Cout >> 1;
 #pragma unroll
         for (int jp = 0; jp < NT / 2; ++jp) {
-            const int nv = n0 + (2 * jp) * 32 + frow, ng = nv + 32;
-            const int col = nb * (BN / 2) + jp * 32 + frow;
-            const bool ok = col < Fout && ng < p.Cout;
             const int lv = (2 * jp) * 32 + frow, lg = lv + 32;            // tile-local channel of value / gate
+            const int cl = jp * 32 + frow;
+            const bool ok = nb * (BN / 2) + cl < Fout && n0 + lg < p.Cout;
             const float sv = sScale[lv], sgt = sScale[lg];
             const int zcv = sZc[lv], zcg = sZc[lg];
             const int zwv = sZw[lv], zwg = sZw[lg];
             const float bv = sBias[lv], bg = sBias[lg];
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i) {
+                const int rbase = wave * (32 * MT) + i * 32 + 4 * fhalf;
+                const unsigned o0 = (unsigned)rbase * ldo + cl;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int rowl = wave * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                    const int m = m0 + rowl;
-                    if (!ok || m >= p.M) continue;
+                    const int cr = (r & 3) + 8 * (r >> 2);
+                    const int rowl = rbase + cr;
                     const int as = sAsum[rowl] - kz;
-                    const float val = (float)(acc[i][2 * jp][r] - zcv - zwv * as) * sv + bv;
-                    const float gate = (float)(acc[i][2 * jp + 1][r] - zcg - zwg * as) * sgt + bg;
-                    const float y = val * (0.5f * gate * (1.0f + erff(gate * 0.70710678118654752440f)));
-                    o8[(long)m * p.ldo + col] = (int8_t)(qd_code(y, od, oz, p.oqmin, p.oqmax) - p.oqoff);
+                    const float val = (float)(acc[i][2 * jp][r] - zcv - __mul24(zwv, as)) * sv + bv;
+                    const float gate = (float)(acc[i][2 * jp + 1][r] - zcg - __mul24(zwg, as)) * sgt + bg;
+                    const float y = val * (0.5f * gate * (1.0f + qd_erff(gate * 0.70710678118654752440f)));
+                    const int8_t code = (int8_t)(qd_code(y, od, oz, p.oqmin, p.oqmax) - p.oqoff);
+                    if (ok && m0 + rowl < p.M) o8[o0 + (unsigned)cr * ldo] = code;      // only the store is predicated
                 }
+            }
         }
         return;
     }
-    // Branch-free per 32x32 tile: out-of-range rows/columns are handled by CLAMPING the addresses of the
+    // Branch-free per 32x32 tile: out-of-range rows/columns are handled by CLAMPING the offsets of the
     // residual / row-bias loads (and predicating only the stores), so the 16 loads of a tile are issued
     // back to back.  (With a per-element `if (...) continue;` every load sat in its own basic block and the
     // epilogue paid one memory latency per element: layers with a residual ran 2-3x slower.)
     const bool has_rb = p.rowbias != nullptr, has_res = p.residual != nullptr;
+    const unsigned ldo = (unsigned)p.ldo, ldr = (unsigned)p.ldr, ldc = (unsigned)p.Cout;
+    float*  const of = reinterpret_cast<float*>(p.out) + (long)m0 * p.ldo + n0;
+    __half* const oh = reinterpret_cast<__half*>(p.out) + (long)m0 * p.ldo + n0;
+    const float*  const rf = reinterpret_cast<const float*>(p.residual) + (long)m0 * p.ldr + n0;
+    const __half* const rh = reinterpret_cast<const __half*>(p.residual) + (long)m0 * p.ldr + n0;
+    int32_t* const oi = p.iout + ((OUT == O_PART ? (long)blockIdx.y * p.M : 0L) + m0) * p.Cout + n0;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int n = n0 + j * 32 + frow;
-        const bool nok = n < p.Cout;
-        const int nc = nok ? n : 0;
-        const float sc = sScale[j * 32 + frow];
-        const int zc_n = sZc[j * 32 + frow];
-        const int zw_n = sZw[j * 32 + frow];
-        const float bias_n = sBias[j * 32 + frow];
+        const int cl = j * 32 + frow;
+        const bool nok = n0 + cl < p.Cout;
+        const int clc = nok ? cl : 0;
+        const float sc = sScale[cl];
+        const int zc_n = sZc[cl];
+        const int zw_n = sZw[cl];
+        const float bias_n = sBias[cl];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int rbase = wave * (32 * MT) + i * 32 + 4 * fhalf;        // rowl = rbase + (r&3) + 8*(r>>2)
             if constexpr (OUT == O_PART || OUT == O_I32) {
+                const unsigned o0 = (unsigned)rbase * ldc + cl;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int rowl = rbase + (r & 3) + 8 * (r >> 2);
-                    const int m = m0 + rowl;
-                    if (!nok || m >= p.M) continue;
-                    if (OUT == O_PART) p.iout[((long)blockIdx.y * p.M + m) * p.Cout + n] = acc[i][j][r] - zw_n * sAsum[rowl];
-                    else p.iout[(long)m * p.Cout + n] = acc[i][j][r] - zc_n - zw_n * (sAsum[rowl] - kz);
+                    const int cr = (r & 3) + 8 * (r >> 2);
+                    const int rowl = rbase + cr;
+                    const int v = OUT == O_PART ? acc[i][j][r] - __mul24(zw_n, sAsum[rowl])
+                                                : acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rowl] - kz);
+                    if (nok && m0 + rowl < p.M) oi[o0 + (unsigned)cr * ldc] = v;
                 }
             } else {
                 float rb[16], rs[16];
                 if (has_rb) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) rb[r] = p.rowbias[(long)sRowB[rbase + (r & 3) + 8 * (r >> 2)] * p.ldrb + nc];
+                    for (int r = 0; r < 16; ++r) rb[r] = p.rowbias[(long)sRowB[rbase + (r & 3) + 8 * (r >> 2)] * p.ldrb + n0 + clc];
                 }
                 if (has_res) {
+                    const unsigned r0 = (unsigned)rbase * ldr + clc;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + rbase + (r & 3) + 8 * (r >> 2);
-                        const long off = (long)(m < p.M ? m : 0) * p.ldr + nc;
-                        if (OUT == O_F32) rs[r] = reinterpret_cast<const float*>(p.residual)[off];
-                        else rs[r] = __half2float(reinterpret_cast<const __half*>(p.residual)[off]);
+                        const int cr = (r & 3) + 8 * (r >> 2);
+                        const unsigned off = (m0 + rbase + cr < p.M) ? r0 + (unsigned)cr * ldr : (unsigned)clc;   // row m0 always exists
+                        if (OUT == O_F32) rs[r] = rf[off];
+                        else rs[r] = __half2float(rh[off]);
                     }
                 }
+                const unsigned o0 = (unsigned)rbase * ldo + cl;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int rowl = rbase + (r & 3) + 8 * (r >> 2);
-                    const int m = m0 + rowl;
-                    const int I = acc[i][j][r] - zc_n - zw_n * (sAsum[rowl] - kz);
+                    const int cr = (r & 3) + 8 * (r >> 2);
+                    const int rowl = rbase + cr;
+                    const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rowl] - kz);
                     float v = (float)I * sc;
                     if (SPLIT) v += facc[SPLIT ? i : 0][SPLIT ? j : 0][r];
                     v += bias_n;
                     if (has_rb) v += rb[r];
                     if (has_res) v += rs[r];
-                    if (nok && m < p.M) {
-                        if (OUT == O_F32) reinterpret_cast<float*>(p.out)[(long)m * p.ldo + n] = v;
-                        else reinterpret_cast<__half*>(p.out)[(long)m * p.ldo + n] = __float2half(v);
+                    if (nok && m0 + rowl < p.M) {
+                        if (OUT == O_F32) of[o0 + (unsigned)cr * ldo] = v;
+                        else oh[o0 + (unsigned)cr * ldo] = __float2half(v);
                     }
                 }
             }
@@ -600,6 +616,9 @@ int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
         QD_REQUIRE(!g.fill16 || qd_aligned(g.fill16, 16), "qd_conv2d_i8 (tiled): fill16 must be 16-byte aligned");
         k.seg[s] = SegD{g.c0, g.clen, g.kstep0, (g.clen + 63) / 64, g.scale, g.zc, g.zw, g.zfill, g.fill16};
     }
+    QD_REQUIRE((long)d->kh * d->kw * (d->seg[0].clen + (d->nseg == 2 ? d->seg[1].clen : 0)) < 32768,
+               "qd_conv2d_i8 (tiled): K too long for the 24-bit zero-point multiply");
+    QD_REQUIRE(d->ldo < (1 << 22) && d->ldr < (1 << 22) && d->Cout < (1 << 22), "qd_conv2d_i8 (tiled): row strides must be < 2^22 elements");
     const bool split = d->nseg == 2;
     const bool geglu = d->epilogue == QD_EPI_GEGLU_I8;
     const int out = geglu ? O_GEGLU : (iout ? O_I32 : (d->out_dtype == QD_F16 ? O_F16 : O_F32));

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void geglu_quant_kernel(const T* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float a = qd_ld(xa + wd * 4 + j), g = qd_ld(xg + wd * 4 + j);
-            float gl = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
+            float gl = 0.5f * g * (1.0f + qd_erff(g * 0.70710678118654752440f));
             int code = qd_code(a * gl, delta, zp, qmin, qmax) - off;
             u |= (unsigned)(code & 0xff) << (8 * j);
         }
