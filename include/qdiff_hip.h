@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 3
+#define QD_ABI_VERSION 4
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -209,9 +209,10 @@ int qd_geglu_quant(const void* h, int h_dtype, int64_t M, int F, int64_t ldh,
  *             O is written as out[b][t][h*d + c] (merged heads, ldo = row stride, fp32).
  *     prm: device float[16] = {cs (=dq*dk*scale), zq', zk', dw, zpw, dv_dw (=dw*dv), zv', ...}
  *          (layout in DESIGN.md §4.4); built once on device by the host, never read back.
- *     ksum: row sums of the stored k bytes (rsum of step 1), or NULL when zq' == 0 (symmetric q).
- *     qsum: ignored, may be NULL — the -zk'*qsum_i + d*zq'*zk' part of the zero-point restoration is
- *           constant along a softmax row and cancels exactly.
+ *     q_asym: 0 when zq' == 0 (symmetric q quantiser), else 1: the kernel then restores the per-key term
+ *           -zq' * sum_d k'[j][d] with a constant-operand MFMA.  qsum / ksum are ignored (may be NULL; kept
+ *           for source compatibility): the per-query terms -zk'*qsum_i + d*zq'*zk' are constant along a
+ *           softmax row and cancel exactly.
  * ------------------------------------------------------------------------------------------ */
 int qd_quantize_heads(const void* x, int x_dtype, int B, int T, int H, int d,
                       int64_t sb, int64_t st, int64_t sh, int64_t sd, float prescale,
@@ -221,7 +222,7 @@ int qd_quantize_heads(const void* x, int x_dtype, int B, int T, int H, int d,
 int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt,
                const int32_t* qsum, const int32_t* ksum, const int32_t* vsum,
                int BH, int H, int T, int S, int d, int Tpad, int Spad, int dpad,
-               const float* prm, int wbits, int wmin, int wmax,
+               const float* prm, int wbits, int wmin, int wmax, int q_asym,
                float* out, int64_t ldo, void* stream);
 
 #ifdef __cplusplus

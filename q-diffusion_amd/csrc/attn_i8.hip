@@ -38,8 +38,9 @@ struct AttnK {
 // VALU budget.  The kernel is VALU-bound (every score costs an int->float convert, an exp2 at quarter
 // rate and, in the second sweep, the quantisation of P), so the score path is kept to the minimum:
 //   * per-QUERY terms of the zero-point restoration (-zk*qsum_i + d*zq*zk) are dropped: a constant added
-//     to a softmax row cancels exactly.  Only the per-KEY term -zq*ksum_j is applied, as one 24-bit
-//     multiply-add (ksum <= d*128 and zq <= 255 fit v_mad_i32_i24; v_mul_lo_u32 is quarter rate);
+//     to a softmax row cancels exactly.  The per-KEY term -zq*sum_d k'[j][d] is computed by the matrix
+//     pipe itself: one more MFMA per K fragment against a constant operand whose bytes are all -zq
+//     (the MFMA pipe has slack, the VALU does not), so no key row sums are needed at all;
 //   * the row maximum is subtracted in the INTEGER domain for free: the MFMA accumulator is initialised
 //     with -max instead of 0, so exp2 sees cs*log2e*(s - max) with an exact difference;
 //   * rounding to the probability grid is one float add of 1.5*2^23 (round-half-even lands in the low
@@ -73,31 +74,35 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 4) ? 2 : 1) void attn_k
     for (int kk = 0; kk < DT; ++kk) qf[kk] = *reinterpret_cast<const v4i*>(qrow + kk * 32);
 
     const int8_t* kbase = p.k + (long)bh * p.Spad * p.dpad + (long)frow * p.dpad + half * 16;
-    const int32_t* ksum = ASYM ? p.ksum + (long)bh * p.Spad + 4 * half : nullptr;
+    // -zq' in [-127, 128] as one or two int8 constants (128 does not fit a signed byte)
+    const int c1 = nzq > 127 ? 64 : nzq, c2 = nzq - c1;
+    const int c1w = (c1 & 0xff) * 0x01010101, c2w = (c2 & 0xff) * 0x01010101;
+    const v4i c1v = {c1w, c1w, c1w, c1w}, c2v = {c2w, c2w, c2w, c2w};
     const int ntile = p.Spad >> 5;
     const int tail_tile = (p.S & 31) ? ntile - 1 : ntile;         // index of the ragged tile (or none)
 
     // K-tile registers (double-buffered by hand: `kf/ks` = current tile, loaded one iteration ahead)
-    auto load_k = [&](int jt, v4i (&kf)[DT], v4i (&ks)[4]) __attribute__((always_inline)) {
+    auto load_k = [&](int jt, v4i (&kf)[DT]) __attribute__((always_inline)) {
         const int8_t* kp = kbase + (long)jt * 32 * p.dpad;
 #pragma unroll
         for (int kk = 0; kk < DT; ++kk) kf[kk] = *reinterpret_cast<const v4i*>(kp + kk * 32);
-        if (ASYM) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) ks[g] = *reinterpret_cast<const v4i*>(ksum + jt * 32 + 8 * g);
-        }
     };
     // d[4g+e] = (score of key jt*32 + e + 8g + 4*half) - base, per-query constants dropped
-    auto scores = [&](const v4i (&kf)[DT], const v4i (&ks)[4], int base, int (&d)[16]) __attribute__((always_inline)) {
+    auto scores = [&](const v4i (&kf)[DT], int base, int (&d)[16]) __attribute__((always_inline)) {
         v16i acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = -base;
 #pragma unroll
-        for (int kk = 0; kk < DT; ++kk) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], qf[kk], acc, 0, 0, 0);
+        for (int kk = 0; kk < DT; ++kk) {
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], qf[kk], acc, 0, 0, 0);
+            if (ASYM) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], c1v, acc, 0, 0, 0);
+        }
+        if (ASYM && c2 != 0) {                                    // wave-uniform, only when zq' == -128
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+            for (int kk = 0; kk < DT; ++kk) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], c2v, acc, 0, 0, 0);
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) d[g * 4 + e] = ASYM ? acc[g * 4 + e] + __mul24(nzq, ks[g][e]) : acc[g * 4 + e];
+        for (int r = 0; r < 16; ++r) d[r] = acc[r];
     };
     auto key_ok = [&](int jt, int r) __attribute__((always_inline)) { return jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half < p.S; };
 
@@ -105,11 +110,11 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 4) ? 2 : 1) void attn_k
     int mi;                                                       // running integer row max (shifted scores)
     float l = 0.f;
     {
-        v4i kf[DT], ks[4], kfn[DT], ksn[4];
-        load_k(0, kf, ks);
+        v4i kf[DT], kfn[DT];
+        load_k(0, kf);
         {   // seed the running max with tile 0's (so every later difference s - mi is small and exact in fp32)
             int d[16];
-            scores(kf, ks, 0, d);
+            scores(kf, 0, d);
             if (tail_tile == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) if (!key_ok(0, r)) d[r] = MASKED;
@@ -119,9 +124,9 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 4) ? 2 : 1) void attn_k
             for (int r = 1; r < 16; ++r) mi = max(mi, d[r]);
         }
         for (int jt = 0; jt < ntile; ++jt) {
-            if (jt + 1 < ntile) load_k(jt + 1, kfn, ksn);
+            if (jt + 1 < ntile) load_k(jt + 1, kfn);
             int d[16];
-            scores(kf, ks, mi, d);                                // d = s - mi
+            scores(kf, mi, d);                                // d = s - mi
             const bool tail = jt == tail_tile;
             if (tail) {
 #pragma unroll
@@ -143,8 +148,6 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 4) ? 2 : 1) void attn_k
             if (jt + 1 < ntile) {
 #pragma unroll
                 for (int kk = 0; kk < DT; ++kk) kf[kk] = kfn[kk];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) ks[g] = ksn[g];
             }
         }
     }
@@ -169,15 +172,15 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 4) ? 2 : 1) void attn_k
     int dlo = 0, dhi = 0, nvalid = 0;                             // signed operand-byte sums, valid-key count
     const int8_t* vbase = p.vt + ((long)bh * p.dpad + frow) * p.Spad + half * 16;
     {
-        v4i kf[DT], ks[4], kfn[DT], ksn[4];
-        load_k(0, kf, ks);
+        v4i kf[DT], kfn[DT];
+        load_k(0, kf);
         for (int jt = 0; jt < ntile; ++jt) {
             v4i vf[DT];
 #pragma unroll
             for (int t = 0; t < DT; ++t) vf[t] = *reinterpret_cast<const v4i*>(vbase + (long)t * 32 * p.Spad + jt * 32);
-            if (jt + 1 < ntile) load_k(jt + 1, kfn, ksn);
+            if (jt + 1 < ntile) load_k(jt + 1, kfn);
             int d[16];
-            scores(kf, ks, mi, d);                                // d = s - rowmax <= 0
+            scores(kf, mi, d);                                // d = s - rowmax <= 0
             const bool tail = jt == tail_tile;
             unsigned ub[16];                                      // float bits of uu + MAGIC: low 16 bits == uu
 #pragma unroll
@@ -219,8 +222,6 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 4) ? 2 : 1) void attn_k
             if (jt + 1 < ntile) {
 #pragma unroll
                 for (int kk = 0; kk < DT; ++kk) kf[kk] = kfn[kk];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) ks[g] = ksn[g];
             }
         }
     }
@@ -264,7 +265,7 @@ int launch_dt(const AttnK& k, bool p16, bool asym, hipStream_t st) {
 
 extern "C" int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt, const int32_t* qsum, const int32_t* ksum,
                           const int32_t* vsum, int BH, int H, int T, int S, int d, int Tpad, int Spad, int dpad,
-                          const float* prm, int wbits, int wmin, int wmax, float* out, int64_t ldo, void* stream) {
+                          const float* prm, int wbits, int wmin, int wmax, int q_asym, float* out, int64_t ldo, void* stream) {
     QD_REQUIRE(q && k && vt && vsum && prm && out, "qd_attn_i8: null pointer");
     QD_REQUIRE(BH > 0 && H > 0 && BH % H == 0 && T > 0 && S > 0 && d > 0, "qd_attn_i8: bad shape");
     QD_REQUIRE(Tpad % 32 == 0 && Spad % 32 == 0 && dpad % 32 == 0 && Tpad >= T && Spad >= S && dpad >= d, "qd_attn_i8: padded dims must be multiples of 32");
@@ -273,7 +274,8 @@ extern "C" int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt, co
     QD_REQUIRE(wmax - wmin <= (wbits == 16 ? 65535 : 255), "qd_attn_i8: probability grid [%d,%d] wider than %d bits", wmin, wmax, wbits);
     QD_REQUIRE(qd_aligned(q, 16) && qd_aligned(k, 16) && qd_aligned(vt, 16), "qd_attn_i8: operands must be 16-byte aligned");
     (void)qsum;                                  // per-query constants cancel in the softmax: never needed
-    const bool asym = ksum != nullptr;
+    (void)ksum;                                  // per-key term: constant-operand MFMA inside the kernel
+    const bool asym = q_asym != 0;
     AttnK a{q, k, vt, qsum, ksum, vsum, prm, out, (long)ldo, BH, H, T, S, d, Tpad, Spad, dpad, (float)wmin, (float)wmax, wmin};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool p16 = wbits == 16;

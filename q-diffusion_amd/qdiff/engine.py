@@ -327,7 +327,7 @@ def build_attn_plan(aq_q, aq_k, aq_v, aq_w, scale, prescale, device):
     ap.prm = prm
     ap.grids = (gq, gk, gv)
     ap.qparams = (qq, qk, qv)
-    ap.asym = not (aq_q.sym and aq_k.sym)
+    ap.asym = not aq_q.sym                 # q has a non-zero stored zero point -> per-key restoration term
     ap.prescale = float(prescale)
     ap.scale = float(scale)
     return ap
@@ -342,16 +342,16 @@ def attention(ap, q, k, v, B, T, S, H, d, q_strides, k_strides, v_strides, out=N
     q8 = torch.empty((BH, Tpad, dpad), dtype=torch.int8, device=dev)
     k8 = torch.empty((BH, Spad, dpad), dtype=torch.int8, device=dev)
     v8 = torch.empty((BH, dpad, Spad), dtype=torch.int8, device=dev)
-    qsum = None          # per-query zero-point terms are constant along a softmax row and cancel: not needed
-    ksum = torch.empty((BH, Spad), dtype=torch.int32, device=dev) if ap.asym else None
+    # no q/k row sums: per-query zero-point terms cancel in the softmax, the per-key term is restored by
+    # the attention kernel's constant-operand MFMA
     vsum = torch.empty((BH, dpad), dtype=torch.int32, device=dev)
     gq, gk, gv = ap.grids
-    hip.quantize_heads(q, B, T, H, d, q_strides, ap.prescale, ap.qparams[0], gq, False, q8, qsum, Tpad, dpad)
-    hip.quantize_heads(k, B, S, H, d, k_strides, ap.prescale, ap.qparams[1], gk, False, k8, ksum, Spad, dpad)
+    hip.quantize_heads(q, B, T, H, d, q_strides, ap.prescale, ap.qparams[0], gq, False, q8, None, Tpad, dpad)
+    hip.quantize_heads(k, B, S, H, d, k_strides, ap.prescale, ap.qparams[1], gk, False, k8, None, Spad, dpad)
     hip.quantize_heads(v, B, S, H, d, v_strides, 1.0, ap.qparams[2], gv, True, v8, vsum, Spad, dpad)
     if out is None:
         out = torch.empty((B * T, H * d), dtype=torch.float32, device=dev)
-    hip.attn_i8(q8, k8, v8, qsum, ksum, vsum, BH, H, T, S, d, Tpad, Spad, dpad, ap.prm, ap.wbits, ap.wmin, ap.wmax,
+    hip.attn_i8(q8, k8, v8, vsum, BH, H, T, S, d, Tpad, Spad, dpad, ap.prm, ap.wbits, ap.wmin, ap.wmax, ap.asym,
                 out, out.stride(0))
     return out
 

@@ -82,9 +82,9 @@ def load():
     lib.qd_geglu_quant.argtypes = [vp, i32, i64, i32, i64, vp, i32, i32, i32, vp, i64, vp]
     lib.qd_quantize_heads.argtypes = [vp, i32, i32, i32, i32, i32, i64, i64, i64, i64, f32, vp, i32, i32, i32, i32,
                                       vp, vp, i32, i32, vp]
-    lib.qd_attn_i8.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp,
+    lib.qd_attn_i8.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp,
                                i64, vp]
-    if lib.qd_abi_version() != 3:
+    if lib.qd_abi_version() != 4:
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -264,6 +264,7 @@ def quantize_heads(x, B, T, H, d, strides, prescale, qparams, grid, transpose, o
                                     dpad, _stream()), "qd_quantize_heads")
 
 
-def attn_i8(q, k, vt, qsum, ksum, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, wmax, out, ldo):
-    _check(load().qd_attn_i8(_ptr(q), _ptr(k), _ptr(vt), _ptr(qsum), _ptr(ksum), _ptr(vsum), BH, H, T, S, d, Tpad, Spad,
-                             dpad, _ptr(prm), wbits, wmin, wmax, _ptr(out), ldo, _stream()), "qd_attn_i8")
+def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, wmax, q_asym, out, ldo):
+    """q_asym: the q quantiser has a non-zero stored zero point (the kernel restores -zq'*sum_d k' itself)."""
+    _check(load().qd_attn_i8(_ptr(q), _ptr(k), _ptr(vt), None, None, _ptr(vsum), BH, H, T, S, d, Tpad, Spad,
+                             dpad, _ptr(prm), wbits, wmin, wmax, 1 if q_asym else 0, _ptr(out), ldo, _stream()), "qd_attn_i8")

@@ -212,7 +212,7 @@ def quantize_heads(x, B, T, H, d, strides, prescale, qparams, grid, transpose, o
             rsum.copy_(buf.sum(1).to(torch.int32))
 
 
-def attn_i8(q, k, vt, qsum, ksum, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, wmax, out, ldo):
+def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, wmax, q_asym, out, ldo):
     cs, zq, zk, dw, zpw, osc, zv = (float(prm[i]) for i in range(7))
     inv = torch.empty(Spad, dtype=torch.long)
     inv[_perm_index(Spad)] = torch.arange(Spad)
