@@ -34,12 +34,12 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 4
+#define QD_ABI_VERSION 5
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
 /* epilogues of qd_conv2d_i8 */
-enum { QD_EPI_LINEAR = 0, QD_EPI_GEGLU_I8 = 1 };
+enum { QD_EPI_LINEAR = 0, QD_EPI_GEGLU_I8 = 1, QD_EPI_HEADS_I8 = 2, QD_EPI_HEADS_T_I8 = 3 };
 
 int         qd_abi_version(void);
 const char* qd_last_error(void);
@@ -132,6 +132,18 @@ typedef struct {
                                       per K range (exact), then one pass that sums them and applies the epilogue.
                                       NULL = never split.  Results do not depend on it (integer partial sums).       */
     int64_t        splitk_ws_bytes;
+    /* QD_EPI_HEADS_I8 / QD_EPI_HEADS_T_I8 (w_tiled, one segment): the Linear is a q/k/v projection of an
+     * attention block (qdiff/quant_block.py:190-221).  Rows are m = b*hd_T + t, columns n = h*hd_d + dd.
+     * y = (I*scale + bias) * oq_prescale is quantised with oq_* (the block's act_quantizer_q/k/v) and
+     * written as int8 in the operand layout of qd_attn_i8, exactly what qd_quantize_heads would produce:
+     *   HEADS_I8  : out[(b*H+h)][hd_Tpad][hd_dpad]               (transpose=0 layout)
+     *   HEADS_T_I8: out[(b*H+h)][hd_dpad][hd_Tpad], key-permuted (transpose=1 layout); hd_sum[(b*H+h)][hd_dpad]
+     *               += column sums (caller zeroes hd_sum first).
+     * Pad bytes are not written: out must be zero-initialised once (it can then be reused).
+     * hd_T must be a multiple of 128 (a tile of rows never straddles two samples).                         */
+    int32_t        hd_H, hd_d, hd_T, hd_Tpad, hd_dpad;
+    float          oq_prescale;
+    int32_t*       hd_sum;
 } qd_conv_desc;
 
 int qd_conv2d_i8(const qd_conv_desc* d, void* stream);

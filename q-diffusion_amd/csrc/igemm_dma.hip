@@ -52,12 +52,19 @@ struct ConvD {
     float oqmin, oqmax;
     int   oqoff;
     int   it_per;             // O_PART: K-steps per split (blockIdx.y = split index)
+    int   hdH, hdd, hdT, hdTpad, hddpad;   // O_HROWS / O_HTR: heads, head dim, tokens per sample, padded dims
+    float oqpre;              // O_HROWS / O_HTR: multiplier applied before the output quantiser
+    int32_t* hdsum;           // O_HTR: [(b*H+h)][dpad] column sums of the stored bytes (atomically accumulated)
 };
 
 // O_PART: split-K partial.  The block contracts K-steps [y*it_per, (y+1)*it_per) only and stores
 // acc - zw[n]*Asum_part[m] (int32, exact) into slice y of the workspace; splitk_finalize_kernel sums
 // the slices, restores the K-independent constants and applies the float epilogue.
-enum { O_F32 = 0, O_F16 = 1, O_I32 = 2, O_GEGLU = 3, O_PART = 4 };
+// O_HROWS / O_HTR: the output feeds the attention kernel: it is quantised with the attention block's
+// q/k/v activation quantiser and written as int8 straight into the head-major operand layout of
+// attn_i8.hip (rows [(b,h)][t][dpad] for q and k; transposed + key-permuted [(b,h)][dd][t] plus column
+// sums for v) — the fp32 projection output and the separate qd_quantize_heads pass disappear.
+enum { O_F32 = 0, O_F16 = 1, O_I32 = 2, O_GEGLU = 3, O_PART = 4, O_HROWS = 5, O_HTR = 6 };
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -398,6 +405,79 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
         }
         return;
     }
+    if constexpr (OUT == O_HROWS || OUT == O_HTR) {
+        // rows m = b*T + t, columns n = h*d + dd.  The host guarantees T % BM == 0 and M % T == 0: a block
+        // lies inside one sample and has no ragged rows.  Pad bytes (dd >= d) are never written: the operand
+        // buffers are zero-initialised once and reused.
+        const float od = p.oq[0], oz = p.oq[1];
+        int8_t* o8 = reinterpret_cast<int8_t*>(p.out);
+        const int bidx = m0 / p.hdT, t0 = m0 - bidx * p.hdT;
+        int* sPart = reinterpret_cast<int*>(smem);            // [4][BN] column-sum partials (the ring is dead by now)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int cl = j * 32 + frow;
+            const bool nok = n0 + cl < p.Cout;
+            const int nn = nok ? n0 + cl : 0;
+            const int h = nn / p.hdd, dd = nn - h * p.hdd;
+            const float sc = sScale[cl];
+            const int zc_n = sZc[cl];
+            const int zw_n = sZw[cl];
+            const float bias_n = sBias[cl];
+            if constexpr (OUT == O_HROWS) {
+                int8_t* ob = o8 + (((long)bidx * p.hdH + h) * p.hdTpad + t0) * p.hddpad + dd;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int rbase = wave * (32 * MT) + i * 32 + 4 * fhalf;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rowl = rbase + (r & 3) + 8 * (r >> 2);
+                        const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rowl] - kz);
+                        const float v = (float)I * sc + bias_n;
+                        const int8_t code = (int8_t)(qd_code(v * p.oqpre, od, oz, p.oqmin, p.oqmax) - p.oqoff);
+                        if (nok) ob[(unsigned)rowl * (unsigned)p.hddpad] = code;
+                    }
+                }
+            } else {
+                int8_t* ob = o8 + (((long)bidx * p.hdH + h) * p.hddpad + dd) * p.hdTpad + t0 + fhalf * 16;
+                int csum = 0;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int tile0 = wave * (32 * MT) + i * 32;   // first row of this 32-key tile inside the block
+                    v4i pk;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        unsigned w = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * g + e;
+                            const int rowl = tile0 + 4 * fhalf + (r & 3) + 8 * (r >> 2);
+                            const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rowl] - kz);
+                            const float v = (float)I * sc + bias_n;
+                            const int code = qd_code(v * p.oqpre, od, oz, p.oqmin, p.oqmax) - p.oqoff;
+                            csum += code;
+                            w |= (unsigned)(code & 0xff) << (8 * e);
+                        }
+                        pk[g] = (int)w;
+                    }
+                    // key slot p = half*16 + r  <->  key (r&3) + 8*(r>>2) + 4*half of the tile (attn_i8.hip): the
+                    // MFMA C layout IS the permuted order, so a lane's 16 codes are 16 contiguous bytes
+                    if (nok) *reinterpret_cast<v4i*>(ob + tile0) = pk;
+                }
+                csum += __shfl_xor(csum, 32);
+                if (fhalf == 0) sPart[wave * BN + cl] = nok ? csum : 0;
+            }
+        }
+        if constexpr (OUT == O_HTR) {
+            __syncthreads();
+            const int c = threadIdx.x;
+            if (c < BN && n0 + c < p.Cout) {
+                const int tot = sPart[c] + sPart[BN + c] + sPart[2 * BN + c] + sPart[3 * BN + c];
+                const int n = n0 + c, h = n / p.hdd, dd = n - h * p.hdd;
+                atomicAdd(&p.hdsum[((long)bidx * p.hdH + h) * p.hddpad + dd], tot);
+            }
+        }
+        return;
+    }
     // Branch-free per 32x32 tile: out-of-range rows/columns are handled by CLAMPING the offsets of the
     // residual / row-bias loads (and predicating only the stores), so the 16 loads of a tile are issued
     // back to back.  (With a per-element `if (...) continue;` every load sat in its own basic block and the
@@ -558,7 +638,7 @@ int dispatch(ConvD& k, bool split, int out, hipStream_t st, int nsplit = 1) {
         hipLaunchKernelGGL((igemm_dma_kernel<MT, NT, SP, O>), grid, block, 0, st, k);       \
         return 0;                                                                           \
     }
-    QD_CASE(false, O_F32) QD_CASE(false, O_F16) QD_CASE(false, O_I32)
+    QD_CASE(false, O_F32) QD_CASE(false, O_F16) QD_CASE(false, O_I32) QD_CASE(false, O_HROWS) QD_CASE(false, O_HTR)
     if constexpr (MT == 1) { QD_CASE(true, O_F32) QD_CASE(true, O_F16) QD_CASE(false, O_PART) }
     if constexpr (NT == 4) { QD_CASE(false, O_GEGLU) }
 #undef QD_CASE
@@ -621,7 +701,22 @@ int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
     QD_REQUIRE(d->ldo < (1 << 22) && d->ldr < (1 << 22) && d->Cout < (1 << 22), "qd_conv2d_i8 (tiled): row strides must be < 2^22 elements");
     const bool split = d->nseg == 2;
     const bool geglu = d->epilogue == QD_EPI_GEGLU_I8;
-    const int out = geglu ? O_GEGLU : (iout ? O_I32 : (d->out_dtype == QD_F16 ? O_F16 : O_F32));
+    const bool heads = d->epilogue == QD_EPI_HEADS_I8 || d->epilogue == QD_EPI_HEADS_T_I8;
+    const int out = geglu ? O_GEGLU : heads ? (d->epilogue == QD_EPI_HEADS_I8 ? O_HROWS : O_HTR)
+                                            : (iout ? O_I32 : (d->out_dtype == QD_F16 ? O_F16 : O_F32));
+    if (heads) {
+        QD_REQUIRE(!iout && d->nseg == 1 && d->oq_params && d->out, "qd_conv2d_i8 (tiled): heads epilogue needs one segment, oq_params and out");
+        QD_REQUIRE(d->oq_max - d->oq_off <= 127 && d->oq_min - d->oq_off >= -128, "qd_conv2d_i8 (tiled): heads output grid does not fit int8");
+        QD_REQUIRE(d->hd_H > 0 && d->hd_d > 0 && d->hd_H * d->hd_d == d->Cout, "qd_conv2d_i8 (tiled): heads epilogue: H*d must equal Cout");
+        QD_REQUIRE(d->hd_T > 0 && d->hd_T % 128 == 0 && k.M % d->hd_T == 0, "qd_conv2d_i8 (tiled): heads epilogue: tokens per sample (%d) must be a multiple of 128 dividing M", d->hd_T);
+        QD_REQUIRE(d->hd_Tpad % 32 == 0 && d->hd_Tpad >= d->hd_T && d->hd_dpad % 32 == 0 && d->hd_dpad >= d->hd_d, "qd_conv2d_i8 (tiled): heads epilogue: bad padded dims");
+        QD_REQUIRE(qd_aligned(d->out, 16) && (d->epilogue != QD_EPI_HEADS_T_I8 || d->hd_sum), "qd_conv2d_i8 (tiled): heads epilogue: out unaligned or hd_sum missing");
+        QD_REQUIRE(!d->rowbias && !d->residual, "qd_conv2d_i8 (tiled): heads epilogue takes no rowbias / residual");
+        k.oq = d->oq_params; k.oqmin = (float)d->oq_min; k.oqmax = (float)d->oq_max; k.oqoff = d->oq_off;
+        k.hdH = d->hd_H; k.hdd = d->hd_d; k.hdT = d->hd_T; k.hdTpad = d->hd_Tpad; k.hddpad = d->hd_dpad;
+        k.oqpre = d->oq_prescale; k.hdsum = d->hd_sum;
+    }
+    const bool mt2_ok = !heads || d->hd_T % 256 == 0;            // a block must stay inside one sample
     if (geglu) {
         QD_REQUIRE(!iout && d->nseg == 1 && d->oq_params && d->Cout % 64 == 0, "qd_conv2d_i8 (tiled): GEGLU epilogue needs one segment, oq_params and Cout %% 64 == 0");
         QD_REQUIRE(d->oq_max - d->oq_off <= 127 && d->oq_min - d->oq_off >= -128, "qd_conv2d_i8 (tiled): GEGLU output grid does not fit int8");
@@ -666,12 +761,12 @@ int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
         if (force_gmt == 2) rc = dispatch<2, 4>(k, split, out, st);
         else rc = dispatch<1, 4>(k, split, out, st);
     } else if (N % 160 == 0) {
-        if (!split && (force_mt ? force_mt == 2 : blocks(256, 160) >= 512)) rc = dispatch<2, 5>(k, split, out, st);      // >= 2 blocks per CU
+        if (!split && mt2_ok && (force_mt ? force_mt == 2 : blocks(256, 160) >= 512)) rc = dispatch<2, 5>(k, split, out, st);      // >= 2 blocks per CU
         else rc = dispatch<1, 5>(k, split, out, st);
     } else if (N % 224 == 0) {
         rc = dispatch<1, 7>(k, split, out, st);
     } else if (N > 64) {
-        if (!split && blocks(256, 128) >= 512) rc = dispatch<2, 4>(k, split, out, st);
+        if (!split && mt2_ok && blocks(256, 128) >= 512) rc = dispatch<2, 4>(k, split, out, st);
         else rc = dispatch<1, 4>(k, split, out, st);
     } else {
         rc = dispatch<1, 2>(k, split, out, st);

@@ -356,6 +356,62 @@ def attention(ap, q, k, v, B, T, S, H, d, q_strides, k_strides, v_strides, out=N
     return out
 
 
+_HEAD_BUFS = {}
+
+
+def head_buffers(device, BH, Tpad, Spad, dpad):
+    """(q8 [BH][Tpad][dpad], k8 [BH][Spad][dpad], v8^T [BH][dpad][Spad], vsum [BH][dpad]): the int8 operands of
+    qd_attn_i8, zero-initialised ONCE and shared by every attention block of that shape on the device
+    (stream-ordered reuse; the projection epilogues never write pad bytes, so the pads stay zero, and a
+    captured HIP graph keeps pointing at stable addresses)."""
+    key = (device, BH, Tpad, Spad, dpad)
+    bufs = _HEAD_BUFS.get(key)
+    if bufs is None:
+        bufs = (torch.zeros((BH, Tpad, dpad), dtype=torch.int8, device=device),
+                torch.zeros((BH, Spad, dpad), dtype=torch.int8, device=device),
+                torch.zeros((BH, dpad, Spad), dtype=torch.int8, device=device),
+                torch.zeros((BH, dpad), dtype=torch.int32, device=device))
+        _HEAD_BUFS[key] = bufs
+    return bufs
+
+
+def heads_fusable(plan, T, H):
+    """The projection `plan` can write its output directly as attention operand bytes (QD_EPI_HEADS_*)."""
+    return bool(plan.pack.tiled and len(plan.segs) == 1 and T % 128 == 0 and plan.Cout % H == 0
+                and (plan.Cout // H) % 4 == 0)
+
+
+def project_heads(plan, xq, B, T, H, ap, which, out8, vsum=None):
+    """q (which=0) / k (1) / v (2) projection of B*T token rows `xq`, quantised with the attention block's
+    own act quantiser inside the GEMM epilogue and stored in the operand layout of the attention kernel."""
+    d = plan.Cout // H
+    if which == 2:
+        vsum.zero_()
+    call = hip.ConvCall(x=xq, w=plan.pack.wq, out=out8, bias=plan.bias, ldx=plan.ldx, ldk=plan.pack.ldk, ldo=0,
+                        B=B, H=1, W=T, Ho=1, Wo=T, Cout=plan.Cout, kh=1, kw=1, stride=1, pad_t=0, pad_l=0,
+                        wbits=plan.pack.wbits, w_tiled=True, segs=plan.segs,
+                        epilogue=hip.EPI_HEADS_T_I8 if which == 2 else hip.EPI_HEADS_I8,
+                        oq_params=ap.qparams[which], oq_grid=ap.grids[which],
+                        heads=dict(H=H, d=d, T=T, Tpad=pad32(T), dpad=pad32(d), sum=vsum,
+                                   prescale=ap.prescale if which < 2 else 1.0))
+    hip.conv2d_i8(call)
+
+
+def heads_from_float(ap, which, x, B, T, H, d, strides, out8, vsum=None):
+    """Same operand bytes from an fp32 projection output (the unfused route: ragged token counts, context k/v)."""
+    hip.quantize_heads(x, B, T, H, d, strides, ap.prescale if which < 2 else 1.0, ap.qparams[which], ap.grids[which],
+                       which == 2, out8, vsum if which == 2 else None, pad32(T), pad32(d))
+
+
+def attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d, out=None):
+    """Fused quantised attention on prepared operand bytes; returns merged-head rows out[B*T][H*d] fp32."""
+    if out is None:
+        out = torch.empty((B * T, H * d), dtype=torch.float32, device=q8.device)
+    hip.attn_i8(q8, k8, v8, vsum, B * H, H, T, S, d, pad32(T), pad32(S), pad32(d), ap.prm, ap.wbits, ap.wmin, ap.wmax,
+                ap.asym, out, out.stride(0))
+    return out
+
+
 def sinusoid(timesteps, dim, flavour):
     """Timestep sinusoid table (K6 front half; tiny, kept in torch).  flavour 'ldm': cos|sin with
     /half (ldm util.py:151-171); 'ddim': sin|cos with /(half-1) (ddim diffusion.py:6-24)."""

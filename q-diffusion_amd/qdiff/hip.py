@@ -40,10 +40,12 @@ class ConvDesc(ctypes.Structure):
                 ("seg", ConvSeg * 2),
                 ("oq_params", ctypes.c_void_p), ("oq_min", ctypes.c_int32), ("oq_max", ctypes.c_int32),
                 ("oq_off", ctypes.c_int32), ("_pad2", ctypes.c_int32),
-                ("splitk_ws", ctypes.c_void_p), ("splitk_ws_bytes", ctypes.c_int64)]
+                ("splitk_ws", ctypes.c_void_p), ("splitk_ws_bytes", ctypes.c_int64),
+                ("hd_H", ctypes.c_int32), ("hd_d", ctypes.c_int32), ("hd_T", ctypes.c_int32), ("hd_Tpad", ctypes.c_int32),
+                ("hd_dpad", ctypes.c_int32), ("oq_prescale", ctypes.c_float), ("hd_sum", ctypes.c_void_p)]
 
 
-EPI_LINEAR, EPI_GEGLU_I8 = 0, 1
+EPI_LINEAR, EPI_GEGLU_I8, EPI_HEADS_I8, EPI_HEADS_T_I8 = 0, 1, 2, 3
 
 
 EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_quantize_act", "qd_pack_weights", "qd_pack_weights_t4",
@@ -84,7 +86,7 @@ def load():
                                       vp, vp, i32, i32, vp]
     lib.qd_attn_i8.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp,
                                i64, vp]
-    if lib.qd_abi_version() != 4:
+    if lib.qd_abi_version() != 5:
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -162,7 +164,7 @@ class ConvCall:
     """Python-side description of one qd_conv2d_i8 launch (tensors, not pointers)."""
     __slots__ = ("x", "w", "out", "bias", "rowbias", "residual", "ldx", "ldk", "ldo", "ldr", "ld_rowbias",
                  "B", "H", "W", "Ho", "Wo", "Cout", "kh", "kw", "stride", "pad_t", "pad_l", "wbits", "w_tiled", "segs",
-                 "epilogue", "oq_params", "oq_grid", "splitk")
+                 "epilogue", "oq_params", "oq_grid", "splitk", "heads")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -212,10 +214,15 @@ def _conv_desc(c):
     d.wbits = c.wbits
     d.w_tiled = 1 if c.w_tiled else 0
     d.epilogue = c.epilogue or EPI_LINEAR
-    if d.epilogue == EPI_GEGLU_I8:
+    if d.epilogue != EPI_LINEAR:
         d.oq_params = _ptr(c.oq_params, "oq_params")
         d.oq_min, d.oq_max, d.oq_off = c.oq_grid.qmin, c.oq_grid.qmax, c.oq_grid.off
-        d.out_dtype = F32                           # unused: the output is int8 rows
+        d.out_dtype = F32                           # unused: the output is int8
+        if d.epilogue in (EPI_HEADS_I8, EPI_HEADS_T_I8):
+            hd = c.heads                            # dict(H, d, T, Tpad, dpad, prescale, sum)
+            d.hd_H, d.hd_d, d.hd_T, d.hd_Tpad, d.hd_dpad = hd["H"], hd["d"], hd["T"], hd["Tpad"], hd["dpad"]
+            d.oq_prescale = float(hd["prescale"])
+            d.hd_sum = _ptr(hd.get("sum"), "hd_sum")
     else:
         d.out_dtype = _dtype(c.out) if c.out is not None else F32
     d.nseg = len(c.segs)

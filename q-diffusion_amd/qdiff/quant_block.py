@@ -384,22 +384,30 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
     def _attn_int(self, att, rows, B, T, C, ln, ctx_rows, S):
         """norm -> q/k/v projections -> fused quantised attention -> to_out (+ residual rows)."""
         h = att.heads
+        ap = self._attn_plan(att, float(att.scale), 1.0, rows.device)
         if ctx_rows is None:
-            q8, k8, v8 = _ln_to([att.to_q, att.to_k, att.to_v], rows, B * T, C, ln)
-            q = att.to_q.forward_codes(q8, 1, 1, B * T)
-            k = att.to_k.forward_codes(k8, 1, 1, B * T)
-            v = att.to_v.forward_codes(v8, 1, 1, B * T)
+            xq, xk, xv = _ln_to([att.to_q, att.to_k, att.to_v], rows, B * T, C, ln)
             S = T
         else:
-            (q8,) = _ln_to([att.to_q], rows, B * T, C, ln)
-            q = att.to_q.forward_codes(q8, 1, 1, B * T)
-            k = _linear_rows(att.to_k, ctx_rows)
-            v = _linear_rows(att.to_v, ctx_rows)
-        inner = q.shape[1]
+            (xq,) = _ln_to([att.to_q], rows, B * T, C, ln)
+            xk = xv = None
+        inner = att.to_q.conv_plan().Cout
         d = inner // h
-        ap = self._attn_plan(att, float(att.scale), 1.0, rows.device)
-        o = engine.attention(ap, q, k, v, B, T, S, h, d, (T * inner, inner, d, 1), (S * inner, inner, d, 1),
-                             (S * inner, inner, d, 1))
+        q8, k8, v8, vsum = engine.head_buffers(rows.device, B * h, engine.pad32(T), engine.pad32(S), engine.pad32(d))
+
+        def operand(mod, codes, which, n_tok, buf):
+            # projection -> attention operand bytes: inside the GEMM epilogue when the shape allows it, else
+            # fp32 projection + qd_quantize_heads (ragged token counts; the 77 context tokens of cross-attention)
+            if codes is not None and engine.heads_fusable(mod.conv_plan(), n_tok, h):
+                engine.project_heads(mod.conv_plan(), codes, B, n_tok, h, ap, which, buf, vsum)
+                return
+            y = mod.forward_codes(codes, 1, 1, B * n_tok) if codes is not None else _linear_rows(mod, ctx_rows)
+            engine.heads_from_float(ap, which, y, B, n_tok, h, d, (n_tok * inner, inner, d, 1), buf, vsum)
+
+        operand(att.to_q, xq, 0, T, q8)
+        operand(att.to_k, xk, 1, S, k8)
+        operand(att.to_v, xv, 2, S, v8)
+        o = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, h, d)
         return _linear_rows(att.to_out[0], o, residual=rows)
 
     def _forward_int(self, x, context):

@@ -158,6 +158,16 @@ def conv2d_i8(c, acc_out=None):
         y = (t[:, :, 0] * F.gelu(t[:, :, 1])).reshape(rows.shape[0], c.Cout // 2)
         c.out[:, :c.Cout // 2] = (_codes(y, c.oq_params, c.oq_grid) - c.oq_grid.off).to(torch.int8)
         return
+    if getattr(c, "epilogue", 0) in (2, 3):
+        # QD_EPI_HEADS_I8 / QD_EPI_HEADS_T_I8: the projection output as attention operand bytes
+        hd = c.heads
+        Bn, inner = rows.shape[0] // hd["T"], hd["H"] * hd["d"]
+        rsum = torch.zeros_like(hd["sum"]) if (c.epilogue == 3 and hd.get("sum") is not None) else None
+        quantize_heads(rows.contiguous(), Bn, hd["T"], hd["H"], hd["d"], (hd["T"] * inner, inner, hd["d"], 1), hd["prescale"],
+                       c.oq_params, c.oq_grid, c.epilogue == 3, c.out, rsum, hd["Tpad"], hd["dpad"])
+        if rsum is not None:
+            hd["sum"] += rsum                                    # the kernel accumulates atomically into a zeroed buffer
+        return
     c.out[:, :c.Cout] = rows.to(c.out.dtype)
 
 

@@ -439,3 +439,45 @@ def test_attention_fused(cuda, case):
     assert (diff > 2e-4 * rng).float().mean().item() <= 1e-2
     assert diff.max().item() <= 2e-2 * rng
     assert ((got - want_fq).abs() > 1e-3 * rng).float().mean().item() <= 1e-2
+
+
+@pytest.mark.parametrize("T,N,K", [(128, 320, 320), (256, 640, 640), (512, 320, 1280)])
+def test_projection_heads_epilogue_matches_quantize_heads(cuda, T, N, K):
+    """q/k/v projections that write attention operand bytes from the GEMM epilogue (QD_EPI_HEADS_*) produce
+    exactly the bytes (and V column sums) of the fp32 projection followed by qd_quantize_heads."""
+    from qdiff import engine
+    B, H = 2, 8
+    d = N // H
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B * T, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.05
+    bias = torch.randn(N, generator=g) * 0.1
+    q = _weight_quantizer(w, 4, True, g)
+    dx, zx = R.uaq_init_scale(x, 8, False, False, "max")
+    aq = _aq(dx, zx)
+    pack = engine.pack_module_weights(w.to(cuda), [q], 0)
+    plan = engine.build_conv_plan(pack, [aq], 1, 1, 1, 0, bias.to(cuda))
+    assert pack.tiled and engine.heads_fusable(plan, T, H)
+    xq = engine.quantize_rows(x.to(cuda), plan, 1, K, B * T, (0, 1, K))
+    y = engine.conv_forward(plan, xq, 1, 1, B * T)                       # fp32 projection [B*T][N]
+
+    def mk(t, always_zero=False):
+        dd, zz = R.uaq_init_scale(t, 8, False, False, "max", always_zero)
+        return NS(delta=dd, zero_point=zz, n_bits=8, sym=False)
+    yc = y.cpu()
+    pre = 0.7
+    aw = NS(delta=torch.tensor(1.0 / 65535), zero_point=torch.tensor(0.0), n_bits=16, sym=False)
+    ap = engine.build_attn_plan(mk(yc * pre), mk(yc * pre), mk(yc), aw, 1.0, pre, cuda)
+    Tpad, dpad = engine.pad32(T), engine.pad32(d)
+    for which in (0, 1, 2):
+        shape = (B * H, dpad, Tpad) if which == 2 else (B * H, Tpad, dpad)
+        want = torch.zeros(shape, dtype=torch.int8, device=cuda)
+        got = torch.zeros(shape, dtype=torch.int8, device=cuda)
+        ws = torch.zeros((B * H, dpad), dtype=torch.int32, device=cuda)
+        gs = torch.full((B * H, dpad), 7, dtype=torch.int32, device=cuda)   # project_heads must zero it itself
+        engine.heads_from_float(ap, which, y, B, T, H, d, (T * N, N, d, 1), want, ws)
+        engine.project_heads(plan, xq, B, T, H, ap, which, got, gs)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), (which, (got != want).float().mean().item())
+        if which == 2:
+            assert torch.equal(gs, ws)
