@@ -18,6 +18,8 @@
 
 namespace {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 struct AttnK {
     const int8_t* q;
     const int8_t* k;
@@ -51,7 +53,7 @@ struct AttnK {
 // the L2 latency of the (tiny, shared) K/V stream hides behind ~1k VALU cycles.
 template <int DT, bool P16, bool ASYM>
 // (3 blocks per CU was tried for DT=2/P16: 168 VGPRs + 100 B of scratch, 16% slower end to end.)
-__global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 4) ? 2 : 1) void attn_kernel(const AttnK p) {
+__global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_kernel(const AttnK p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frow = lane & 31, half = lane >> 5;
     const int bh = blockIdx.y;
@@ -137,13 +139,21 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 4) ? 2 : 1) void attn_k
             for (int r = 1; r < 16; ++r) tmax = max(tmax, d[r]);
             const int up = max(tmax, 0);                          // the row max moves up by `up`
             const float shift = (float)up * cs2;
-            float a = 0.f;
+            // packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two scores per instruction) around the scalar cvt / exp2
+            v2f a2 = {0.f, 0.f};
+            const v2f cs2v = {cs2, cs2}, nshift = {-shift, -shift};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf((float)d[r], cs2, -shift));
-                a += (tail && d[r] == MASKED) ? 0.f : e;
+            for (int r = 0; r < 16; r += 2) {
+                const v2f df = {(float)d[r], (float)d[r + 1]};
+                const v2f x = __builtin_elementwise_fma(df, cs2v, nshift);
+                v2f e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                if (tail) {
+                    if (d[r] == MASKED) e.x = 0.f;
+                    if (d[r + 1] == MASKED) e.y = 0.f;
+                }
+                a2 += e;
             }
-            l = l * __builtin_amdgcn_exp2f(-shift) + a;           // first tile: l == 0, the factor is irrelevant
+            l = l * __builtin_amdgcn_exp2f(-shift) + (a2.x + a2.y);   // first tile: l == 0, the factor is irrelevant
             mi += up;
             if (jt + 1 < ntile) {
 #pragma unroll
@@ -183,11 +193,18 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 4) ? 2 : 1) void attn_k
             scores(kf, mi, d);                                // d = s - rowmax <= 0
             const bool tail = jt == tail_tile;
             unsigned ub[16];                                      // float bits of uu + MAGIC: low 16 bits == uu
+            const v2f cs2v = {cs2, cs2}, invv = {inv, inv}, ubv = {ubias, ubias}, magic = {MAGIC, MAGIC};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f((float)d[r] * cs2);
-                const float t = fminf(__builtin_fmaf(e, inv, ubias), urange) + MAGIC;   // e*inv + ubias >= 0 always
-                ub[r] = __float_as_uint(t);
+            for (int r = 0; r < 16; r += 2) {
+                const v2f df = {(float)d[r], (float)d[r + 1]};
+                const v2f x = df * cs2v;
+                const v2f e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                v2f t = __builtin_elementwise_fma(e, invv, ubv);                        // e*inv + ubias >= 0 always
+                t.x = fminf(t.x, urange);
+                t.y = fminf(t.y, urange);
+                t += magic;
+                ub[r] = __float_as_uint(t.x);
+                ub[r + 1] = __float_as_uint(t.y);
             }
             if (tail) {
 #pragma unroll
