@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 5
+#define QD_ABI_VERSION 6
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -221,6 +221,9 @@ int qd_geglu_quant(const void* h, int h_dtype, int64_t M, int F, int64_t ldh,
  *             O is written as out[b][t][h*d + c] (merged heads, ldo = row stride, fp32).
  *     prm: device float[16] = {cs (=dq*dk*scale), zq', zk', dw, zpw, dv_dw (=dw*dv), zv', ...}
  *          (layout in DESIGN.md §4.4); built once on device by the host, never read back.
+ *     out8 != NULL: O is not written as fp32 but quantised with oq_* = the act quantiser of the Linear that
+ *           consumes it (to_out[0], quant_block.py:221 -> quant_layer.py:256) and stored as its int8 input rows
+ *           out8[b*T+t][ldo8] (K1 semantics; H*d must already be that Linear's padded input width).
  *     q_asym: 0 when zq' == 0 (symmetric q quantiser), else 1: the kernel then restores the per-key term
  *           -zq' * sum_d k'[j][d] with a constant-operand MFMA.  qsum / ksum are ignored (may be NULL; kept
  *           for source compatibility): the per-query terms -zk'*qsum_i + d*zq'*zk' are constant along a
@@ -235,7 +238,9 @@ int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt,
                const int32_t* qsum, const int32_t* ksum, const int32_t* vsum,
                int BH, int H, int T, int S, int d, int Tpad, int Spad, int dpad,
                const float* prm, int wbits, int wmin, int wmax, int q_asym,
-               float* out, int64_t ldo, void* stream);
+               float* out, int64_t ldo,
+               int8_t* out8, int64_t ldo8, const float* oq_params, int oq_min, int oq_max, int oq_off,
+               void* stream);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,12 @@ struct AttnK {
     int BH, H, T, S, d, Tpad, Spad, dpad;
     float wmin, wmax;
     int iwmin;
+    // optional quantised output (the act quantiser of the Linear that consumes the attention output)
+    int8_t* out8;
+    long ldo8;
+    const float* oq;
+    float oqmin, oqmax;
+    int oqoff;
 };
 
 // prm layout (device floats): 0 cs = dq*dk*scale | 1 zq' | 2 zk' | 3 dw | 4 zpw | 5 dw*dv | 6 zv'
@@ -250,6 +256,7 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_k
 
     // ---- epilogue: restore zero points (exact, int64), scale, store merged-head rows ------------
     const int b = bh / p.H, hh = bh % p.H;
+    const float od = p.out8 ? p.oq[0] : 1.f, oz = p.out8 ? p.oq[1] : 0.f;
     const long kconst = (P16 ? 256L * 128L : 0L) + 128L + (long)p.iwmin - (long)izpw;  // multiplies vsum
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
@@ -263,7 +270,9 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_k
             if (dd >= p.d || i >= p.T) continue;
             long I = (long)ol[t][r] + kconst * vs - (long)zv * us + (long)p.S * izpw * zv;
             if (P16) I += 256L * (long)oh[P16 ? t : 0][r];
-            p.out[((long)b * p.T + i) * p.ldo + hh * p.d + dd] = (float)I * oscale;
+            const float o = (float)I * oscale;
+            if (p.out8) p.out8[((long)b * p.T + i) * p.ldo8 + hh * p.d + dd] = (int8_t)(qd_code(o, od, oz, p.oqmin, p.oqmax) - p.oqoff);
+            else p.out[((long)b * p.T + i) * p.ldo + hh * p.d + dd] = o;
         }
     }
 }
@@ -282,8 +291,11 @@ int launch_dt(const AttnK& k, bool p16, bool asym, hipStream_t st) {
 
 extern "C" int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt, const int32_t* qsum, const int32_t* ksum,
                           const int32_t* vsum, int BH, int H, int T, int S, int d, int Tpad, int Spad, int dpad,
-                          const float* prm, int wbits, int wmin, int wmax, int q_asym, float* out, int64_t ldo, void* stream) {
-    QD_REQUIRE(q && k && vt && vsum && prm && out, "qd_attn_i8: null pointer");
+                          const float* prm, int wbits, int wmin, int wmax, int q_asym, float* out, int64_t ldo,
+                          int8_t* out8, int64_t ldo8, const float* oq_params, int oq_min, int oq_max, int oq_off, void* stream) {
+    QD_REQUIRE(q && k && vt && vsum && prm && (out || out8), "qd_attn_i8: null pointer");
+    QD_REQUIRE(!out8 || (oq_params && ldo8 >= (int64_t)H * d && oq_max - oq_off <= 127 && oq_min - oq_off >= -128),
+               "qd_attn_i8: quantised output needs oq_params, ldo8 >= H*d and a grid that fits int8");
     QD_REQUIRE(BH > 0 && H > 0 && BH % H == 0 && T > 0 && S > 0 && d > 0, "qd_attn_i8: bad shape");
     QD_REQUIRE(Tpad % 32 == 0 && Spad % 32 == 0 && dpad % 32 == 0 && Tpad >= T && Spad >= S && dpad >= d, "qd_attn_i8: padded dims must be multiples of 32");
     QD_REQUIRE(BH < 65536, "qd_attn_i8: too many heads for grid.y");
@@ -293,7 +305,8 @@ extern "C" int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt, co
     (void)qsum;                                  // per-query constants cancel in the softmax: never needed
     (void)ksum;                                  // per-key term: constant-operand MFMA inside the kernel
     const bool asym = q_asym != 0;
-    AttnK a{q, k, vt, qsum, ksum, vsum, prm, out, (long)ldo, BH, H, T, S, d, Tpad, Spad, dpad, (float)wmin, (float)wmax, wmin};
+    AttnK a{q, k, vt, qsum, ksum, vsum, prm, out, (long)ldo, BH, H, T, S, d, Tpad, Spad, dpad, (float)wmin, (float)wmax, wmin,
+            out8, (long)ldo8, oq_params, (float)oq_min, (float)oq_max, oq_off};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool p16 = wbits == 16;
     switch (dpad / 32) {

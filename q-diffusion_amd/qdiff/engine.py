@@ -403,8 +403,17 @@ def heads_from_float(ap, which, x, B, T, H, d, strides, out8, vsum=None):
                        which == 2, out8, vsum if which == 2 else None, pad32(T), pad32(d))
 
 
-def attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d, out=None):
-    """Fused quantised attention on prepared operand bytes; returns merged-head rows out[B*T][H*d] fp32."""
+def attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d, out=None, out_plan=None):
+    """Fused quantised attention on prepared operand bytes; returns merged-head rows out[B*T][H*d] fp32 —
+    or, with out_plan (the ConvPlan of the Linear that consumes the output, one segment, input width H*d), that
+    Linear's int8 input rows [B*T][out_plan.ldx], quantised in the attention epilogue."""
+    if out_plan is not None:
+        if len(out_plan.segs) != 1 or out_plan.ldx != H * d:
+            raise hip.HipEngineError("attention_codes: out_plan must take exactly the H*d merged-head features")
+        out8 = torch.empty((B * T, out_plan.ldx), dtype=torch.int8, device=q8.device)
+        hip.attn_i8(q8, k8, v8, vsum, B * H, H, T, S, d, pad32(T), pad32(S), pad32(d), ap.prm, ap.wbits, ap.wmin, ap.wmax,
+                    ap.asym, None, 0, out8=out8, oq_params=out_plan.qparams[0], oq_grid=out_plan.grids[0])
+        return out8
     if out is None:
         out = torch.empty((B * T, H * d), dtype=torch.float32, device=q8.device)
     hip.attn_i8(q8, k8, v8, vsum, B * H, H, T, S, d, pad32(T), pad32(S), pad32(d), ap.prm, ap.wbits, ap.wmin, ap.wmax,

@@ -85,8 +85,8 @@ def load():
     lib.qd_quantize_heads.argtypes = [vp, i32, i32, i32, i32, i32, i64, i64, i64, i64, f32, vp, i32, i32, i32, i32,
                                       vp, vp, i32, i32, vp]
     lib.qd_attn_i8.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp,
-                               i64, vp]
-    if lib.qd_abi_version() != 5:
+                               i64, vp, i64, vp, i32, i32, i32, vp]
+    if lib.qd_abi_version() != 6:
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -271,7 +271,12 @@ def quantize_heads(x, B, T, H, d, strides, prescale, qparams, grid, transpose, o
                                     dpad, _stream()), "qd_quantize_heads")
 
 
-def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, wmax, q_asym, out, ldo):
-    """q_asym: the q quantiser has a non-zero stored zero point (the kernel restores -zq'*sum_d k' itself)."""
+def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, wmax, q_asym, out, ldo,
+            out8=None, oq_params=None, oq_grid=None):
+    """q_asym: the q quantiser has a non-zero stored zero point (the kernel restores -zq'*sum_d k' itself).
+    out8 (+ oq_params, oq_grid): write the output as the int8 input rows of the consuming Linear instead of fp32."""
+    g = oq_grid
     _check(load().qd_attn_i8(_ptr(q), _ptr(k), _ptr(vt), None, None, _ptr(vsum), BH, H, T, S, d, Tpad, Spad,
-                             dpad, _ptr(prm), wbits, wmin, wmax, 1 if q_asym else 0, _ptr(out), ldo, _stream()), "qd_attn_i8")
+                             dpad, _ptr(prm), wbits, wmin, wmax, 1 if q_asym else 0, _ptr(out), ldo,
+                             _ptr(out8), out8.stride(0) if out8 is not None else 0, _ptr(oq_params),
+                             g.qmin if g else 0, g.qmax if g else 0, g.off if g else 0, _stream()), "qd_attn_i8")

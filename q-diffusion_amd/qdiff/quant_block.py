@@ -407,8 +407,13 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
         operand(att.to_q, xq, 0, T, q8)
         operand(att.to_k, xk, 1, S, k8)
         operand(att.to_v, xv, 2, S, v8)
+        out_lin = att.to_out[0]
+        if out_lin.act_quantizer.inited and out_lin.conv_plan().ldx == inner and len(out_lin.conv_plan().segs) == 1:
+            # the attention epilogue quantises its output for to_out[0]: no fp32 round trip
+            o8 = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, h, d, out_plan=out_lin.conv_plan())
+            return out_lin.forward_codes(o8, 1, 1, B * T, residual=rows)
         o = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, h, d)
-        return _linear_rows(att.to_out[0], o, residual=rows)
+        return _linear_rows(out_lin, o, residual=rows)
 
     def _forward_int(self, x, context):
         B, T, C = x.shape

@@ -222,7 +222,8 @@ def quantize_heads(x, B, T, H, d, strides, prescale, qparams, grid, transpose, o
             rsum.copy_(buf.sum(1).to(torch.int32))
 
 
-def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, wmax, q_asym, out, ldo):
+def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, wmax, q_asym, out, ldo,
+            out8=None, oq_params=None, oq_grid=None):
     cs, zq, zk, dw, zpw, osc, zv = (float(prm[i]) for i in range(7))
     inv = torch.empty(Spad, dtype=torch.long)
     inv[_perm_index(Spad)] = torch.arange(Spad)
@@ -234,7 +235,11 @@ def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, 
     u = torch.clamp(torch.round(p / dw) + zpw, wmin, wmax) - zpw
     o = torch.einsum("bij,bjd->bid", u.double(), vi.double()).float() * osc
     B = BH // H
-    out[:, :H * d] = o.view(B, H, T, d).permute(0, 2, 1, 3).reshape(B * T, H * d)
+    rows = o.view(B, H, T, d).permute(0, 2, 1, 3).reshape(B * T, H * d)
+    if out8 is not None:
+        out8[:, :H * d] = (_codes(rows, oq_params, oq_grid) - oq_grid.off).to(torch.int8)
+    else:
+        out[:, :H * d] = rows
 
 
 def install(monkeypatch):

@@ -481,3 +481,36 @@ def test_projection_heads_epilogue_matches_quantize_heads(cuda, T, N, K):
         assert torch.equal(got, want), (which, (got != want).float().mean().item())
         if which == 2:
             assert torch.equal(gs, ws)
+
+
+def test_attention_quantised_output_matches_quantise_rows(cuda):
+    """qd_attn_i8 with out8: the bytes equal K1 applied to its own fp32 output (same float, same rounding)."""
+    from qdiff import engine
+    B, H, T, S, d = 2, 8, 160, 77, 40
+    g = torch.Generator().manual_seed(41)
+    C = H * d
+    q, k, v = (torch.randn(B, L, C, generator=g) for L in (T, S, S))
+
+    def mk(t, n_bits=8, always_zero=False):
+        dd, zz = R.uaq_init_scale(t, n_bits, False, False, "max", always_zero)
+        return NS(delta=dd, zero_point=zz, n_bits=n_bits, sym=False)
+    heads = lambda t, L: t.view(B, L, H, d).permute(0, 2, 1, 3).reshape(B * H, L, d)
+    p = (torch.einsum("bid,bjd->bij", heads(q, T), heads(k, S)) * d ** -0.5).softmax(-1)
+    ap = engine.build_attn_plan(mk(q), mk(k), mk(v), mk(p, 16, True), d ** -0.5, 1.0, cuda)
+    Tp, Sp, dp = engine.pad32(T), engine.pad32(S), engine.pad32(d)
+    q8 = torch.zeros((B * H, Tp, dp), dtype=torch.int8, device=cuda)
+    k8 = torch.zeros((B * H, Sp, dp), dtype=torch.int8, device=cuda)
+    v8 = torch.zeros((B * H, dp, Sp), dtype=torch.int8, device=cuda)
+    vsum = torch.zeros((B * H, dp), dtype=torch.int32, device=cuda)
+    for which, (t, L, buf) in enumerate(((q, T, q8), (k, S, k8), (v, S, v8))):
+        engine.heads_from_float(ap, which, t.to(cuda), B, L, H, d, (L * C, C, d, 1), buf, vsum)
+    o = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d)
+    # consumer: a Linear with C inputs whose act quantiser is initialised on the attention output
+    w = torch.randn(C, C, generator=g) * 0.05
+    wq = _weight_quantizer(w, 4, True, g)
+    do, zo = R.uaq_init_scale(o.cpu(), 8, False, False, "max")
+    plan = engine.build_conv_plan(engine.pack_module_weights(w.to(cuda), [wq], 0), [_aq(do, zo)], 1, 1, 1, 0, None)
+    want = engine.quantize_rows(o, plan, 1, C, B * T, (0, 1, C))
+    got = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d, out_plan=plan)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
