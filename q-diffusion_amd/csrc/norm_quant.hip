@@ -8,7 +8,9 @@
 
 namespace {
 
-constexpr int GN_ROWS = 32;  // rows per partial-sum block
+// rows per partial-sum block: 32, or 8 when the map is small (S <= 256) so that the statistics pass still
+// launches >= 2 blocks per CU at batch 16 (measured: 33.9 -> 28.1 us at 16x16x1280; 8 rows at S=1024 was slower)
+static inline __host__ __device__ int gn_rows(long S) { return S > 256 ? 32 : 8; }
 
 // partial sums: grid (nchunk, B); thread owns 4 consecutive channels (one float4 load per row), loops over rows.
 template <typename T>
@@ -16,8 +18,9 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
                                                          float* __restrict__ part, int nchunk, int vec) {
     const int chunk = blockIdx.x;
     const long b = blockIdx.y;
-    const long r0 = (long)chunk * GN_ROWS;
-    const long r1 = (r0 + GN_ROWS < S) ? r0 + GN_ROWS : S;
+    const int rows = gn_rows(S);
+    const long r0 = (long)chunk * rows;
+    const long r1 = (r0 + rows < S) ? r0 + rows : S;
     for (int c4 = threadIdx.x; c4 < C / 4; c4 += 256) {
         float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
         const T* p = x + (b * S + r0) * ldx + c4 * 4;
@@ -105,70 +108,125 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 
 // LayerNorm: one wave per row, row held in registers (C <= 64*4*MAXV).
 constexpr int LN_MAXV = 6;  // up to 1536 channels
-template <typename T>
+// NV = float4 chunks per lane (ceil(C/256)), RPW = rows per wave: the loads of RPW rows are issued back to
+// back and their reduction chains interleave (a one-row-per-wave version ran at 1.8 TB/s, latency-bound on
+// the load -> two dependent butterfly reductions -> store chain); gamma/beta are fetched once per wave.
+template <typename T, int NV, int RPW>
 __global__ __launch_bounds__(256) void ln_quant_kernel(const T* __restrict__ x, long M, int C, long ldx, float eps,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int nout, const float* qp0, const float* qp1, const float* qp2,
                                                        float3 qmin, float3 qmax, int3 off, int8_t* o0, int8_t* o1,
                                                        int8_t* o2, long ldo, int vec) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= M) return;
     const int nv = C >> 2;  // float4 count
-    const T* src = x + row * ldx;
-    float v[LN_MAXV][4];
-    float s = 0.f;
+    float v[RPW][NV][4];
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
-        int idx = lane + 64 * k;
-        if (idx < nv) {
-            qd_ld4(src + idx * 4, vec != 0, v[k]);
+    for (int r = 0; r < RPW; ++r) {
+        const long row = row0 + r < M ? row0 + r : M - 1;          // clamp: loads stay in bounds, stores are predicated
+        const T* src = x + row * ldx;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s += v[k][j];
+        for (int k = 0; k < NV; ++k) {
+            const int idx = lane + 64 * k;
+            if (idx < nv) qd_ld4(src + idx * 4, vec != 0, v[r][k]);
         }
     }
+    float g[NV][4], bt[NV][4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
-        int idx = lane + 64 * k;
+    for (int k = 0; k < NV; ++k) {
+        const int idx = lane + 64 * k;
         if (idx < nv) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { float d = v[k][j] - mean; q += d * d; }
+            const float4 a = *reinterpret_cast<const float4*>(gamma + idx * 4), b = *reinterpret_cast<const float4*>(beta + idx * 4);
+            g[k][0] = a.x; g[k][1] = a.y; g[k][2] = a.z; g[k][3] = a.w;
+            bt[k][0] = b.x; bt[k][1] = b.y; bt[k][2] = b.z; bt[k][3] = b.w;
         }
     }
+    float s[RPW], q[RPW];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    for (int r = 0; r < RPW; ++r) {
+        s[r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            if (lane + 64 * k < nv) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[r] += v[r][k][j];
+            }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) s[r] += __shfl_xor(s[r], o);
+    float mean[RPW], rstd[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        mean[r] = s[r] / (float)C;
+        q[r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            if (lane + 64 * k < nv) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = v[r][k][j] - mean[r]; q[r] += d * d; }
+            }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) q[r] += __shfl_xor(q[r], o);
     const float d0 = qp0[0], z0 = qp0[1];
     const float d1 = nout > 1 ? qp1[0] : 1.f, z1 = nout > 1 ? qp1[1] : 0.f;
     const float d2 = nout > 2 ? qp2[0] : 1.f, z2 = nout > 2 ? qp2[1] : 0.f;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
-        int idx = lane + 64 * k;
-        if (idx < nv) {
-            unsigned u0 = 0, u1 = 0, u2 = 0;
+    for (int r = 0; r < RPW; ++r) {
+        rstd[r] = 1.0f / sqrtf(q[r] / (float)C + eps);
+        const long row = row0 + r;
+        if (row >= M) continue;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int c = idx * 4 + j;
-                float y = (v[k][j] - mean) * rstd * gamma[c] + beta[c];
-                u0 |= (unsigned)((qd_code(y, d0, z0, qmin.x, qmax.x) - off.x) & 0xff) << (8 * j);
-                if (nout > 1) u1 |= (unsigned)((qd_code(y, d1, z1, qmin.y, qmax.y) - off.y) & 0xff) << (8 * j);
-                if (nout > 2) u2 |= (unsigned)((qd_code(y, d2, z2, qmin.z, qmax.z) - off.z) & 0xff) << (8 * j);
+        for (int k = 0; k < NV; ++k) {
+            const int idx = lane + 64 * k;
+            if (idx < nv) {
+                unsigned u0 = 0, u1 = 0, u2 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float y = (v[r][k][j] - mean[r]) * rstd[r] * g[k][j] + bt[k][j];
+                    u0 |= (unsigned)((qd_code(y, d0, z0, qmin.x, qmax.x) - off.x) & 0xff) << (8 * j);
+                    if (nout > 1) u1 |= (unsigned)((qd_code(y, d1, z1, qmin.y, qmax.y) - off.y) & 0xff) << (8 * j);
+                    if (nout > 2) u2 |= (unsigned)((qd_code(y, d2, z2, qmin.z, qmax.z) - off.z) & 0xff) << (8 * j);
+                }
+                *reinterpret_cast<unsigned*>(o0 + row * ldo + idx * 4) = u0;
+                if (nout > 1) *reinterpret_cast<unsigned*>(o1 + row * ldo + idx * 4) = u1;
+                if (nout > 2) *reinterpret_cast<unsigned*>(o2 + row * ldo + idx * 4) = u2;
             }
-            *reinterpret_cast<unsigned*>(o0 + row * ldo + idx * 4) = u0;
-            if (nout > 1) *reinterpret_cast<unsigned*>(o1 + row * ldo + idx * 4) = u1;
-            if (nout > 2) *reinterpret_cast<unsigned*>(o2 + row * ldo + idx * 4) = u2;
         }
+    }
+}
+
+template <typename T, int NV>
+void launch_ln(hipStream_t st, const void* x, long M, int C, long ldx, float eps, const float* gamma, const float* beta, int nout,
+               const float* const* qp, float3 mn, float3 mx, int3 of, int8_t* const* o, long ldo, int vec) {
+    constexpr int RPW = NV <= 3 ? 2 : 1;
+    dim3 grid((unsigned)((M + 4 * RPW - 1) / (4 * RPW)));
+    hipLaunchKernelGGL((ln_quant_kernel<T, NV, RPW>), grid, dim3(256), 0, st, (const T*)x, M, C, ldx, eps, gamma, beta, nout, qp[0], qp[1],
+                       qp[2], mn, mx, of, o[0], o[1], o[2], ldo, vec);
+}
+
+template <typename T>
+void dispatch_ln(int nvl, hipStream_t st, const void* x, long M, int C, long ldx, float eps, const float* gamma, const float* beta,
+                 int nout, const float* const* qp, float3 mn, float3 mx, int3 of, int8_t* const* o, long ldo, int vec) {
+    switch (nvl) {
+        case 1:  launch_ln<T, 1>(st, x, M, C, ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, ldo, vec); break;
+        case 2:  launch_ln<T, 2>(st, x, M, C, ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, ldo, vec); break;
+        case 3:  launch_ln<T, 3>(st, x, M, C, ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, ldo, vec); break;
+        case 4:  launch_ln<T, 4>(st, x, M, C, ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, ldo, vec); break;
+        case 5:  launch_ln<T, 5>(st, x, M, C, ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, ldo, vec); break;
+        default: launch_ln<T, LN_MAXV>(st, x, M, C, ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, ldo, vec); break;
     }
 }
 
 }  // namespace
 
 extern "C" int64_t qd_groupnorm_ws_bytes(int64_t B, int64_t C, int64_t S) {
-    int64_t nchunk = (S + GN_ROWS - 1) / GN_ROWS;
+    int64_t nchunk = (S + gn_rows(S) - 1) / gn_rows(S);
     return (B * nchunk * C * 2 + B * C * 2) * (int64_t)sizeof(float);
 }
 
@@ -183,7 +241,7 @@ extern "C" int qd_groupnorm_silu_quant(const void* x, int x_dtype, int64_t B, in
     QD_REQUIRE(ldx >= C && (!out || (ldo >= C && ldo % 16 == 0 && qd_aligned(out, 16))), "qd_groupnorm_silu_quant: bad leading dimensions");
     QD_REQUIRE(B < 65536, "qd_groupnorm_silu_quant: batch too large");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int nchunk = (int)((S + GN_ROWS - 1) / GN_ROWS);
+    const int nchunk = (int)((S + gn_rows(S) - 1) / gn_rows(S));
     const int vec = qd_aligned(x, x_dtype == QD_F32 ? 16 : 8) && ldx % 4 == 0;
     float* part = reinterpret_cast<float*>(ws);
     float* ab = part + (size_t)B * nchunk * C * 2;
@@ -224,13 +282,12 @@ extern "C" int qd_layernorm_quant(const void* x, int x_dtype, int64_t M, int C, 
         (&mx.x)[i] = (float)qmax[i];
         (&of.x)[i] = off[i];
     }
-    dim3 grid((unsigned)((M + 3) / 4));
+    QD_REQUIRE(qd_aligned(gamma, 16) && qd_aligned(beta, 16), "qd_layernorm_quant: gamma/beta must be 16-byte aligned");
     const int vec = qd_aligned(x, x_dtype == QD_F32 ? 16 : 8) && ldx % 4 == 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (x_dtype == QD_F32)
-        hipLaunchKernelGGL(ln_quant_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp[0], qp[1], qp[2], mn, mx, of, o[0], o[1], o[2], (long)ldo, vec);
-    else
-        hipLaunchKernelGGL(ln_quant_kernel<__half>, grid, dim3(256), 0, st, (const __half*)x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp[0], qp[1], qp[2], mn, mx, of, o[0], o[1], o[2], (long)ldo, vec);
+    const int nvl = (C / 4 + 63) / 64;
+    if (x_dtype == QD_F32) dispatch_ln<float>(nvl, st, x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, (long)ldo, vec);
+    else dispatch_ln<__half>(nvl, st, x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, (long)ldo, vec);
     QD_LAUNCH_CHECK("qd_layernorm_quant");
     return 0;
 }
