@@ -761,7 +761,11 @@ int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
         if (force_gmt == 2) rc = dispatch<2, 4>(k, split, out, st);
         else rc = dispatch<1, 4>(k, split, out, st);
     } else if (N % 160 == 0) {
-        if (!split && mt2_ok && (force_mt ? force_mt == 2 : blocks(256, 160) >= 512)) rc = dispatch<2, 5>(k, split, out, st);      // >= 2 blocks per CU
+        // 256-row tiles only pay off when the K loop is long: short-K layers are bound by their output stream and
+        // run better as twice as many 128-row blocks whose load / store phases interleave (measured on SD, -0.3 ms)
+        static const int mt2_mink = getenv("QD_MT2_MINK") ? atoi(getenv("QD_MT2_MINK")) : 2048;
+        const long Ktot = (long)k.taps * d->seg[0].clen;
+        if (!split && mt2_ok && Ktot >= mt2_mink && (force_mt ? force_mt == 2 : blocks(256, 160) >= 512)) rc = dispatch<2, 5>(k, split, out, st);      // >= 2 blocks per CU
         else rc = dispatch<1, 5>(k, split, out, st);
     } else if (N % 224 == 0) {
         rc = dispatch<1, 7>(k, split, out, st);
