@@ -248,8 +248,14 @@ def main():
         measure_igemm(qnn, margs)                      # warm (eager path, caches)
         r = measure_igemm(qnn, margs)
         ach = r["ops"] / (r["total_ms"] * 1e-3) / 1e12
+        # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs of this
+        # command); bench.py cannot collect counters itself, so it reports the committed summary, SD workload only
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_igemm_hbm_traffic.json")
+        if kind == "sd" and os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_call_corrected")
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
-                           "frac": round(ach / I8_MFMA_PEAK_TOPS, 4), "traffic": None,
+                           "frac": round(ach / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic,
                            "kernel": "every qd_conv2d_i8 launch of one evaluation: igemm_dma_kernel<MT,NT,..> (+ splitk_finalize_kernel)", "launches_per_eval": r["launches"],
                            "avg_launch_us": round(1000.0 * r["total_ms"] / r["launches"], 2),
                            "igemm_ms_per_eval": round(r["total_ms"], 3), "algorithmic_GOP_per_eval": round(r["ops"] / 1e9, 1),
