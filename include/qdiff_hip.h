@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 6
+#define QD_ABI_VERSION 7
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -144,6 +144,10 @@ typedef struct {
     int32_t        hd_H, hd_d, hd_T, hd_Tpad, hd_dpad;
     float          oq_prescale;
     int32_t*       hd_sum;
+    /* optional (w_tiled, QD_EPI_LINEAR, fp32 out, Ho*Wo % 128 == 0): the kernel also writes the first level of the
+     * GroupNorm statistics of its output, gn_part[b][Ho*Wo/128][Cout][2] = {sum, sum of squares} over each 128-row
+     * chunk, which qd_groupnorm_silu_quant accepts as part_in (one pass over the tensor less).  Disables split-K. */
+    float*         gn_part;
 } qd_conv_desc;
 
 int qd_conv2d_i8(const qd_conv_desc* d, void* stream);
@@ -176,6 +180,9 @@ int qd_conv2d_i8_acc(const qd_conv_desc* d, int32_t* iout, void* stream);
  *     (attention blocks: openaimodel.py:324, attention.py:280-281, ddim diffusion.py:175).
  *     Two-quantizer outputs are not needed here (split only affects 1x1 skips).
  *     If yout != NULL the fp32 normalised (+SiLU) tensor is also written ([B*S][ldy]).
+ *     part_in != NULL: the first statistics level was already produced by the kernel that wrote x
+ *     (qd_conv_desc.gn_part: [B][nchunk_in][C][2] sums / sums of squares per row chunk); the statistics
+ *     pass over x is skipped.
  * ------------------------------------------------------------------------------------------ */
 int64_t qd_groupnorm_ws_bytes(int64_t B, int64_t C, int64_t S);
 int qd_groupnorm_silu_quant(const void* x, int x_dtype, int64_t B, int64_t S, int C, int64_t ldx,
@@ -183,7 +190,7 @@ int qd_groupnorm_silu_quant(const void* x, int x_dtype, int64_t B, int64_t S, in
                             int apply_silu,
                             const float* qparams, int qmin, int qmax, int off,
                             int8_t* out, int64_t ldo, float* yout, int64_t ldy,
-                            void* ws, void* stream);
+                            void* ws, const float* part_in, int nchunk_in, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K9a LayerNorm -> quantise (up to 3 consumers).  Replaces nn.LayerNorm (attention.py:229-231)

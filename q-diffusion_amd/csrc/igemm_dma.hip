@@ -55,6 +55,8 @@ struct ConvD {
     int   hdH, hdd, hdT, hdTpad, hddpad;   // O_HROWS / O_HTR: heads, head dim, tokens per sample, padded dims
     float oqpre;              // O_HROWS / O_HTR: multiplier applied before the output quantiser
     int32_t* hdsum;           // O_HTR: [(b*H+h)][dpad] column sums of the stored bytes (atomically accumulated)
+    float* gnpart;            // O_F32, optional: per-(sample, 128-row chunk, channel) {sum, sum of squares} of the output,
+    int    gn_nchunk;         //   i.e. the first level of GroupNorm's statistics (layout of gn_partial_kernel); S/128
 };
 
 // O_PART: split-K partial.  The block contracts K-steps [y*it_per, (y+1)*it_per) only and stores
@@ -489,11 +491,17 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
     const float*  const rf = reinterpret_cast<const float*>(p.residual) + (long)m0 * p.ldr + n0;
     const __half* const rh = reinterpret_cast<const __half*>(p.residual) + (long)m0 * p.ldr + n0;
     int32_t* const oi = p.iout + ((OUT == O_PART ? (long)blockIdx.y * p.M : 0L) + m0) * p.Cout + n0;
+    // optional GroupNorm statistics of the tensor being written (consumed by qd_groupnorm_silu_quant instead of
+    // its own pass over HBM): per-column partials in registers -> cross-half shuffle -> fixed-order LDS reduction
+    // over the waves of each 128-row chunk -> one {sum, sumsq} pair per (chunk, channel).  Deterministic.
+    const bool gn = OUT == O_F32 && p.gnpart != nullptr;
+    float* sGn = reinterpret_cast<float*>(smem);          // [4 waves][BN][2]  (the ring is dead by now)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int cl = j * 32 + frow;
         const bool nok = n0 + cl < p.Cout;
         const int clc = nok ? cl : 0;
+        float gs = 0.f, gq = 0.f;
         const float sc = sScale[cl];
         const int zc_n = sZc[cl];
         const int zw_n = sZw[cl];
@@ -541,8 +549,33 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
                     if (nok && m0 + rowl < p.M) {
                         if (OUT == O_F32) of[o0 + (unsigned)cr * ldo] = v;
                         else oh[o0 + (unsigned)cr * ldo] = __float2half(v);
+                        if (gn) { gs += v; gq += v * v; }
                     }
                 }
+            }
+        }
+        if (gn) {
+            gs += __shfl_xor(gs, 32);
+            gq += __shfl_xor(gq, 32);
+            if (fhalf == 0) { sGn[(wave * BN + cl) * 2] = gs; sGn[(wave * BN + cl) * 2 + 1] = gq; }
+        }
+    }
+    if (gn) {
+        __syncthreads();
+        const int c = threadIdx.x;
+        if (c < BN && n0 + c < p.Cout) {
+            constexpr int WPC = 4 / MT;                       // waves per 128-row chunk
+#pragma unroll
+            for (int ch = 0; ch < MT; ++ch) {
+                const int mrow = m0 + ch * 128;
+                if (mrow >= p.M) break;
+                float ts = 0.f, tq = 0.f;
+#pragma unroll
+                for (int w = 0; w < WPC; ++w) { ts += sGn[((ch * WPC + w) * BN + c) * 2]; tq += sGn[((ch * WPC + w) * BN + c) * 2 + 1]; }
+                const int b = mrow / HoWo, chunk = (mrow - b * HoWo) >> 7;
+                float* dst = p.gnpart + (((long)b * p.gn_nchunk + chunk) * p.Cout + n0 + c) * 2;
+                dst[0] = ts;
+                dst[1] = tq;
             }
         }
     }
@@ -716,6 +749,12 @@ int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
         k.hdH = d->hd_H; k.hdd = d->hd_d; k.hdT = d->hd_T; k.hdTpad = d->hd_Tpad; k.hddpad = d->hd_dpad;
         k.oqpre = d->oq_prescale; k.hdsum = d->hd_sum;
     }
+    if (d->gn_part) {
+        QD_REQUIRE(!iout && !heads && !geglu && d->out_dtype == QD_F32, "qd_conv2d_i8 (tiled): gn_part needs the plain fp32 epilogue");
+        QD_REQUIRE((d->Ho * d->Wo) % 128 == 0, "qd_conv2d_i8 (tiled): gn_part needs Ho*Wo %% 128 == 0 (a 128-row chunk stays inside one sample)");
+        k.gnpart = d->gn_part;
+        k.gn_nchunk = d->Ho * d->Wo / 128;
+    }
     const bool mt2_ok = !heads || d->hd_T % 256 == 0;            // a block must stay inside one sample
     if (geglu) {
         QD_REQUIRE(!iout && d->nseg == 1 && d->oq_params && d->Cout % 64 == 0, "qd_conv2d_i8 (tiled): GEGLU epilogue needs one segment, oq_params and Cout %% 64 == 0");
@@ -729,7 +768,7 @@ int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
     int rc;
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     int it_per = 0;
-    const int nsplit = (iout || !d->splitk_ws) ? 1 : choose_splitk(d, &it_per);
+    const int nsplit = (iout || !d->splitk_ws || d->gn_part) ? 1 : choose_splitk(d, &it_per);   // gn_part: fused epilogue only
     if (nsplit >= 2 && d->splitk_ws_bytes >= (int64_t)nsplit * M * N * 4) {
         QD_REQUIRE(qd_aligned(d->splitk_ws, 16), "qd_conv2d_i8 (tiled): splitk_ws must be 16-byte aligned");
         k.iout = reinterpret_cast<int32_t*>(d->splitk_ws);

@@ -233,7 +233,7 @@ extern "C" int64_t qd_groupnorm_ws_bytes(int64_t B, int64_t C, int64_t S) {
 extern "C" int qd_groupnorm_silu_quant(const void* x, int x_dtype, int64_t B, int64_t S, int C, int64_t ldx, int groups,
                                        float eps, const float* gamma, const float* beta, int apply_silu,
                                        const float* qparams, int qmin, int qmax, int off, int8_t* out, int64_t ldo,
-                                       float* yout, int64_t ldy, void* ws, void* stream) {
+                                       float* yout, int64_t ldy, void* ws, const float* part_in, int nchunk_in, void* stream) {
     QD_REQUIRE(x && ws && (out || yout), "qd_groupnorm_silu_quant: null pointer");
     QD_REQUIRE(!out || qparams, "qd_groupnorm_silu_quant: quantised output needs qparams");
     QD_REQUIRE(x_dtype == QD_F32 || x_dtype == QD_F16, "qd_groupnorm_silu_quant: dtype must be f32/f16");
@@ -241,15 +241,19 @@ extern "C" int qd_groupnorm_silu_quant(const void* x, int x_dtype, int64_t B, in
     QD_REQUIRE(ldx >= C && (!out || (ldo >= C && ldo % 16 == 0 && qd_aligned(out, 16))), "qd_groupnorm_silu_quant: bad leading dimensions");
     QD_REQUIRE(B < 65536, "qd_groupnorm_silu_quant: batch too large");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int nchunk = (int)((S + gn_rows(S) - 1) / gn_rows(S));
+    const int nchunk_own = (int)((S + gn_rows(S) - 1) / gn_rows(S));
     const int vec = qd_aligned(x, x_dtype == QD_F32 ? 16 : 8) && ldx % 4 == 0;
     float* part = reinterpret_cast<float*>(ws);
-    float* ab = part + (size_t)B * nchunk * C * 2;
-    if (x_dtype == QD_F32)
+    float* ab = part + (size_t)B * nchunk_own * C * 2;
+    QD_REQUIRE(!part_in || nchunk_in > 0, "qd_groupnorm_silu_quant: part_in needs nchunk_in > 0");
+    const int nchunk = part_in ? nchunk_in : nchunk_own;
+    if (part_in) {
+        // first statistics level came with the tensor (written by the producing GEMM's epilogue)
+    } else if (x_dtype == QD_F32)
         hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, (const float*)x, (long)S, C, (long)ldx, part, nchunk, vec);
     else
         hipLaunchKernelGGL(gn_partial_kernel<__half>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, (const __half*)x, (long)S, C, (long)ldx, part, nchunk, vec);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, (unsigned)B), dim3(64), 0, st, part, nchunk, (long)S, C, groups, eps, gamma, beta, ab);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, (unsigned)B), dim3(64), 0, st, part_in ? part_in : part, nchunk, (long)S, C, groups, eps, gamma, beta, ab);
     long rows = B * S;
     long total = rows * (C / 4);
     dim3 grid((unsigned)((total + 255) / 256));

@@ -183,7 +183,7 @@ class SpatialTransformer(nn.Module):
             t = self.proj_in.forward_codes(xq, b, h, w).view(b, h * w, -1)
             for blk in self.transformer_blocks:
                 t = blk(t, context)
-            out = qb._linear_rows(self.proj_out, t.reshape(b * h * w, t.shape[-1]), residual=rows)
+            out = qb._linear_rows(self.proj_out, t.reshape(b * h * w, t.shape[-1]), residual=rows, gn_stats=True)
             return qb._rows_to_nchw(out, b, h, w)
         t = self.proj_in(self.norm(x))
         t = t.permute(0, 2, 3, 1).reshape(b, h * w, t.shape[1])
@@ -471,7 +471,8 @@ class UNetModel(nn.Module):
         h = self.middle_block(h, emb, context)
         for blk in self.output_blocks:
             split = h.shape[1] if self.split else 0          # reference :772-777
-            h = blk(torch.cat([h, skips.pop()], dim=1), emb, context, split=split)
+            from ..quant_block import cat_channels              # keeps the producers' GroupNorm statistics
+            h = blk(cat_channels(h, skips.pop()), emb, context, split=split)
         return self.out(h.type(x.dtype))
 
 

@@ -213,9 +213,12 @@ def conv_out_hw(H, W, plan, pad_br=None):
 
 
 def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, residual=None, acc_out=None,
-                 out_dtype=torch.float32, pad_tl=None, splitk=None):
+                 out_dtype=torch.float32, pad_tl=None, splitk=None, gn_stats=False):
     """Run K3/K4 on quantised rows xq [B*H*W][ldx].  Returns out [B*Ho*Wo][Cout] (row-major).
-    splitk=False forbids the split-K schedule (tests compare it with the default, which lets the library decide)."""
+    splitk=False forbids the split-K schedule (tests compare it with the default, which lets the library decide).
+    gn_stats=True: when the layer is eligible (tile-ordered int4, fp32 out, Ho*Wo % 128 == 0, not a split-K layer) the
+    kernel also writes the first level of GroupNorm statistics of its output; they are attached to the returned tensor
+    as `out.qd_gn_part` ([B][Ho*Wo/128][Cout][2]) for groupnorm_silu_quant to pick up."""
     if Ho is None:
         Ho, Wo = conv_out_hw(H, W, plan)
     M = B * Ho * Wo
@@ -230,7 +233,14 @@ def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, re
                         B=B, H=H, W=W, Ho=Ho, Wo=Wo, Cout=plan.Cout, kh=plan.kh, kw=plan.kw, stride=plan.stride,
                         pad_t=pad, pad_l=pad, wbits=plan.pack.wbits, w_tiled=plan.pack.tiled, segs=plan.segs,
                         splitk=splitk)
+    part = None
+    if (gn_stats and acc_out is None and plan.pack.tiled and out.dtype == torch.float32 and (Ho * Wo) % 128 == 0
+            and out.stride(0) == plan.Cout and (splitk is False or hip.splitk_ws_bytes(call) == 0)):
+        part = torch.empty((B, Ho * Wo // 128, plan.Cout, 2), dtype=torch.float32, device=xq.device)
+        call.gn_part = part
     hip.conv2d_i8(call, acc_out=acc_out)
+    if part is not None:
+        out.qd_gn_part = part
     return out if acc_out is None else acc_out
 
 
@@ -263,8 +273,15 @@ def _workspace(nbytes, device):
     return buf
 
 
-def groupnorm_silu_quant(x_rows, B, S, C, gn, silu, plan=None, want_float=False):
-    """x_rows: channels-last rows [B*S][>=C] (fp32/fp16).  Returns (int8 rows for `plan`, float rows)."""
+def groupnorm_silu_quant(x_rows, B, S, C, gn, silu, plan=None, want_float=False, part=None):
+    """x_rows: channels-last rows [B*S][>=C] (fp32/fp16).  Returns (int8 rows for `plan`, float rows).
+    part: first-level statistics that came with x_rows from its producer (conv_forward(gn_stats=True))."""
+    if part is not None:
+        # producers that ran as one [B*S]-row GEMM report [1][B*S/128]: same memory as [B][S/128] when S % 128 == 0
+        if S % 128 == 0 and part.shape[2] == C and part.shape[0] * part.shape[1] * 128 == B * S and part.is_contiguous():
+            part = part.view(B, S // 128, C, 2)
+        else:
+            part = None
     dev = x_rows.device
     ws = _workspace(hip.groupnorm_ws_bytes(B, C, S), dev)
     out = torch.empty((B * S, plan.ldx), dtype=torch.int8, device=dev) if plan is not None else None
@@ -273,7 +290,7 @@ def groupnorm_silu_quant(x_rows, B, S, C, gn, silu, plan=None, want_float=False)
         raise hip.HipEngineError("groupnorm producer feeds single-segment consumers of the same width only")
     hip.groupnorm_silu_quant(x_rows, B, S, C, x_rows.stride(0), gn.num_groups, gn.eps, gn.weight, gn.bias, silu,
                              plan.qparams[0] if plan is not None else None, plan.grids[0] if plan is not None else None,
-                             out, plan.ldx if plan is not None else 0, ws, yout=y, ldy=C)
+                             out, plan.ldx if plan is not None else 0, ws, yout=y, ldy=C, part=part)
     return out, y
 
 

@@ -42,7 +42,8 @@ class ConvDesc(ctypes.Structure):
                 ("oq_off", ctypes.c_int32), ("_pad2", ctypes.c_int32),
                 ("splitk_ws", ctypes.c_void_p), ("splitk_ws_bytes", ctypes.c_int64),
                 ("hd_H", ctypes.c_int32), ("hd_d", ctypes.c_int32), ("hd_T", ctypes.c_int32), ("hd_Tpad", ctypes.c_int32),
-                ("hd_dpad", ctypes.c_int32), ("oq_prescale", ctypes.c_float), ("hd_sum", ctypes.c_void_p)]
+                ("hd_dpad", ctypes.c_int32), ("oq_prescale", ctypes.c_float), ("hd_sum", ctypes.c_void_p),
+                ("gn_part", ctypes.c_void_p)]
 
 
 EPI_LINEAR, EPI_GEGLU_I8, EPI_HEADS_I8, EPI_HEADS_T_I8 = 0, 1, 2, 3
@@ -77,7 +78,7 @@ def load():
     lib.qd_conv2d_i8_splitk_ws_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.qd_conv2d_i8_splitk_ws_bytes.restype = ctypes.c_int64
     lib.qd_groupnorm_silu_quant.argtypes = [vp, i32, i64, i64, i32, i64, i32, f32, vp, vp, i32, vp, i32, i32, i32, vp,
-                                            i64, vp, i64, vp, vp]
+                                            i64, vp, i64, vp, vp, i32, vp]
     lib.qd_layernorm_quant.argtypes = [vp, i32, i64, i32, i64, f32, vp, vp, i32, ctypes.POINTER(vp),
                                        ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32),
                                        ctypes.POINTER(vp), i64, vp]
@@ -86,7 +87,7 @@ def load():
                                       vp, vp, i32, i32, vp]
     lib.qd_attn_i8.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp,
                                i64, vp, i64, vp, i32, i32, i32, vp]
-    if lib.qd_abi_version() != 6:
+    if lib.qd_abi_version() != 7:
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -164,7 +165,7 @@ class ConvCall:
     """Python-side description of one qd_conv2d_i8 launch (tensors, not pointers)."""
     __slots__ = ("x", "w", "out", "bias", "rowbias", "residual", "ldx", "ldk", "ldo", "ldr", "ld_rowbias",
                  "B", "H", "W", "Ho", "Wo", "Cout", "kh", "kw", "stride", "pad_t", "pad_l", "wbits", "w_tiled", "segs",
-                 "epilogue", "oq_params", "oq_grid", "splitk", "heads")
+                 "epilogue", "oq_params", "oq_grid", "splitk", "heads", "gn_part")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -225,6 +226,7 @@ def _conv_desc(c):
             d.hd_sum = _ptr(hd.get("sum"), "hd_sum")
     else:
         d.out_dtype = _dtype(c.out) if c.out is not None else F32
+    d.gn_part = _ptr(c.gn_part, "gn_part")
     d.nseg = len(c.segs)
     for i, s in enumerate(c.segs):
         g = d.seg[i]
@@ -238,11 +240,14 @@ def groupnorm_ws_bytes(B, C, S):
     return int(load().qd_groupnorm_ws_bytes(B, C, S))
 
 
-def groupnorm_silu_quant(x, B, S, C, ldx, groups, eps, gamma, beta, silu, qparams, grid, out, ldo, ws, yout=None, ldy=0):
+def groupnorm_silu_quant(x, B, S, C, ldx, groups, eps, gamma, beta, silu, qparams, grid, out, ldo, ws, yout=None, ldy=0,
+                         part=None):
+    """part: optional [B][nchunk][C][2] fp32 first-level statistics written by the producer of x (ConvCall.gn_part)."""
     g = grid or Grid(0, 0, 0)
     _check(load().qd_groupnorm_silu_quant(_ptr(x), _dtype(x), B, S, C, ldx, groups, float(eps), _ptr(gamma), _ptr(beta),
                                           1 if silu else 0, _ptr(qparams), g.qmin, g.qmax, g.off, _ptr(out), ldo,
-                                          _ptr(yout), ldy, _ptr(ws), _stream()), "qd_groupnorm_silu_quant")
+                                          _ptr(yout), ldy, _ptr(ws), _ptr(part), part.shape[1] if part is not None else 0,
+                                          _stream()), "qd_groupnorm_silu_quant")
 
 
 def layernorm_quant(x, M, C, ldx, eps, gamma, beta, qparams_list, grids, outs, ldo):

@@ -35,11 +35,32 @@ def _nhwc_rows(x):
         x = x.contiguous(memory_format=torch.channels_last)
         if x.stride(1) != 1:  # degenerate shapes where channels_last == contiguous
             x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
-    return x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+    rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+    _carry_gn_part(x, rows)
+    return rows
+
+
+def _carry_gn_part(src, dst):
+    """GroupNorm first-level statistics written by the kernel that produced `src` (engine.conv_forward(gn_stats=True))
+    travel with the tensor as a plain attribute; views do not inherit attributes, so re-attach them by hand."""
+    part = getattr(src, "qd_gn_part", None)
+    if part is not None:
+        dst.qd_gn_part = part
+    return dst
 
 
 def _rows_to_nchw(rows, B, H, W):
-    return rows.view(B, H, W, rows.shape[1]).permute(0, 3, 1, 2)
+    return _carry_gn_part(rows, rows.view(B, H, W, rows.shape[1]).permute(0, 3, 1, 2))
+
+
+def cat_channels(a, b):
+    """torch.cat([a, b], dim=1) of two NCHW activations that keeps the producers' GroupNorm statistics."""
+    out = torch.cat([a, b], dim=1)
+    pa, pb = getattr(a, "qd_gn_part", None), getattr(b, "qd_gn_part", None)
+    if pa is not None and pb is not None and pa.shape[0] * pa.shape[1] == pb.shape[0] * pb.shape[1]:
+        n = pa.shape[0] * pa.shape[1]
+        out.qd_gn_part = torch.cat([pa.reshape(1, n, -1, 2), pb.reshape(1, n, -1, 2)], dim=2)
+    return out
 
 
 def _int_mode(*modules):
@@ -56,7 +77,7 @@ def _gn_silu_to(conv, rows, B, S, C, gn, silu=True):
     if not conv.act_quantizer.inited:
         y = F.group_norm(rows.view(B, S, C).permute(0, 2, 1).float(), gn.num_groups, gn.weight, gn.bias, gn.eps)
         conv._init_act_quantizers(F.silu(y) if silu else y)
-    xq, _ = engine.groupnorm_silu_quant(rows, B, S, C, gn, silu, plan=conv.conv_plan())
+    xq, _ = engine.groupnorm_silu_quant(rows, B, S, C, gn, silu, plan=conv.conv_plan(), part=getattr(rows, "qd_gn_part", None))
     return xq
 
 
@@ -69,13 +90,13 @@ def _ln_to(consumers, rows, M, C, ln):
     return engine.layernorm_quant(rows, M, C, ln, [m.conv_plan() for m in consumers])
 
 
-def _linear_rows(lin, rows, residual=None):
+def _linear_rows(lin, rows, residual=None, gn_stats=False):
     """QuantModule linear on float rows [M,K] -> [M,N] (quantise + integer GEMM)."""
     lin._init_act_quantizers(rows)
     plan = lin.conv_plan()
     M, K = rows.shape
     xq = engine.quantize_rows(rows, plan, 1, K, M, (0, rows.stride(1), rows.stride(0)))
-    return engine.conv_forward(plan, xq, 1, 1, M, 1, M, residual=residual)
+    return engine.conv_forward(plan, xq, 1, 1, M, 1, M, residual=residual, gn_stats=gn_stats)
 
 
 class _AttnQuant:
@@ -188,14 +209,14 @@ class QuantResBlock(BaseQuantBlock, *_TIMESTEP_BASES):
         rows = _nhwc_rows(x)
         xq = _gn_silu_to(conv1, rows, B, S, C, self.in_layers[0])
         e = self.emb_layers(emb)                                      # SiLU + integer linear -> [B, Cout]
-        h = conv1.forward_codes(xq, B, H, W, rowbias=e.float().contiguous())
+        h = conv1.forward_codes(xq, B, H, W, rowbias=e.float().contiguous(), gn_stats=True)
         hq = _gn_silu_to(conv2, h, B, S, self.out_channels, self.out_layers[0])
         if isinstance(self.skip_connection, nn.Identity):
             res = rows
         else:
             sk = self.skip_connection(x, split=split) if split != 0 else self.skip_connection(x)
             res = _nhwc_rows(sk)
-        out = conv2.forward_codes(hq, B, H, W, residual=res)
+        out = conv2.forward_codes(hq, B, H, W, residual=res, gn_stats=True)     # the next block normalises this
         return _rows_to_nchw(out, B, H, W)
 
 

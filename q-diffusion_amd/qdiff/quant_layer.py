@@ -370,8 +370,11 @@ class QuantModule(nn.Module):
                 sb, sc, sh, sw = x.stride()
             xq = engine.quantize_rows(x, plan, B, C, H * W, (sb, sc, sw))
             Ho, Wo = engine.conv_out_hw(H, W, plan)
-            out = engine.conv_forward(plan, xq, B, H, W, Ho, Wo)
-            return out.view(B, Ho, Wo, plan.Cout).permute(0, 3, 1, 2)
+            out = engine.conv_forward(plan, xq, B, H, W, Ho, Wo, gn_stats=True)   # most conv outputs feed a GroupNorm
+            y = out.view(B, Ho, Wo, plan.Cout).permute(0, 3, 1, 2)
+            if hasattr(out, "qd_gn_part"):
+                y.qd_gn_part = out.qd_gn_part
+            return y
         if self.kind == 'conv1d':
             B, C, T = x.shape
             sb, sc, st = x.stride()
@@ -407,10 +410,10 @@ class QuantModule(nn.Module):
             cache[0] = key
         return cache[1]
 
-    def forward_codes(self, xq, B, H, W, Ho=None, Wo=None, rowbias=None, residual=None, pad_tl=None):
+    def forward_codes(self, xq, B, H, W, Ho=None, Wo=None, rowbias=None, residual=None, pad_tl=None, gn_stats=False):
         """Integer path for a producer that already emitted this module's int8 rows (fused blocks)."""
         return engine.conv_forward(self.conv_plan(), xq, B, H, W, Ho, Wo, rowbias=rowbias, residual=residual,
-                                   pad_tl=pad_tl)
+                                   pad_tl=pad_tl, gn_stats=gn_stats)
 
     # -- forward ------------------------------------------------------------------------------
     def forward(self, input: torch.Tensor, split: int = 0):

@@ -169,15 +169,30 @@ def conv2d_i8(c, acc_out=None):
             hd["sum"] += rsum                                    # the kernel accumulates atomically into a zeroed buffer
         return
     c.out[:, :c.Cout] = rows.to(c.out.dtype)
+    if getattr(c, "gn_part", None) is not None:                  # first level of GroupNorm statistics, 128-row chunks
+        ch = c.out[:, :c.Cout].float().view(-1, 128, c.Cout)
+        c.gn_part.view(-1, c.Cout, 2).copy_(torch.stack([ch.sum(1), (ch * ch).sum(1)], dim=-1))
 
 
 def groupnorm_ws_bytes(B, C, S):
     return 64
 
 
-def groupnorm_silu_quant(x, B, S, C, ldx, groups, eps, gamma, beta, silu, qparams, grid, out, ldo, ws, yout=None, ldy=0):
+def groupnorm_silu_quant(x, B, S, C, ldx, groups, eps, gamma, beta, silu, qparams, grid, out, ldo, ws, yout=None, ldy=0,
+                         part=None):
     v = x[:, :C].float().view(B, S, C).permute(0, 2, 1)
-    y = F.group_norm(v, groups, gamma, beta, eps)
+    if part is not None:
+        # statistics from the producer's partial sums (what the kernel does with part_in), fp64 second level
+        st = part.double().view(B, -1, groups, C // groups, 2).sum(dim=(1, 3))
+        n = S * (C // groups)
+        mean = st[..., 0] / n
+        var = (st[..., 1] / n - mean * mean).clamp_min(0)
+        rstd = (1.0 / torch.sqrt(var + eps)).float().repeat_interleave(C // groups, dim=1).view(B, C, 1)
+        fmean = mean.float().repeat_interleave(C // groups, dim=1).view(B, C, 1)
+        a = rstd * gamma.view(1, C, 1)
+        y = v * a + (beta.view(1, C, 1) - fmean * a)
+    else:
+        y = F.group_norm(v, groups, gamma, beta, eps)
     if silu:
         y = y * torch.sigmoid(y)
     rows = y.permute(0, 2, 1).reshape(B * S, C)
@@ -242,9 +257,14 @@ def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, 
         out[:, :H * d] = rows
 
 
+def splitk_ws_bytes(c):
+    """The emulation never splits K (the schedule does not change results)."""
+    return 0
+
+
 def install(monkeypatch):
     """Replace qdiff.hip's device entry points by the emulation (CPU tensors only)."""
     from qdiff import hip
     for name in ("quantize_act", "pack_weights", "pack_weights_t4", "conv2d_i8", "groupnorm_ws_bytes", "groupnorm_silu_quant",
-                 "layernorm_quant", "geglu_quant", "quantize_heads", "attn_i8"):
+                 "layernorm_quant", "geglu_quant", "quantize_heads", "attn_i8", "splitk_ws_bytes"):
         monkeypatch.setattr(hip, name, globals()[name])

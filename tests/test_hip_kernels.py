@@ -514,3 +514,40 @@ def test_attention_quantised_output_matches_quantise_rows(cuda):
     got = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d, out_plan=plan)
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("B,C,H,Cout,k", [(2, 64, 16, 320, 3), (3, 320, 16, 160, 1), (1, 96, 32, 640, 3)])
+def test_conv_emits_groupnorm_statistics(cuda, B, C, H, Cout, k):
+    """gn_stats=True: the GEMM epilogue writes per-128-row {sum, sumsq} of its own output; GroupNorm fed with them
+    produces the same codes as the two-pass kernel (statistics differ only by fp32 summation order)."""
+    from qdiff import engine, hip
+    g = torch.Generator().manual_seed(51)
+    x = F.silu(torch.randn(B, C, H, H, generator=g))
+    w = torch.randn(Cout, C, k, k, generator=g) * 0.05
+    bias = torch.randn(Cout, generator=g)
+    q = _weight_quantizer(w, 4, True, g)
+    d, z = R.uaq_init_scale(x, 8, False, False, "max")
+    plan = engine.build_conv_plan(engine.pack_module_weights(w.to(cuda), [q], 0), [_aq(d, z)], k, k, 1, k // 2, bias.to(cuda))
+    xq = engine.quantize_rows(x.to(cuda), plan, B, C, H * H, (C * H * H, H * H, 1))
+    res = torch.randn(B * H * H, Cout, generator=g).to(cuda)
+    out = engine.conv_forward(plan, xq, B, H, H, residual=res, gn_stats=True, splitk=False)
+    ref = engine.conv_forward(plan, xq, B, H, H, residual=res, splitk=False)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and hasattr(out, "qd_gn_part")
+    part = out.qd_gn_part.cpu().double()
+    ch = ref.cpu().double().view(B, H * H // 128, 128, Cout)
+    want = torch.stack([ch.sum(2), (ch * ch).sum(2)], dim=-1)
+    assert (part - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+    # consumer
+    gn = torch.nn.GroupNorm(32, Cout).to(cuda)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(Cout, generator=g)); gn.bias.copy_(torch.randn(Cout, generator=g))
+    y = F.silu(F.group_norm(ref.view(B, H * H, Cout).permute(0, 2, 1), 32, gn.weight, gn.bias, gn.eps)).cpu()
+    dy, zy = R.uaq_init_scale(y, 8, False, False, "max")
+    w2 = torch.randn(32, Cout, 1, 1, generator=g) * 0.05
+    plan2 = engine.build_conv_plan(engine.pack_module_weights(w2.to(cuda), [_weight_quantizer(w2, 4, True, g)], 0), [_aq(dy, zy)], 1, 1, 1, 0, None)
+    a, _ = engine.groupnorm_silu_quant(ref, B, H * H, Cout, gn, True, plan=plan2)
+    b, _ = engine.groupnorm_silu_quant(out, B, H * H, Cout, gn, True, plan=plan2, part=out.qd_gn_part)
+    torch.cuda.synchronize()
+    diff = (a.int() - b.int()).abs()
+    assert diff.max().item() <= 1 and (diff > 0).float().mean().item() <= 1e-3
