@@ -10,8 +10,9 @@
 //     swizzle of the A tile is applied to the source chunk index instead;
 //   * weights are pre-tiled at pack time (qd_pack_weights_t4): one K-step x 32 output channels is a
 //     contiguous 1-KB block already in fragment order, so the B copy is a straight memcpy and the
-//     fragment read is a conflict-free ds_read_b64; nibbles are unpacked (and their zero point
-//     subtracted) at fragment-read time, which keeps 4-bit weights 4-bit all the way into LDS;
+//     fragment read is a conflict-free ds_read_b64; the RAW nibbles are unpacked at fragment-read time
+//     (two AND/shift per 8 weights — the weight zero point is restored in the epilogue through the
+//     activation row sums), which keeps 4-bit weights 4-bit all the way into LDS;
 //   * a 3-deep LDS ring keeps two K-steps in flight across the single barrier per step
 //     (counted s_waitcnt vmcnt(N), raw s_barrier: cdna_hip_programming.md §5 "Pipelining across
 //     barriers").

@@ -224,6 +224,20 @@ class Upsample(nn.Module):
 
     def forward(self, x):
         assert x.shape[1] == self.channels
+        if self.use_conv:
+            from .. import quant_block as qb
+            conv = self.conv
+            if qb._int_mode(conv) and conv.split == 0 and conv.act_quantizer.inited and not conv.act_quantizer.running_stat:
+                # quantisation commutes with nearest-neighbour replication: quantise the small map, replicate the int8
+                # rows (4x fewer bytes than replicating fp32 and quantising the large map), then the integer conv
+                from .. import engine
+                b, c, h, w = x.shape
+                rows = qb._nhwc_rows(x)
+                plan = conv.conv_plan()
+                xq = engine.quantize_rows(rows, plan, 1, c, b * h * w, (0, 1, rows.stride(0)))
+                up = xq.view(b, h, 1, w, 1, -1).expand(b, h, 2, w, 2, xq.shape[1]).reshape(b * 4 * h * w, xq.shape[1])
+                out = conv.forward_codes(up, b, 2 * h, 2 * w, gn_stats=True)
+                return qb._rows_to_nchw(out, b, 2 * h, 2 * w)
         x = F.interpolate(x, scale_factor=2, mode="nearest")
         return self.conv(x) if self.use_conv else x
 
