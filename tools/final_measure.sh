@@ -30,3 +30,5 @@ json.dump(res, open(f"{out}/pmc_hbm.json", "w"), indent=1)
 print(json.dumps(res))
 PY
 head -40 $out/kernel_stats.md | cut -c1-150
+# keep the summaries only: the raw databases exceed what gpurun copies back
+find $out -name '*.db' -delete; find $out -name '*.csv' -delete
