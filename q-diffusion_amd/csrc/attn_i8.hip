@@ -15,6 +15,7 @@
 // 16-bit probabilities are split into hi/lo bytes: two exact int32 accumulators, combined in int64.
 #include "common.h"
 #include <climits>
+#include <type_traits>
 
 namespace {
 
@@ -131,11 +132,13 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_k
 #pragma unroll
             for (int r = 1; r < 16; ++r) mi = max(mi, d[r]);
         }
-        for (int jt = 0; jt < ntile; ++jt) {
+        // The ragged last tile is peeled out of the loop (TAIL is a compile-time flag): with a run-time `tail` the
+        // compiler kept 56 masking selects per tile in the hot loop (a third of sweep 1's VALU work).
+        auto s1_tile = [&](int jt, auto tail_tag) __attribute__((always_inline)) {
+            constexpr bool tail = decltype(tail_tag)::value;
             if (jt + 1 < ntile) load_k(jt + 1, kfn);
             int d[16];
             scores(kf, mi, d);                                // d = s - mi
-            const bool tail = jt == tail_tile;
             if (tail) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) if (!key_ok(jt, r)) d[r] = MASKED;
@@ -165,7 +168,9 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_k
 #pragma unroll
                 for (int kk = 0; kk < DT; ++kk) kf[kk] = kfn[kk];
             }
-        }
+        };
+        for (int jt = 0; jt < tail_tile; ++jt) s1_tile(jt, std::false_type{});
+        if (tail_tile < ntile) s1_tile(tail_tile, std::true_type{});
     }
     {
         const int mo = __shfl_xor(mi, 32);
@@ -190,14 +195,14 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_k
     {
         v4i kf[DT], kfn[DT];
         load_k(0, kf);
-        for (int jt = 0; jt < ntile; ++jt) {
+        auto s2_tile = [&](int jt, auto tail_tag) __attribute__((always_inline)) {
+            constexpr bool tail = decltype(tail_tag)::value;
             v4i vf[DT];
 #pragma unroll
             for (int t = 0; t < DT; ++t) vf[t] = *reinterpret_cast<const v4i*>(vbase + (long)t * 32 * p.Spad + jt * 32);
             if (jt + 1 < ntile) load_k(jt + 1, kfn);
             int d[16];
             scores(kf, mi, d);                                // d = s - rowmax <= 0
-            const bool tail = jt == tail_tile;
             unsigned ub[16];                                      // float bits of uu + MAGIC: low 16 bits == uu
             const v2f cs2v = {cs2, cs2}, invv = {inv, inv}, ubv = {ubias, ubias}, magic = {MAGIC, MAGIC};
 #pragma unroll
@@ -246,7 +251,9 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_k
 #pragma unroll
                 for (int kk = 0; kk < DT; ++kk) kf[kk] = kfn[kk];
             }
-        }
+        };
+        for (int jt = 0; jt < tail_tile; ++jt) s2_tile(jt, std::false_type{});
+        if (tail_tile < ntile) s2_tile(tail_tile, std::true_type{});
     }
     // sum over valid keys of uu = 256*hi + lo, from the signed operand bytes (masked keys hold 0)
     int uusum = dlo + 128 * nvalid + (P16 ? 256 * (dhi + 128 * nvalid) : 0);
