@@ -139,7 +139,9 @@ typedef struct {
      *   HEADS_I8  : out[(b*H+h)][hd_Tpad][hd_dpad]               (transpose=0 layout)
      *   HEADS_T_I8: out[(b*H+h)][hd_dpad][hd_Tpad], key-permuted (transpose=1 layout); hd_sum[(b*H+h)][hd_dpad]
      *               += column sums (caller zeroes hd_sum first).
-     * Pad bytes are not written: out must be zero-initialised once (it can then be reused).
+     * HEADS_I8 also accepts an fp32 `residual` (added before the quantiser): with hd_H = 1, hd_d = Cout it is
+     * "Linear + residual -> int8 rows of the next Linear" (transformer FF output feeding SpatialTransformer.proj_out).
+ * Pad bytes are not written: out must be zero-initialised once (it can then be reused).
      * hd_T must be a multiple of 128 (a tile of rows never straddles two samples).                         */
     int32_t        hd_H, hd_d, hd_T, hd_Tpad, hd_dpad;
     float          oq_prescale;

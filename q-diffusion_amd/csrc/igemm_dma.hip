@@ -428,14 +428,25 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
             const float bias_n = sBias[cl];
             if constexpr (OUT == O_HROWS) {
                 int8_t* ob = o8 + (((long)bidx * p.hdH + h) * p.hdTpad + t0) * p.hddpad + dd;
+                // optional fp32 residual (H = 1, d = Cout turns this epilogue into "Linear + residual -> the next
+                // Linear's int8 rows": the FF output of a transformer block feeding SpatialTransformer.proj_out)
+                const bool hres = p.residual != nullptr;
+                const float* rfh = reinterpret_cast<const float*>(p.residual) + (long)m0 * p.ldr + n0;
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const int rbase = wave * (32 * MT) + i * 32 + 4 * fhalf;
+                    float rs[16];
+                    if (hres) {
+                        const unsigned r0 = (unsigned)rbase * (unsigned)p.ldr + (nok ? cl : 0);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) rs[r] = rfh[r0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.ldr];
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int rowl = rbase + (r & 3) + 8 * (r >> 2);
                         const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rowl] - kz);
-                        const float v = (float)I * sc + bias_n;
+                        float v = (float)I * sc + bias_n;
+                        if (hres) v += rs[r];
                         const int8_t code = (int8_t)(qd_code(v * p.oqpre, od, oz, p.oqmin, p.oqmax) - p.oqoff);
                         if (nok) ob[(unsigned)rowl * (unsigned)p.hddpad] = code;
                     }
@@ -745,7 +756,8 @@ int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
         QD_REQUIRE(d->hd_T > 0 && d->hd_T % 128 == 0 && k.M % d->hd_T == 0, "qd_conv2d_i8 (tiled): heads epilogue: tokens per sample (%d) must be a multiple of 128 dividing M", d->hd_T);
         QD_REQUIRE(d->hd_Tpad % 32 == 0 && d->hd_Tpad >= d->hd_T && d->hd_dpad % 32 == 0 && d->hd_dpad >= d->hd_d, "qd_conv2d_i8 (tiled): heads epilogue: bad padded dims");
         QD_REQUIRE(qd_aligned(d->out, 16) && (d->epilogue != QD_EPI_HEADS_T_I8 || d->hd_sum), "qd_conv2d_i8 (tiled): heads epilogue: out unaligned or hd_sum missing");
-        QD_REQUIRE(!d->rowbias && !d->residual, "qd_conv2d_i8 (tiled): heads epilogue takes no rowbias / residual");
+        QD_REQUIRE(!d->rowbias && (!d->residual || (d->epilogue == QD_EPI_HEADS_I8 && d->out_dtype == QD_F32)),
+                   "qd_conv2d_i8 (tiled): heads epilogue takes no rowbias; an fp32 residual only with QD_EPI_HEADS_I8");
         k.oq = d->oq_params; k.oqmin = (float)d->oq_min; k.oqmax = (float)d->oq_max; k.oqoff = d->oq_off;
         k.hdH = d->hd_H; k.hdd = d->hd_d; k.hdT = d->hd_T; k.hdTpad = d->hd_Tpad; k.hddpad = d->hd_dpad;
         k.oqpre = d->oq_prescale; k.hdsum = d->hd_sum;

@@ -181,9 +181,16 @@ class SpatialTransformer(nn.Module):
             rows = qb._nhwc_rows(x)
             xq = qb._gn_silu_to(self.proj_in, rows, b, h * w, c, self.norm, silu=False)
             t = self.proj_in.forward_codes(xq, b, h, w).view(b, h * w, -1)
-            for blk in self.transformer_blocks:
-                t = blk(t, context)
-            out = qb._linear_rows(self.proj_out, t.reshape(b * h * w, t.shape[-1]), residual=rows, gn_stats=True)
+            last = len(self.transformer_blocks) - 1
+            for i, blk in enumerate(self.transformer_blocks):
+                if i == last and self.proj_out.act_quantizer.inited and isinstance(blk, qb.QuantBasicTransformerBlock):
+                    t = blk(t, context, out_plan=self.proj_out.conv_plan())     # may hand back proj_out's int8 rows
+                else:
+                    t = blk(t, context)
+            if t.dtype == torch.int8:
+                out = self.proj_out.forward_codes(t, 1, 1, b * h * w, residual=rows, gn_stats=True)
+            else:
+                out = qb._linear_rows(self.proj_out, t.reshape(b * h * w, t.shape[-1]), residual=rows, gn_stats=True)
             return qb._rows_to_nchw(out, b, h, w)
         t = self.proj_in(self.norm(x))
         t = t.permute(0, 2, 3, 1).reshape(b, h * w, t.shape[1])

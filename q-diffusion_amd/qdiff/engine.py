@@ -414,6 +414,26 @@ def project_heads(plan, xq, B, T, H, ap, which, out8, vsum=None):
     hip.conv2d_i8(call)
 
 
+def rows_i8_fusable(plan, next_plan, T):
+    """`plan`'s output (+ residual) can be written as `next_plan`'s int8 input rows by the GEMM epilogue."""
+    return bool(plan.pack.tiled and len(plan.segs) == 1 and len(next_plan.segs) == 1 and T % 128 == 0
+                and plan.Cout % 32 == 0 and next_plan.ldx == plan.Cout)
+
+
+def linear_to_rows_i8(plan, xq, B, T, next_plan, residual=None):
+    """Linear on B*T token rows whose only consumer is `next_plan`: out = quantise_next(I*scale + bias + residual), int8
+    rows [B*T][next_plan.ldx] (QD_EPI_HEADS_I8 with one "head" as wide as the layer: plain row-major bytes)."""
+    out8 = torch.empty((B * T, next_plan.ldx), dtype=torch.int8, device=xq.device)
+    call = hip.ConvCall(x=xq, w=plan.pack.wq, out=out8, bias=plan.bias, residual=residual, ldx=plan.ldx, ldk=plan.pack.ldk, ldo=0,
+                        ldr=(residual.stride(0) if residual is not None else 0),
+                        B=B, H=1, W=T, Ho=1, Wo=T, Cout=plan.Cout, kh=1, kw=1, stride=1, pad_t=0, pad_l=0,
+                        wbits=plan.pack.wbits, w_tiled=True, segs=plan.segs, epilogue=hip.EPI_HEADS_I8,
+                        oq_params=next_plan.qparams[0], oq_grid=next_plan.grids[0],
+                        heads=dict(H=1, d=plan.Cout, T=T, Tpad=T, dpad=plan.Cout, prescale=1.0, sum=None))
+    hip.conv2d_i8(call)
+    return out8
+
+
 def heads_from_float(ap, which, x, B, T, H, d, strides, out8, vsum=None):
     """Same operand bytes from an fp32 projection output (the unfused route: ragged token counts, context k/v)."""
     hip.quantize_heads(x, B, T, H, d, strides, ap.prescale if which < 2 else 1.0, ap.qparams[which], ap.grids[which],

@@ -378,8 +378,11 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
             att.forward = MethodType(cross_attn_forward, att)
             att.use_act_quant = False
 
-    def forward(self, x, context=None):
-        return self._forward(x, context)
+    def forward(self, x, context=None, out_plan=None):
+        """out_plan (engine-internal, optional): ConvPlan of the module that consumes this block's output and nothing
+        else (SpatialTransformer.proj_out).  When the block runs on the integer path and the shape allows it, the FF
+        output GEMM then returns that consumer's int8 input rows [B*T][ldx] instead of the fp32 tokens."""
+        return self._forward(x, context, out_plan)
 
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
         self.attn1.use_act_quant = act_quant
@@ -389,7 +392,7 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
     def _attn_inited(self, att):
         return _aq_ready(att.act_quantizer_q, att.act_quantizer_k, att.act_quantizer_v, att.act_quantizer_w)
 
-    def _forward(self, x, context=None):
+    def _forward(self, x, context=None, out_plan=None):
         if context is None and isinstance(x, (tuple, list)):
             x, context = x
         a1, a2 = self.attn1, self.attn2
@@ -397,7 +400,7 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
         glu = isinstance(self.ff.net[0], ldm_unet.GEGLU) or type(self.ff.net[0]).__name__ == "GEGLU"
         if (glu and a1.use_act_quant and a2.use_act_quant and _int_mode(*mods, self.ff.net[0].proj)
                 and self._attn_inited(a1) and self._attn_inited(a2)):
-            return self._forward_int(x, context)
+            return self._forward_int(x, context, out_plan)
         x = self.attn1(self.norm1(x)) + x
         x = self.attn2(self.norm2(x), context=context) + x
         return self.ff(self.norm3(x)) + x
@@ -436,7 +439,7 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
         o = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, h, d)
         return _linear_rows(out_lin, o, residual=rows)
 
-    def _forward_int(self, x, context):
+    def _forward_int(self, x, context, out_plan=None):
         B, T, C = x.shape
         rows = x.reshape(B * T, C)
         if rows.stride(1) != 1 or rows.stride(0) != C:
@@ -462,6 +465,9 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
             if not ff_out.act_quantizer.inited:
                 ff_out._init_act_quantizers(hcat[:, :Fdim] * F.gelu(hcat[:, Fdim:]))
             g8 = engine.geglu_quant(hcat, B * T, Fdim, ff_out.conv_plan())
+        if out_plan is not None and engine.rows_i8_fusable(ff_out.conv_plan(), out_plan, T):
+            # FF output + residual quantised for the consumer inside the GEMM epilogue: the fp32 tokens are never written
+            return engine.linear_to_rows_i8(ff_out.conv_plan(), g8, B, T, out_plan, residual=rows)
         rows = ff_out.forward_codes(g8, 1, 1, B * T, residual=rows)
         return rows.view(B, T, C)
 

@@ -228,7 +228,7 @@ def quantize_heads(x, B, T, H, d, strides, prescale, qparams, grid, transpose, o
     buf = torch.zeros(B * H, Tpad, dpad, dtype=torch.int64)
     buf[:, :T, :d] = q
     if not transpose:
-        out.copy_(buf.to(torch.int8))
+        out.view(buf.shape).copy_(buf.to(torch.int8))        # out may be viewed as plain rows [B*T][dpad] (H = 1)
         if rsum is not None:
             rsum.copy_(buf.sum(-1).to(torch.int32))
     else:

@@ -551,3 +551,26 @@ def test_conv_emits_groupnorm_statistics(cuda, B, C, H, Cout, k):
     torch.cuda.synchronize()
     diff = (a.int() - b.int()).abs()
     assert diff.max().item() <= 1 and (diff > 0).float().mean().item() <= 1e-3
+
+
+def test_linear_residual_to_int8_rows_matches_unfused(cuda):
+    """QD_EPI_HEADS_I8 with one full-width head + fp32 residual == fp32 Linear(+residual) followed by K1."""
+    from qdiff import engine
+    B, T, K, N = 2, 256, 1280, 320
+    g = torch.Generator().manual_seed(61)
+    x = torch.randn(B * T, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.03
+    bias = torch.randn(N, generator=g) * 0.1
+    res = torch.randn(B * T, N, generator=g).to(cuda)
+    dx, zx = R.uaq_init_scale(x, 8, False, False, "max")
+    plan = engine.build_conv_plan(engine.pack_module_weights(w.to(cuda), [_weight_quantizer(w, 4, True, g)], 0), [_aq(dx, zx)], 1, 1, 1, 0, bias.to(cuda))
+    xq = engine.quantize_rows(x.to(cuda), plan, 1, K, B * T, (0, 1, K))
+    y = engine.conv_forward(plan, xq, 1, 1, B * T, residual=res)
+    w2 = torch.randn(64, N, generator=g) * 0.05
+    dy, zy = R.uaq_init_scale(y.cpu(), 8, False, False, "max")
+    nxt = engine.build_conv_plan(engine.pack_module_weights(w2.to(cuda), [_weight_quantizer(w2, 4, True, g)], 0), [_aq(dy, zy)], 1, 1, 1, 0, None)
+    assert engine.rows_i8_fusable(plan, nxt, T)
+    want = engine.quantize_rows(y, nxt, 1, N, B * T, (0, 1, N))
+    got = engine.linear_to_rows_i8(plan, xq, B, T, nxt, residual=res)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
