@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 7
+#define QD_ABI_VERSION 8
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -250,6 +250,23 @@ int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt,
                float* out, int64_t ldo,
                int8_t* out8, int64_t ldo8, const float* oq_params, int oq_min, int oq_max, int oq_off,
                void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K7s/K8s  the two attention contractions as standalone batched integer GEMMs, for callers that use
+ *     QuantQKMatMul / QuantSMVMatMul on their own (qdiff/quant_block.py:114-160 with the softmax applied by the
+ *     caller in between, ldm openaimodel.py:384-406).  Operands are the same qd_quantize_heads layouts.
+ *     qd_bmm_qk_i8: out[bh][t][s] = cs * sum_d (q'-zq')(k'-zk')   prm = {cs, zq', zk'} (device floats);
+ *                   out rows have stride ldo, heads stride bstride (elements).
+ *     qd_bmm_pv_i8: w[bh][t][s] fp32 probabilities (row stride ldw, head stride wbstride) are quantised with
+ *                   u = clamp(rint(w/dw)+zpw, wmin, wmax) and contracted with v:
+ *                   out[bh][c][t] = dw*dv * sum_s (u-zpw)(v'-zv')   ("bct": row stride ldo, head stride obstride);
+ *                   vt / vsum = transpose=1 output of qd_quantize_heads; prm[3..6] = {dw, zpw, dw*dv, zv'}.
+ * ------------------------------------------------------------------------------------------ */
+int qd_bmm_qk_i8(const int8_t* q, const int8_t* k, int BH, int T, int S, int d, int Tpad, int Spad, int dpad,
+                 const float* prm, float* out, int64_t ldo, int64_t bstride, void* stream);
+int qd_bmm_pv_i8(const float* w, int64_t ldw, int64_t wbstride, const int8_t* vt, const int32_t* vsum,
+                 int BH, int T, int S, int d, int Spad, int dpad, const float* prm, int wbits, int wmin, int wmax,
+                 float* out, int64_t ldo, int64_t obstride, void* stream);
 
 #ifdef __cplusplus
 }

@@ -458,6 +458,61 @@ def attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d, out=None, out_plan=None
     return out
 
 
+# ------------------------------------------------------------------------------------------------
+# standalone attention matmuls (QuantQKMatMul / QuantSMVMatMul used on their own)
+# ------------------------------------------------------------------------------------------------
+def _softmax_grid(aq_w):
+    if aq_w.n_bits not in (8, 16) and aq_w.n_bits > 8:
+        raise hip.HipEngineError(f"softmax bit-width {aq_w.n_bits} unsupported (<=8 or 16)")
+    if aq_w.sym:
+        nl = 2 ** (aq_w.n_bits - 1) - 1
+        return (16 if aq_w.n_bits > 8 else 8), -nl - 1, nl
+    return (16 if aq_w.n_bits > 8 else 8), 0, 2 ** aq_w.n_bits - 1
+
+
+def qk_matmul_int(aq_q, aq_k, q, k, scale):
+    """QuantQKMatMul.forward on the integer engine (reference quant_block.py:123-134): q [BH][c][T], k [BH][c][S]
+    fp32 ("bct"); q*scale and k*scale are quantised, the contraction is exact int32, the T x S scores are returned
+    as fp32 [BH][T][S] (the API materialises them: the caller applies the softmax)."""
+    BH, c, T = q.shape
+    S = k.shape[2]
+    dev = q.device
+    gq, gk = act_grid(aq_q.n_bits, aq_q.sym), act_grid(aq_k.n_bits, aq_k.sym)
+    pq, pk = qparams_of(aq_q, dev), qparams_of(aq_k, dev)
+    prm = torch.zeros(8, dtype=torch.float32, device=dev)
+    prm[0], prm[1], prm[2] = pq[0] * pk[0], pq[1] - gq.off, pk[1] - gk.off
+    Tpad, Spad, dpad = pad32(T), pad32(S), pad32(c)
+    q8 = torch.empty((BH, Tpad, dpad), dtype=torch.int8, device=dev)
+    k8 = torch.empty((BH, Spad, dpad), dtype=torch.int8, device=dev)
+    hip.quantize_heads(q, BH, T, 1, c, (q.stride(0), q.stride(2), 0, q.stride(1)), float(scale), pq, gq, False, q8, None, Tpad, dpad)
+    hip.quantize_heads(k, BH, S, 1, c, (k.stride(0), k.stride(2), 0, k.stride(1)), float(scale), pk, gk, False, k8, None, Spad, dpad)
+    out = torch.empty((BH, T, S), dtype=torch.float32, device=dev)
+    hip.bmm_qk_i8(q8, k8, BH, T, S, c, Tpad, Spad, dpad, prm, out)
+    return out
+
+
+def smv_matmul_int(aq_w, aq_v, weight, v):
+    """QuantSMVMatMul.forward on the integer engine (reference quant_block.py:152-157): weight [BH][T][S] fp32
+    probabilities, v [BH][c][S]; returns [BH][c][T] fp32."""
+    BH, T, S = weight.shape
+    c = v.shape[1]
+    dev = weight.device
+    gv = act_grid(aq_v.n_bits, aq_v.sym)
+    pv, pw = qparams_of(aq_v, dev), qparams_of(aq_w, dev)
+    wbits, wmin, wmax = _softmax_grid(aq_w)
+    prm = torch.zeros(8, dtype=torch.float32, device=dev)
+    prm[3], prm[4], prm[5], prm[6] = pw[0], pw[1], pw[0] * pv[0], pv[1] - gv.off
+    Spad, dpad = pad32(S), pad32(c)
+    v8 = torch.empty((BH, dpad, Spad), dtype=torch.int8, device=dev)
+    vsum = torch.empty((BH, dpad), dtype=torch.int32, device=dev)
+    hip.quantize_heads(v, BH, S, 1, c, (v.stride(0), v.stride(2), 0, v.stride(1)), 1.0, pv, gv, True, v8, vsum, Spad, dpad)
+    if weight.stride(2) != 1:
+        weight = weight.contiguous()
+    out = torch.empty((BH, c, T), dtype=torch.float32, device=dev)
+    hip.bmm_pv_i8(weight.float(), v8, vsum, BH, T, S, c, Spad, dpad, prm, wbits, wmin, wmax, out)
+    return out
+
+
 def sinusoid(timesteps, dim, flavour):
     """Timestep sinusoid table (K6 front half; tiny, kept in torch).  flavour 'ldm': cos|sin with
     /half (ldm util.py:151-171); 'ddim': sin|cos with /(half-1) (ddim diffusion.py:6-24)."""

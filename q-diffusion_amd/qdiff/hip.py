@@ -52,7 +52,7 @@ EPI_LINEAR, EPI_GEGLU_I8, EPI_HEADS_I8, EPI_HEADS_T_I8 = 0, 1, 2, 3
 EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_quantize_act", "qd_pack_weights", "qd_pack_weights_t4",
            "qd_conv2d_i8", "qd_conv2d_i8_splitk_ws_bytes",
            "qd_conv2d_i8_acc", "qd_groupnorm_ws_bytes", "qd_groupnorm_silu_quant", "qd_layernorm_quant",
-           "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8"]
+           "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8", "qd_bmm_qk_i8", "qd_bmm_pv_i8"]
 
 _lib = None
 
@@ -87,7 +87,9 @@ def load():
                                       vp, vp, i32, i32, vp]
     lib.qd_attn_i8.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp,
                                i64, vp, i64, vp, i32, i32, i32, vp]
-    if lib.qd_abi_version() != 7:
+    lib.qd_bmm_qk_i8.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i64, i64, vp]
+    lib.qd_bmm_pv_i8.argtypes = [vp, i64, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i64, i64, vp]
+    if lib.qd_abi_version() != 8:
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -285,3 +287,15 @@ def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, 
                              dpad, _ptr(prm), wbits, wmin, wmax, 1 if q_asym else 0, _ptr(out), ldo,
                              _ptr(out8), out8.stride(0) if out8 is not None else 0, _ptr(oq_params),
                              g.qmin if g else 0, g.qmax if g else 0, g.off if g else 0, _stream()), "qd_attn_i8")
+
+
+def bmm_qk_i8(q8, k8, BH, T, S, d, Tpad, Spad, dpad, prm, out):
+    """out [BH][T][S] fp32 = cs * sum_d (q'-zq')(k'-zk'); prm = device floats {cs, zq', zk'}."""
+    _check(load().qd_bmm_qk_i8(_ptr(q8), _ptr(k8), BH, T, S, d, Tpad, Spad, dpad, _ptr(prm), _ptr(out), out.stride(1),
+                               out.stride(0), _stream()), "qd_bmm_qk_i8")
+
+
+def bmm_pv_i8(w, v8t, vsum, BH, T, S, d, Spad, dpad, prm, wbits, wmin, wmax, out):
+    """w [BH][T][S] fp32 probabilities -> quantised (prm[3..6]) -> out [BH][d][T] fp32."""
+    _check(load().qd_bmm_pv_i8(_ptr(w), w.stride(1), w.stride(0), _ptr(v8t), _ptr(vsum), BH, T, S, d, Spad, dpad, _ptr(prm),
+                               wbits, wmin, wmax, _ptr(out), out.stride(1), out.stride(0), _stream()), "qd_bmm_pv_i8")

@@ -232,6 +232,12 @@ class QuantQKMatMul(BaseQuantBlock):
         self.act_quantizer_k = UniformAffineQuantizer(**act_quant_params)
 
     def forward(self, q, k):
+        if (self.use_act_quant and not torch.is_grad_enabled() and q.dim() == 3 and q.shape[1] % 4 == 0
+                and _aq_ready(self.act_quantizer_q, self.act_quantizer_k) and not self.act_quantizer_q.running_stat
+                and self.act_quantizer_q.n_bits <= 8 and self.act_quantizer_k.n_bits <= 8):
+            # standalone use (this module called outside the fused QuantAttentionBlock path): integer engine,
+            # exact int32 contraction, the T x S score matrix is materialised as the API requires
+            return engine.qk_matmul_int(self.act_quantizer_q, self.act_quantizer_k, q.float(), k.float(), float(self.scale))
         if self.use_act_quant:
             q, k = self.act_quantizer_q(q * self.scale), self.act_quantizer_k(k * self.scale)
         else:
@@ -254,6 +260,10 @@ class QuantSMVMatMul(BaseQuantBlock):
         self.act_quantizer_w = UniformAffineQuantizer(**params_w)
 
     def forward(self, weight, v):
+        if (self.use_act_quant and not torch.is_grad_enabled() and v.dim() == 3 and v.shape[1] % 4 == 0
+                and _aq_ready(self.act_quantizer_v, self.act_quantizer_w) and not self.act_quantizer_v.running_stat
+                and not self.act_quantizer_w.running_stat and self.act_quantizer_v.n_bits <= 8):
+            return engine.smv_matmul_int(self.act_quantizer_w, self.act_quantizer_v, weight, v.float())
         if self.use_act_quant:
             weight, v = self.act_quantizer_w(weight), self.act_quantizer_v(v)
         return th.einsum("bts,bcs->bct", weight, v)

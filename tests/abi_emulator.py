@@ -257,6 +257,22 @@ def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, 
         out[:, :H * d] = rows
 
 
+def bmm_qk_i8(q8, k8, BH, T, S, d, Tpad, Spad, dpad, prm, out):
+    cs, zq, zk = float(prm[0]), int(prm[1]), int(prm[2])
+    qi = q8.to(torch.int64)[:, :T, :d] - zq
+    ki = k8.to(torch.int64)[:, :S, :d] - zk
+    out.copy_(torch.einsum("bid,bjd->bij", qi.double(), ki.double()).float() * cs)
+
+
+def bmm_pv_i8(w, v8t, vsum, BH, T, S, d, Spad, dpad, prm, wbits, wmin, wmax, out):
+    dw, zpw, osc, zv = (float(prm[i]) for i in range(3, 7))
+    inv = torch.empty(Spad, dtype=torch.long)
+    inv[_perm_index(Spad)] = torch.arange(Spad)
+    vi = v8t.to(torch.int64)[:, :, inv][:, :d, :S] - int(zv)                    # [BH, d, S]
+    u = torch.clamp(torch.round(w.float() / dw) + zpw, wmin, wmax) - zpw
+    out.copy_(torch.einsum("bts,bcs->bct", u.double(), vi.double()).float() * osc)
+
+
 def splitk_ws_bytes(c):
     """The emulation never splits K (the schedule does not change results)."""
     return 0
@@ -266,5 +282,5 @@ def install(monkeypatch):
     """Replace qdiff.hip's device entry points by the emulation (CPU tensors only)."""
     from qdiff import hip
     for name in ("quantize_act", "pack_weights", "pack_weights_t4", "conv2d_i8", "groupnorm_ws_bytes", "groupnorm_silu_quant",
-                 "layernorm_quant", "geglu_quant", "quantize_heads", "attn_i8", "splitk_ws_bytes"):
+                 "layernorm_quant", "geglu_quant", "quantize_heads", "attn_i8", "splitk_ws_bytes", "bmm_qk_i8", "bmm_pv_i8"):
         monkeypatch.setattr(hip, name, globals()[name])

@@ -574,3 +574,45 @@ def test_linear_residual_to_int8_rows_matches_unfused(cuda):
     got = engine.linear_to_rows_i8(plan, xq, B, T, nxt, residual=res)
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+
+
+
+def test_standalone_qk_smv_matmuls_vs_reference_golden(cuda):
+    """QuantQKMatMul / QuantSMVMatMul on their own through qd_bmm_qk_i8 / qd_bmm_pv_i8 vs the real reference's
+    outputs (tests/golden/ops.pt, ldm_qk_smv): exact integers and one fp32 multiply -> 2e-6 of range."""
+    from golden_util import load_fixture
+    from test_host_logic import _standalone_matmul_modules
+    c = [a for a in load_fixture("ops.pt")["attention"] if a["kind"] == "ldm_qk_smv"][0]
+    qk, smv = _standalone_matmul_modules(c)
+    qk, smv = qk.to(cuda), smv.to(cuda)
+    with torch.no_grad():
+        w = qk(c["q"].to(cuda), c["k"].to(cuda)).cpu()
+        a = smv(torch.softmax(c["weight"].float(), dim=-1).to(cuda), c["v"].to(cuda)).cpu()
+    assert (w - c["weight"]).abs().max() <= 2e-6 * c["weight"].abs().max()
+    assert (a - c["out"]).abs().max() <= 2e-6 * c["out"].abs().max()
+
+
+@pytest.mark.parametrize("smb", [8, 16])
+def test_standalone_bmm_kernels_asymmetric_ragged(cuda, smb):
+    """Asymmetric 8-bit q/k/v, 8/16-bit probabilities, ragged T/S, d=40: vs the fp64 evaluation of the reference formula."""
+    from qdiff import engine
+    BH, d, T, S = 6, 40, 100, 77
+    g = torch.Generator().manual_seed(71)
+    q, k, v = (torch.randn(BH, d, L, generator=g) for L in (T, S, S))
+    scale = d ** -0.25
+
+    def mk(t, n_bits=8, always_zero=False):
+        dd, zz = R.uaq_init_scale(t, n_bits, False, False, "max", always_zero)
+        return NS(delta=dd, zero_point=zz, n_bits=n_bits, sym=False, inited=True, running_stat=False)
+    aq_q, aq_k, aq_v = mk(q * scale), mk(k * scale), mk(v)
+    # codes with the reference's fp32 arithmetic (IEEE division, round-half-even), contraction in fp64
+    fq = lambda t, a: (torch.clamp(torch.round(t.float() / a.delta.float()) + float(a.zero_point), 0, 2 ** a.n_bits - 1)
+                       - float(a.zero_point)).double() * float(a.delta)
+    want_w = torch.einsum("bct,bcs->bts", fq(q * torch.tensor(scale), aq_q), fq(k * torch.tensor(scale), aq_k))
+    got_w = engine.qk_matmul_int(aq_q, aq_k, q.to(cuda), k.to(cuda), scale).cpu()
+    assert (got_w.double() - want_w).abs().max() <= 2e-6 * want_w.abs().max()
+    p = torch.softmax(got_w, dim=-1)
+    aq_w = mk(p, smb, always_zero=True)
+    want_a = torch.einsum("bts,bcs->bct", fq(p, aq_w), fq(v, aq_v))
+    got_a = engine.smv_matmul_int(aq_w, aq_v, p.to(cuda), v.to(cuda)).cpu()
+    assert (got_a.double() - want_a).abs().max() <= 2e-6 * want_a.abs().max()

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     from qdiff import hip
     assert sorted(hip.EXPORTS) == declared
     lib.qd_abi_version.restype = ctypes.c_int
-    assert lib.qd_abi_version() == 7
+    assert lib.qd_abi_version() == 8
     assert lib.qd_device_ok() in (0, 1)                  # no compute calls without a GPU
 
 
@@ -233,3 +233,34 @@ def test_packing_mode_selection(emu):
     assert engine.pack_module_weights(w, [mk(8, 131)], 0).mode == 8        # u8 codes: W-128 + row-sum correction
     assert engine.pack_module_weights(w, [mk(6, 30)], 0).mode == 0         # W - zp fits int8 directly
     assert engine.pack_module_weights(w, [mk(4, 200)], 0).mode == 8        # degenerate zero point: general path
+
+
+
+def _standalone_matmul_modules(c):
+    """QuantQKMatMul / QuantSMVMatMul with the quantiser state of the reference's golden case."""
+    import qdiff
+    from qdiff.quant_block import QuantQKMatMul, QuantSMVMatMul
+    aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True, symmetric=True)
+    qk, smv = QuantQKMatMul(aq), QuantSMVMatMul(aq, sm_abit=8)
+    qk.scale = c["scale"]
+    for mod, table in ((qk, c["qq"]), (smv, c["qs"])):
+        for n, (d, z) in table.items():
+            qz = getattr(mod, n)
+            qz.delta = torch.nn.Parameter(d.clone()) if torch.is_tensor(d) else d
+            qz.zero_point = z
+            qz.inited = True
+    qk.use_act_quant = smv.use_act_quant = True
+    return qk, smv
+
+
+def test_standalone_qk_smv_matmuls_on_emulator(emu):
+    """The two attention matmul modules used on their own (reference quant_block.py:114-160) take the integer
+    engine too; vs the real reference's outputs (ops.pt 'attention' / ldm_qk_smv), 2e-5 of range."""
+    ops = load_fixture("ops.pt")
+    c = [a for a in ops["attention"] if a["kind"] == "ldm_qk_smv"][0]
+    qk, smv = _standalone_matmul_modules(c)
+    with torch.no_grad():
+        w = qk(c["q"], c["k"])
+        assert (w - c["weight"]).abs().max() <= 2e-5 * c["weight"].abs().max()
+        a = smv(torch.softmax(c["weight"].float(), dim=-1), c["v"])
+    assert (a - c["out"]).abs().max() <= 2e-5 * c["out"].abs().max()
