@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 8
+#define QD_ABI_VERSION 9
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -166,6 +166,13 @@ int64_t qd_conv2d_i8_splitk_ws_bytes(const qd_conv_desc* d);
  *     The stored operand is the RAW code W (0..15); its zero point is restored in the epilogue
  *     through qd_conv_seg.zw[n] = zw[n] and activation row sums.  wsum[n] += sum W over the slice. */
 int qd_pack_weights_t4(const float* w, const float* alpha, const float* delta, const float* zp,
+                       int Cout, int Cin_total, int taps, int c0, int clen, int clen_pad, int n_levels,
+                       uint8_t* wt, int kstep0, int ntiles, int32_t* wsum, void* stream);
+
+/* K2c  the same tile order for 8-bit weights: wt[kstep][ntile][2 KB], each block [ksub(2)][half(2)][n%32][16 B] =
+ *     the 16 stored bytes W-128 of row n for K = ksub*32 + half*16 + 0..15 (qd_conv_desc.wbits = 8, w_tiled = 1,
+ *     qd_conv_seg.zw[n] = zw[n]-128).  wsum[n] += sum (W-128) over the slice. */
+int qd_pack_weights_t8(const float* w, const float* alpha, const float* delta, const float* zp,
                        int Cout, int Cin_total, int taps, int c0, int clen, int clen_pad, int n_levels,
                        uint8_t* wt, int kstep0, int ntiles, int32_t* wsum, void* stream);
 

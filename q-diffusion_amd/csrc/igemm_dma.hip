@@ -104,13 +104,17 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(qd_lds_ptr)(p);
 }
 
-template <int MT, int NT, bool SPLIT, int OUT>
+// WB = weight bits of the tile-ordered operand: 4 (raw nibbles, 1 KB per K-step x 32 channels, qd_pack_weights_t4) or
+// 8 (s8 bytes W-128, 2 KB, qd_pack_weights_t8); everything but the B tile size and the fragment read is shared.
+template <int MT, int NT, bool SPLIT, int OUT, int WB>
 __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const ConvD p) {
+    static_assert(WB == 4 || WB == 8, "weight bits");
     constexpr int BM = 128 * MT, BN = 32 * NT;
-    constexpr int A_BYTES = BM * 64, B_BYTES = NT * 1024;
+    constexpr int TB = 256 * WB;                  // bytes of one (K-step, 32-channel) weight tile
+    constexpr int A_BYTES = BM * 64, B_BYTES = NT * TB;
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int NA = 2 * MT;                    // A DMA instructions per wave per stage (16 rows each)
-    constexpr int NB = (NT * 16 + 63) / 64;       // B DMA instructions per wave per stage (NT*256 B per wave)
+    constexpr int NB = (NT * TB / 64 + 63) / 64;  // B DMA instructions per wave per stage (NT*TB/4 bytes per wave)
     constexpr int PER = NA + NB;
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE + 2 * BM * 4 + 4 * BN * 4];
@@ -162,12 +166,12 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
     int lrr = ltap / p.kw, lq = ltap - lrr * p.kw;
     const int8_t* a_cur[NA];                      // source of the NEXT K-step for DMA instruction i
     int           a_inc[NA];                      // 64 for real pixels, 0 for fill / zero sources
-    const uint8_t* b_cur = p.wt + ((long)(p.seg[0].kstep0 + it_begin) * p.ntiles + (long)nb * NT) * 1024 + wave * (NT * 256) + lane * 16;
-    const long b_inc = (long)p.ntiles * 1024;
+    const uint8_t* b_cur = p.wt + ((long)(p.seg[0].kstep0 + it_begin) * p.ntiles + (long)nb * NT) * TB + wave * (NT * TB / 4) + lane * 16;
+    const long b_inc = (long)p.ntiles * TB;
     const int8_t* zero16 = reinterpret_cast<const int8_t*>(qd_zero16);
     bool b_ok[NB];                                // the last N-block may cover n-tiles that do not exist
 #pragma unroll
-    for (int r = 0; r < NB; ++r) b_ok[r] = nb * NT + (wave * (NT * 256) + r * 1024 + lane * 16) / 1024 < p.ntiles;
+    for (int r = 0; r < NB; ++r) b_ok[r] = nb * NT + (wave * (NT * TB / 4) + r * 1024 + lane * 16) / TB < p.ntiles;
 
     auto set_tap = [&]() __attribute__((always_inline)) {
         const SegD& sg = p.seg[ls];
@@ -202,9 +206,9 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
             const int r = d - NA;
 #pragma unroll
             for (int rr = 0; rr < NB; ++rr)
-                if (rr == r && rr * 64 + lane < NT * 16)
+                if (rr == r && rr * 64 + lane < NT * TB / 64)
                     glds16(b_ok[rr] ? (const void*)(b_cur + rr * 1024) : (const void*)zero16,
-                           stage_base + A_BYTES + wave * (NT * 256) + rr * 1024);
+                           stage_base + A_BYTES + wave * (NT * TB / 4) + rr * 1024);
         }
     };
     auto advance = [&]() __attribute__((always_inline)) {
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
             const int row = wave * (32 * MT) + i * 32 + frow;
             a_off[i][ks] = row * 64 + (((ks * 2 + fhalf) ^ ((row >> 2) & 3)) * 16);
         }
-    const int b_off = (fhalf * 32 + frow) * 8;   // + ks*512 + j*1024
+    const int b_off = (fhalf * 32 + frow) * (WB * 2);   // + ks*(TB/2) + j*TB
 
     float pr_scale = 0.f, pr_bias = 0.f;
     int   pr_zc = 0, pr_zw = 0;
@@ -338,9 +342,14 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const uint2 pk = *reinterpret_cast<const uint2*>(cB + b_off + ks * 512 + j * 1024);
-                const v4i bf = {(int)(pk.x & 0x0F0F0F0Fu), (int)((pk.x >> 4) & 0x0F0F0F0Fu),
-                                (int)(pk.y & 0x0F0F0F0Fu), (int)((pk.y >> 4) & 0x0F0F0F0Fu)};
+                v4i bf;
+                if constexpr (WB == 4) {
+                    const uint2 pk = *reinterpret_cast<const uint2*>(cB + b_off + ks * (TB / 2) + j * TB);
+                    bf = v4i{(int)(pk.x & 0x0F0F0F0Fu), (int)((pk.x >> 4) & 0x0F0F0F0Fu),
+                             (int)(pk.y & 0x0F0F0F0Fu), (int)((pk.y >> 4) & 0x0F0F0F0Fu)};
+                } else {
+                    bf = *reinterpret_cast<const v4i*>(cB + b_off + ks * (TB / 2) + j * TB);
+                }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
                     acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf, acc[i][j], 0, 0, 0);
@@ -672,7 +681,54 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const int32_t* __r
     }
 }
 
-template <int MT, int NT>
+// tile-ordered s8 packer: thread = one 16-byte unit (row n, 16 consecutive K), stored byte = W - 128
+__global__ __launch_bounds__(256) void pack_t8_kernel(const float* __restrict__ w, const float* __restrict__ alpha,
+                                                      const float* __restrict__ delta, const float* __restrict__ zp,
+                                                      int Cout, int Cin_total, int taps, int c0, int clen,
+                                                      int n_levels, uint8_t* __restrict__ wt, int kstep0, int ntiles,
+                                                      int nsteps_tap, int32_t* __restrict__ wsum) {
+    long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)taps * nsteps_tap * ntiles * 128;
+    if (gid >= total) return;
+    const int nn = (int)(gid & 31);
+    const int kh4 = (int)((gid >> 5) & 3);
+    long rest = gid >> 7;
+    const int jt = (int)(rest % ntiles);
+    rest /= ntiles;
+    const int cs = (int)(rest % nsteps_tap);
+    const int t = (int)(rest / nsteps_tap);
+    const int n = jt * 32 + nn;
+    const int cbase = cs * 64 + kh4 * 16;
+    int sum = 0;
+    float d = 1.f, z = 0.f;
+    if (n < Cout) { d = delta[n]; z = zp[n]; }
+    v4i pk;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        unsigned word = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = cbase + g * 4 + e;
+            int stored = 0;
+            if (n < Cout && c < clen) {
+                const float wv = w[((long)n * Cin_total + c0 + c) * taps + t];
+                float q;
+                if (alpha) q = floorf(wv / d) + (alpha[((long)n * clen + c) * taps + t] >= 0.f ? 1.f : 0.f);
+                else q = rintf(wv / d);
+                q = fminf(fmaxf(q + z, 0.f), (float)(n_levels - 1));
+                stored = (int)q - 128;
+                sum += stored;
+            }
+            word |= (unsigned)(stored & 0xff) << (8 * e);
+        }
+        pk[g] = (int)word;
+    }
+    const long kstep = kstep0 + (long)t * nsteps_tap + cs;
+    *reinterpret_cast<v4i*>(wt + (kstep * ntiles + jt) * 2048 + (kh4 * 32 + nn) * 16) = pk;
+    if (wsum && sum != 0) atomicAdd(&wsum[n], sum);
+}
+
+template <int MT, int NT, int WB = 4>
 int dispatch(ConvD& k, bool split, int out, hipStream_t st, int nsplit = 1) {
     constexpr int BM = 128 * MT, BN = 32 * NT;
     k.nblk_m = (k.M + BM - 1) / BM;
@@ -680,12 +736,13 @@ int dispatch(ConvD& k, bool split, int out, hipStream_t st, int nsplit = 1) {
     dim3 grid(k.nblk_m * k.nblk_n, nsplit), block(256);
 #define QD_CASE(SP, O)                                                                      \
     if (split == SP && out == O) {                                                          \
-        hipLaunchKernelGGL((igemm_dma_kernel<MT, NT, SP, O>), grid, block, 0, st, k);       \
+        hipLaunchKernelGGL((igemm_dma_kernel<MT, NT, SP, O, WB>), grid, block, 0, st, k);   \
         return 0;                                                                           \
     }
-    QD_CASE(false, O_F32) QD_CASE(false, O_F16) QD_CASE(false, O_I32) QD_CASE(false, O_HROWS) QD_CASE(false, O_HTR)
+    QD_CASE(false, O_F32) QD_CASE(false, O_F16) QD_CASE(false, O_I32)
+    if constexpr (WB == 4) { QD_CASE(false, O_HROWS) QD_CASE(false, O_HTR) }
     if constexpr (MT == 1) { QD_CASE(true, O_F32) QD_CASE(true, O_F16) QD_CASE(false, O_PART) }
-    if constexpr (NT == 4) { QD_CASE(false, O_GEGLU) }
+    if constexpr (NT == 4 && WB == 4) { QD_CASE(false, O_GEGLU) }
 #undef QD_CASE
     qd_set_error("qd_conv2d_i8 (tiled): unsupported variant split=%d out=%d MT=%d", (int)split, out, MT);
     return 1;
@@ -700,7 +757,7 @@ int choose_splitk(const qd_conv_desc* d, int* it_per) {
     *it_per = 0;
     if (!d->w_tiled || d->nseg != 1 || d->epilogue != QD_EPI_LINEAR) return 1;
     const long M = (long)d->B * d->Ho * d->Wo;
-    const int  N = d->Cout, bn = 32 * nt_for(N);
+    const int  N = d->Cout, bn = 32 * (d->wbits == 8 ? (N > 64 ? 4 : 2) : nt_for(N));
     const long blocks0 = ((M + 127) / 128) * ((N + bn - 1) / bn);
     const int  total = d->kh * d->kw * ((d->seg[0].clen + 63) / 64);
     if (blocks0 > 256) return 1;
@@ -724,7 +781,9 @@ extern "C" int64_t qd_conv2d_i8_splitk_ws_bytes(const qd_conv_desc* d) {
 }
 
 int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
-    QD_REQUIRE(d->wbits == 4, "tiled weights are int4 only");
+    QD_REQUIRE(d->wbits == 4 || d->wbits == 8, "tiled weights are int4 or int8");
+    const bool w8 = d->wbits == 8;
+    QD_REQUIRE(!w8 || d->epilogue == QD_EPI_LINEAR, "qd_conv2d_i8 (tiled): the fused GEGLU / head-layout epilogues are int4-weight only");
     QD_REQUIRE(d->ldx % 16 == 0 && qd_aligned(d->x, 16) && qd_aligned(d->w, 16), "qd_conv2d_i8 (tiled): x/w must be 16-byte aligned, ldx %% 16 == 0");
     ConvD k{};
     k.x = d->x; k.wt = d->w; k.out = d->out; k.iout = iout;
@@ -786,7 +845,8 @@ int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
         QD_REQUIRE(qd_aligned(d->splitk_ws, 16), "qd_conv2d_i8 (tiled): splitk_ws must be 16-byte aligned");
         k.iout = reinterpret_cast<int32_t*>(d->splitk_ws);
         k.it_per = it_per;
-        switch (nt_for(N)) {
+        if (w8) rc = N > 64 ? dispatch<1, 4, 8>(k, false, O_PART, st, nsplit) : dispatch<1, 2, 8>(k, false, O_PART, st, nsplit);
+        else switch (nt_for(N)) {
             case 5:  rc = dispatch<1, 5>(k, false, O_PART, st, nsplit); break;
             case 7:  rc = dispatch<1, 7>(k, false, O_PART, st, nsplit); break;
             case 4:  rc = dispatch<1, 4>(k, false, O_PART, st, nsplit); break;
@@ -807,7 +867,14 @@ int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
     }
     static const int force_mt = getenv("QD_TILE_MT") ? atoi(getenv("QD_TILE_MT")) : 0;       // tuning knob: 1 / 2, 0 = heuristic
     static const int force_gmt = getenv("QD_GEGLU_MT") ? atoi(getenv("QD_GEGLU_MT")) : 0;
-    if (geglu) {
+    if (w8) {                                      // int8 weights (CIFAR W8A8): 128-wide N tiles
+        if (N > 64) {
+            if (!split && blocks(256, 128) >= 512) rc = dispatch<2, 4, 8>(k, split, out, st);
+            else rc = dispatch<1, 4, 8>(k, split, out, st);
+        } else {
+            rc = dispatch<1, 2, 8>(k, split, out, st);
+        }
+    } else if (geglu) {
         // 128-row tiles by default: the erf/quantise epilogue is VALU-heavy and overlaps better with other
         // blocks' main loops at 4 waves per SIMD (measured -0.24 ms per SD evaluation vs 256-row tiles)
         if (force_gmt == 2) rc = dispatch<2, 4>(k, split, out, st);
@@ -845,5 +912,21 @@ extern "C" int qd_pack_weights_t4(const float* w, const float* alpha, const floa
     hipLaunchKernelGGL(pack_t4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        w, alpha, delta, zp, Cout, Cin_total, taps, c0, clen, clen_pad, n_levels, wt, kstep0, ntiles, nsteps_tap, wsum);
     QD_LAUNCH_CHECK("qd_pack_weights_t4");
+    return 0;
+}
+
+extern "C" int qd_pack_weights_t8(const float* w, const float* alpha, const float* delta, const float* zp, int Cout,
+                                  int Cin_total, int taps, int c0, int clen, int clen_pad, int n_levels, uint8_t* wt,
+                                  int kstep0, int ntiles, int32_t* wsum, void* stream) {
+    QD_REQUIRE(w && delta && zp && wt, "qd_pack_weights_t8: null pointer");
+    QD_REQUIRE(Cout > 0 && taps > 0 && clen > 0 && c0 >= 0 && c0 + clen <= Cin_total, "qd_pack_weights_t8: bad shape");
+    QD_REQUIRE(clen_pad % 16 == 0 && clen_pad >= clen, "qd_pack_weights_t8: clen_pad must be a multiple of 16");
+    QD_REQUIRE(n_levels >= 2 && n_levels <= 256, "qd_pack_weights_t8: n_levels %d does not fit a byte", n_levels);
+    QD_REQUIRE(ntiles == (Cout + 31) / 32 && qd_aligned(wt, 16), "qd_pack_weights_t8: bad tile layout");
+    const int nsteps_tap = (clen_pad + 63) / 64;
+    const long total = (long)taps * nsteps_tap * ntiles * 128;
+    hipLaunchKernelGGL(pack_t8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       w, alpha, delta, zp, Cout, Cin_total, taps, c0, clen, n_levels, wt, kstep0, ntiles, nsteps_tap, wsum);
+    QD_LAUNCH_CHECK("qd_pack_weights_t8");
     return 0;
 }

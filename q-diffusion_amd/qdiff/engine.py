@@ -19,6 +19,8 @@ from .hip import Grid, pad16, pad32
 # int4 weight layout: "tiled" (MFMA-tile order, LDS-DMA kernel csrc/igemm_dma.hip) or "rows"
 # (row-major nibbles, register-staged kernel csrc/igemm_i8.hip; kept for A/B measurements)
 W4_LAYOUT = os.environ.get("QDIFF_W4_LAYOUT", "tiled")
+# 8-bit weights: "tiled" = the same LDS-DMA kernel with 2-KB s8 tiles (qd_pack_weights_t8), "rows" = first-generation kernel
+W8_LAYOUT = os.environ.get("QDIFF_W8_LAYOUT", "tiled")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -111,6 +113,9 @@ def pack_module_weights(weight, quantizers, split, row_perm=None):
         mode = 8
     pk = WeightPack()
     pk.Cout, pk.taps, pk.Cin = Cout, taps, Cin
+    pk.tiled = (mode == 4 and W4_LAYOUT == "tiled") or (mode != 4 and W8_LAYOUT == "tiled")
+    if pk.tiled and mode != 4:
+        mode = 8                                   # the tile order always stores W-128 (zw-128 goes to the epilogue)
     pk.mode, pk.wbits = mode, (4 if mode == 4 else 8)
     kofs, segs = 0, []
     for (c0, c1) in bounds:
@@ -118,14 +123,13 @@ def pack_module_weights(weight, quantizers, split, row_perm=None):
         segs.append(dict(c0w=c0, clen=clen, clen_pad=pad16(clen), kofs=kofs))
         kofs += pad16(clen)
     pk.ldk = max(pad32(kofs), 32)
-    pk.tiled = mode == 4 and W4_LAYOUT == "tiled"
     if pk.tiled:
         # MFMA-tile-ordered nibbles for the LDS-DMA kernel: [kstep][n/32][1 KB], kstep = (segment, tap, 64-ch step)
         ntiles, kstep = (Cout + 31) // 32, 0
         for sg in segs:
             sg["kstep0"] = kstep
             kstep += taps * ((sg["clen_pad"] + 63) // 64)
-        pk.wq = torch.zeros(kstep * ntiles * 1024, dtype=torch.uint8, device=dev)
+        pk.wq = torch.zeros(kstep * ntiles * (1024 if mode == 4 else 2048), dtype=torch.uint8, device=dev)
     else:
         nbytes = Cout * taps * pk.ldk // (2 if mode == 4 else 1)
         pk.wq = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
@@ -143,8 +147,9 @@ def pack_module_weights(weight, quantizers, split, row_perm=None):
             alpha = alpha.index_select(0, row_perm).contiguous() if alpha is not None else None
         wsum = torch.zeros(Cout, dtype=torch.int32, device=dev)
         if pk.tiled:
-            hip.pack_weights_t4(w, alpha, delta, z.contiguous(), Cout, Cin, taps, sg["c0w"], sg["clen"], levels,
-                                pk.wq, sg["kstep0"], (Cout + 31) // 32, wsum)
+            (hip.pack_weights_t4 if mode == 4 else hip.pack_weights_t8)(
+                w, alpha, delta, z.contiguous(), Cout, Cin, taps, sg["c0w"], sg["clen"], levels,
+                pk.wq, sg["kstep0"], (Cout + 31) // 32, wsum)
         else:
             hip.pack_weights(w, alpha, delta, z.contiguous(), Cout, Cin, taps, sg["c0w"], sg["clen"], levels, mode,
                              pk.wq, pk.ldk, sg["kofs"], wsum)
@@ -152,6 +157,7 @@ def pack_module_weights(weight, quantizers, split, row_perm=None):
         sg["delta_w"] = delta
         # epilogue-side weight zero point: stored operand is W-128 (mode 8) or the raw nibble W (tiled int4)
         sg["zw"] = (z.to(torch.int32) - 128).contiguous() if mode == 8 else (z.to(torch.int32).contiguous() if pk.tiled else None)
+        # (tiled int4: raw nibbles, zw = zp; tiled / row-major int8: W-128, zw = zp-128; row-major int4 / direct s8: none)
         sg["wzp"] = z.to(torch.int8).contiguous() if (mode == 4 and not pk.tiled) else None
     pk.segs = segs
     pk.row_perm = row_perm
@@ -247,7 +253,7 @@ def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, re
 def conv_forward_geglu(plan, xq, M, next_plan):
     """GEGLU projection (plan packed with geglu_row_perm) with the fused value*gelu(gate) -> quantise
     epilogue: returns the int8 rows [M][next_plan.ldx] that `next_plan` (the FF output Linear) consumes."""
-    if not plan.pack.tiled or plan.pack.row_perm is None or len(plan.segs) != 1 or len(next_plan.segs) != 1:
+    if not plan.pack.tiled or plan.pack.wbits != 4 or plan.pack.row_perm is None or len(plan.segs) != 1 or len(next_plan.segs) != 1:
         raise hip.HipEngineError("fused GEGLU epilogue needs a tile-ordered int4 projection packed with geglu_row_perm")
     out = torch.empty((M, next_plan.ldx), dtype=torch.int8, device=xq.device)
     call = hip.ConvCall(x=xq, w=plan.pack.wq, out=out, bias=plan.bias, ldx=plan.ldx, ldk=plan.pack.ldk, ldo=next_plan.ldx,
@@ -394,7 +400,7 @@ def head_buffers(device, BH, Tpad, Spad, dpad):
 
 def heads_fusable(plan, T, H):
     """The projection `plan` can write its output directly as attention operand bytes (QD_EPI_HEADS_*)."""
-    return bool(plan.pack.tiled and len(plan.segs) == 1 and T % 128 == 0 and plan.Cout % H == 0
+    return bool(plan.pack.tiled and plan.pack.wbits == 4 and len(plan.segs) == 1 and T % 128 == 0 and plan.Cout % H == 0
                 and (plan.Cout // H) % 4 == 0)
 
 
@@ -416,7 +422,7 @@ def project_heads(plan, xq, B, T, H, ap, which, out8, vsum=None):
 
 def rows_i8_fusable(plan, next_plan, T):
     """`plan`'s output (+ residual) can be written as `next_plan`'s int8 input rows by the GEMM epilogue."""
-    return bool(plan.pack.tiled and len(plan.segs) == 1 and len(next_plan.segs) == 1 and T % 128 == 0
+    return bool(plan.pack.tiled and plan.pack.wbits == 4 and len(plan.segs) == 1 and len(next_plan.segs) == 1 and T % 128 == 0
                 and plan.Cout % 32 == 0 and next_plan.ldx == plan.Cout)
 
 

@@ -50,6 +50,7 @@ EPI_LINEAR, EPI_GEGLU_I8, EPI_HEADS_I8, EPI_HEADS_T_I8 = 0, 1, 2, 3
 
 
 EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_quantize_act", "qd_pack_weights", "qd_pack_weights_t4",
+           "qd_pack_weights_t8",
            "qd_conv2d_i8", "qd_conv2d_i8_splitk_ws_bytes",
            "qd_conv2d_i8_acc", "qd_groupnorm_ws_bytes", "qd_groupnorm_silu_quant", "qd_layernorm_quant",
            "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8", "qd_bmm_qk_i8", "qd_bmm_pv_i8"]
@@ -73,6 +74,7 @@ def load():
     lib.qd_quantize_act.argtypes = [vp, i32, i64, i64, i64, i64, i64, i64, i32, i32, i32, vp, i32, i32, i32, vp, i64, i32, vp]
     lib.qd_pack_weights.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp, vp, vp]
     lib.qd_pack_weights_t4.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]
+    lib.qd_pack_weights_t8.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]
     lib.qd_conv2d_i8.argtypes = [ctypes.POINTER(ConvDesc), vp]
     lib.qd_conv2d_i8_acc.argtypes = [ctypes.POINTER(ConvDesc), vp, vp]
     lib.qd_conv2d_i8_splitk_ws_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
@@ -89,7 +91,7 @@ def load():
                                i64, vp, i64, vp, i32, i32, i32, vp]
     lib.qd_bmm_qk_i8.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i64, i64, vp]
     lib.qd_bmm_pv_i8.argtypes = [vp, i64, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i64, i64, vp]
-    if lib.qd_abi_version() != 8:
+    if lib.qd_abi_version() != 9:
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -161,6 +163,12 @@ def pack_weights_t4(w, alpha, delta, zp, Cout, Cin_total, taps, c0, clen, n_leve
     _check(load().qd_pack_weights_t4(_ptr(w), _ptr(alpha), _ptr(delta), _ptr(zp), Cout, Cin_total, taps, c0, clen,
                                      pad16(clen), n_levels, _ptr(wt), kstep0, ntiles, _ptr(wsum), _stream()),
            "qd_pack_weights_t4")
+
+
+def pack_weights_t8(w, alpha, delta, zp, Cout, Cin_total, taps, c0, clen, n_levels, wt, kstep0, ntiles, wsum):
+    _check(load().qd_pack_weights_t8(_ptr(w), _ptr(alpha), _ptr(delta), _ptr(zp), Cout, Cin_total, taps, c0, clen,
+                                     pad16(clen), n_levels, _ptr(wt), kstep0, ntiles, _ptr(wsum), _stream()),
+           "qd_pack_weights_t8")
 
 
 class ConvCall:

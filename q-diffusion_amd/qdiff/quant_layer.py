@@ -406,7 +406,7 @@ class QuantModule(nn.Module):
         cache = self.__dict__.setdefault('_geglu_cache', [None, None])
         if cache[0] != key:
             pack = engine.pack_module_weights(self.weight, [wq], 0, row_perm=engine.geglu_row_perm(F, self.weight.device))
-            cache[1] = engine.build_conv_plan(pack, [aq], 1, 1, 1, 0, self.bias) if pack.tiled else None
+            cache[1] = engine.build_conv_plan(pack, [aq], 1, 1, 1, 0, self.bias) if (pack.tiled and pack.wbits == 4) else None
             cache[0] = key
         return cache[1]
 

@@ -98,9 +98,31 @@ def pack_weights_t4(w, alpha, delta, zp, Cout, Cin_total, taps, c0, clen, n_leve
     wsum += code.sum(dim=(1, 2)).to(torch.int32)          # raw nibble sums; zero point restored via zw in the epilogue
 
 
+def pack_weights_t8(w, alpha, delta, zp, Cout, Cin_total, taps, c0, clen, n_levels, wt, kstep0, ntiles, wsum):
+    """qd_pack_weights_t8: wt[kstep][ntile][ksub*2+half][n%32][16 B], stored byte = W - 128."""
+    wv = w.reshape(Cout, Cin_total, taps)[:, c0:c0 + clen].float()
+    d, z = delta.view(-1, 1, 1), zp.view(-1, 1, 1)
+    q = (torch.floor(wv / d) + (alpha.reshape(Cout, clen, taps) >= 0).float()) if alpha is not None else torch.round(wv / d)
+    stored = torch.clamp(q + z, 0, n_levels - 1).to(torch.int64) - 128                  # [Cout, clen, taps]
+    pad = (clen + 15) // 16 * 16
+    nst = (pad + 63) // 64
+    full = torch.zeros(ntiles * 32, taps, nst * 64, dtype=torch.int64)
+    full[:Cout, :, :clen] = stored.permute(0, 2, 1)
+    units = full.view(ntiles, 32, taps, nst, 4, 16).permute(2, 3, 0, 4, 1, 5).contiguous()   # [t, cs, jt, kh4, nn, 16]
+    view = wt.view(torch.int8).view(-1, ntiles, 4, 32, 16)
+    view[kstep0:kstep0 + taps * nst] = units.view(taps * nst, ntiles, 4, 32, 16).to(torch.int8)
+    wsum += stored.sum(dim=(1, 2)).to(torch.int32)
+
+
 def _unpack_rows(c, seg):
     """stored int64 weight bytes [Cout, taps, clen] of one segment (after the nibble unpack)."""
     taps = c.kh * c.kw
+    if getattr(c, "w_tiled", False) and c.wbits == 8:
+        ntiles, nst = (c.Cout + 31) // 32, (seg["clen"] + 63) // 64
+        k0 = seg.get("kstep0", 0)
+        blk = c.w.view(torch.int8).view(-1, ntiles, 4, 32, 16)[k0:k0 + taps * nst].to(torch.int64)   # [t*cs, jt, kh4, nn, 16]
+        vals = blk.view(taps, nst, ntiles, 4, 32, 16)
+        return vals.permute(2, 4, 0, 1, 3, 5).reshape(ntiles * 32, taps, nst * 64)[:c.Cout, :, :seg["clen"]]
     if getattr(c, "w_tiled", False):
         ntiles, nst = (c.Cout + 31) // 32, (seg["clen"] + 63) // 64
         k0 = seg.get("kstep0", 0)
@@ -281,6 +303,6 @@ def splitk_ws_bytes(c):
 def install(monkeypatch):
     """Replace qdiff.hip's device entry points by the emulation (CPU tensors only)."""
     from qdiff import hip
-    for name in ("quantize_act", "pack_weights", "pack_weights_t4", "conv2d_i8", "groupnorm_ws_bytes", "groupnorm_silu_quant",
+    for name in ("quantize_act", "pack_weights", "pack_weights_t4", "pack_weights_t8", "conv2d_i8", "groupnorm_ws_bytes", "groupnorm_silu_quant",
                  "layernorm_quant", "geglu_quant", "quantize_heads", "attn_i8", "splitk_ws_bytes", "bmm_qk_i8", "bmm_pv_i8"):
         monkeypatch.setattr(hip, name, globals()[name])

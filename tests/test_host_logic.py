@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     from qdiff import hip
     assert sorted(hip.EXPORTS) == declared
     lib.qd_abi_version.restype = ctypes.c_int
-    assert lib.qd_abi_version() == 8
+    assert lib.qd_abi_version() == 9
     assert lib.qd_device_ok() in (0, 1)                  # no compute calls without a GPU
 
 
@@ -231,8 +231,21 @@ def test_packing_mode_selection(emu):
     mk = lambda bits, zp: NS(delta=torch.full((8, 1, 1, 1), 0.1), zero_point=torch.full((8, 1, 1, 1), float(zp)), n_levels=2 ** bits)
     assert engine.pack_module_weights(w, [mk(4, 7)], 0).mode == 4          # int4 nibbles
     assert engine.pack_module_weights(w, [mk(8, 131)], 0).mode == 8        # u8 codes: W-128 + row-sum correction
-    assert engine.pack_module_weights(w, [mk(6, 30)], 0).mode == 0         # W - zp fits int8 directly
+    pk = engine.pack_module_weights(w, [mk(6, 30)], 0)
+    assert pk.mode == 8 and pk.tiled and pk.wbits == 8                    # tile order always stores W-128
     assert engine.pack_module_weights(w, [mk(4, 200)], 0).mode == 8        # degenerate zero point: general path
+
+
+def test_packing_mode_selection_row_major_layout(emu, monkeypatch):
+    """QDIFF_W8_LAYOUT=rows keeps the first-generation row-major int8 kernel: there W - zp is stored directly when it fits."""
+    from types import SimpleNamespace as NS
+    from qdiff import engine
+    monkeypatch.setattr(engine, "W8_LAYOUT", "rows")
+    w = torch.randn(8, 16, 1, 1)
+    mk = lambda bits, zp: NS(delta=torch.full((8, 1, 1, 1), 0.1), zero_point=torch.full((8, 1, 1, 1), float(zp)), n_levels=2 ** bits)
+    pk = engine.pack_module_weights(w, [mk(6, 30)], 0)
+    assert pk.mode == 0 and not pk.tiled
+    assert engine.pack_module_weights(w, [mk(8, 131)], 0).mode == 8
 
 
 
