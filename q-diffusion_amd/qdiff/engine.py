@@ -164,6 +164,36 @@ def pack_module_weights(weight, quantizers, split, row_perm=None):
     return pk
 
 
+_PACK_SEG_TENSORS = ("wsum", "delta_w", "zw", "wzp")
+_PACK_SEG_INTS = ("c0w", "clen", "clen_pad", "kofs", "kstep0")
+
+
+def pack_to_dict(pk):
+    """WeightPack -> plain dict of CPU tensors / ints (what a packed checkpoint stores per layer)."""
+    cpu = lambda t: None if t is None else t.detach().cpu()
+    segs = []
+    for sg in pk.segs:
+        e = {k: int(sg[k]) for k in _PACK_SEG_INTS if k in sg}
+        e.update({k: cpu(sg.get(k)) for k in _PACK_SEG_TENSORS})
+        segs.append(e)
+    return dict(wq=cpu(pk.wq), ldk=pk.ldk, wbits=pk.wbits, mode=pk.mode, Cout=pk.Cout, taps=pk.taps, Cin=pk.Cin,
+                tiled=bool(pk.tiled), row_perm=cpu(pk.row_perm), segs=segs)
+
+
+def pack_from_dict(d, device):
+    """Inverse of pack_to_dict: the tensors go to `device`, nothing is re-quantised."""
+    dev = lambda t: None if t is None else t.to(device)
+    pk = WeightPack()
+    pk.wq, pk.ldk, pk.wbits, pk.mode = dev(d["wq"]), int(d["ldk"]), int(d["wbits"]), int(d["mode"])
+    pk.Cout, pk.taps, pk.Cin, pk.tiled, pk.row_perm = int(d["Cout"]), int(d["taps"]), int(d["Cin"]), bool(d["tiled"]), dev(d["row_perm"])
+    pk.segs = []
+    for e in d["segs"]:
+        sg = {k: int(e[k]) for k in _PACK_SEG_INTS if k in e}
+        sg.update({k: dev(e.get(k)) for k in _PACK_SEG_TENSORS})
+        pk.segs.append(sg)
+    return pk
+
+
 # ------------------------------------------------------------------------------------------------
 # conv / linear plans (K3/K4)
 # ------------------------------------------------------------------------------------------------

@@ -304,7 +304,9 @@ class QuantModule(nn.Module):
         st, pd, dl = one(kw['stride']), one(kw['padding']), one(kw['dilation'])
         if kw['groups'] != 1 or any(d != 1 for d in dl) or len(set(st)) != 1 or len(set(pd)) != 1:
             return None
-        ks = tuple(self.weight.shape[2:])
+        ks = self.__dict__.get('_ksize')                 # remembered: the fp32 weight may have been released (load_packed)
+        if ks is None:
+            ks = self.__dict__['_ksize'] = tuple(self.weight.shape[2:])
         if self.kind == 'conv1d':
             return 1, ks[0], st[0], pd[0]
         return ks[0], ks[1], st[0], pd[0]
@@ -334,14 +336,31 @@ class QuantModule(nn.Module):
         tracking, so call this (or QuantModel.invalidate_plans()) after such an edit."""
         self._pack_key = self._plan_key = self._wdq_key = None
         self.__dict__.pop('_geglu_cache', None)
+        self.__dict__.pop('_frozen_pack', None)
+        self.__dict__.pop('_frozen_geglu_pack', None)
+
+    def load_packed(self, pack, geglu_pack=None):
+        """Install packed weights read from a packed checkpoint (utils.load_packed_ckpt): the integer path then never
+        looks at the fp32 weight / AdaRound alpha again (they can be freed); invalidate() returns to the live weights."""
+        self._geometry()                                   # records the kernel size while the weight still has its shape
+        self.__dict__['_frozen_pack'] = pack
+        self.__dict__['_frozen_geglu_pack'] = geglu_pack
+        self._pack_key = self._plan_key = None
+        self.__dict__.pop('_geglu_cache', None)
 
     def conv_plan(self):
         """Packed weights + epilogue constants for the current quantiser state (lazy, cached)."""
         wqs, aqs = self._weight_quantizers(), self._act_quantizers()
-        for q, w in zip(wqs, self._weight_slices()):
-            if hasattr(q, 'ensure_init'):
-                q.ensure_init(w)
-        wkey = (tuple(engine.quantizer_key(q) for q in wqs), self.weight._version, self.weight.data_ptr(), self.split)
+        frozen = self.__dict__.get('_frozen_pack')
+        if frozen is not None:
+            wkey = ('frozen', id(frozen))
+            if self._pack_key != wkey:
+                self._pack, self._pack_key, self._plan_key = frozen, wkey, None
+        else:
+            for q, w in zip(wqs, self._weight_slices()):
+                if hasattr(q, 'ensure_init'):
+                    q.ensure_init(w)
+            wkey = (tuple(engine.quantizer_key(q) for q in wqs), self.weight._version, self.weight.data_ptr(), self.split)
         if self._pack_key != wkey:
             self._pack = engine.pack_module_weights(self.weight, wqs, self.split)
             self._pack_key, self._plan_key = wkey, None
@@ -395,6 +414,15 @@ class QuantModule(nn.Module):
         """Second plan of a GEGLU projection: rows packed (value tile, gate tile) interleaved for the fused
         value*gelu(gate)->quantise epilogue (engine.conv_forward_geglu).  None if the layer does not
         qualify (needs tile-ordered int4 weights and an even split into 32-row tiles)."""
+        fz = self.__dict__.get('_frozen_geglu_pack')
+        if self.__dict__.get('_frozen_pack') is not None:
+            if fz is None:
+                return None
+            key = ('frozen', id(fz), engine.quantizer_key(self.act_quantizer))
+            cache = self.__dict__.setdefault('_geglu_cache', [None, None])
+            if cache[0] != key:
+                cache[0], cache[1] = key, engine.build_conv_plan(fz, [self.act_quantizer], 1, 1, 1, 0, self.bias)
+            return cache[1]
         F = self.weight.shape[0] // 2
         if self.kind != 'linear' or self.split != 0 or F % 32 != 0:
             return None

@@ -156,3 +156,91 @@ def export_cali_state_dict(qnn):
         delattr(m, name)
         setattr(m, name, v)
     return sd
+
+
+# ------------------------------------------------------------------------------------------------
+# packed checkpoint: what the kernels read, not what calibration wrote
+# ------------------------------------------------------------------------------------------------
+PACKED_FORMAT = "qdiff-packed-v1"
+
+
+def export_packed_ckpt(qnn):
+    """Serializable inference state of a calibrated QuantModel in (True, True) state.  The reference's checkpoint keeps,
+    per quantised layer, the fp32 weight, the fp32 AdaRound alpha of the same shape, delta and zero_point (SD-v1.4: ~7 GB);
+    this one keeps the packed int4/int8 codes the kernels contract (tile-ordered), the per-channel constants and the
+    activation quantisers (SD-v1.4 W4: ~0.45 GB).  Float parameters that are not quantised weights (norms, biases) are
+    stored as they are.  See load_packed_ckpt."""
+    from . import engine
+    mods, quantizers, skip = {}, {}, set()
+    for name, m in qnn.model.named_modules():
+        if isinstance(m, QuantModule):
+            if not m.int_ready():
+                raise ValueError(f"{name}: export_packed_ckpt needs set_quant_state(True, True) and initialised quantisers")
+            entry = dict(pack=engine.pack_to_dict(m.conv_plan().pack), split=int(m.split))
+            gc = m.__dict__.get("_geglu_cache")
+            if gc and gc[1] is not None:
+                entry["geglu_pack"] = engine.pack_to_dict(gc[1].pack)
+            mods[name] = entry
+            skip.add(f"{name}.weight")
+        if isinstance(m, UniformAffineQuantizer) and not isinstance(m, AdaRoundQuantizer) and "weight_quantizer" not in name \
+                and m.inited and m.delta is not None:
+            z = m.zero_point
+            quantizers[name] = dict(delta=m.delta.detach().cpu().clone() if torch.is_tensor(m.delta) else float(m.delta),
+                                    zero_point=z.detach().cpu().clone() if torch.is_tensor(z) else float(z))
+    tensors = {}
+    for k, v in qnn.model.state_dict().items():
+        if k in skip or "weight_quantizer" in k or "act_quantizer" in k:
+            continue
+        tensors[k] = v.detach().cpu().clone()
+    return dict(format=PACKED_FORMAT, modules=mods, quantizers=quantizers, tensors=tensors)
+
+
+def save_packed_ckpt(qnn, path):
+    torch.save(export_packed_ckpt(qnn), path)
+
+
+def load_packed_ckpt(qnn, ckpt, free_weights=True):
+    """Load a packed checkpoint (dict or path) into a QuantModel built on the same architecture (its weights are
+    irrelevant).  Leaves the model in (True, True) state; with free_weights the fp32 weights of the quantised layers are
+    released (the integer path does not read them; the floating-point states are then unavailable)."""
+    from . import engine
+    if not isinstance(ckpt, dict):
+        ckpt = torch.load(ckpt, map_location="cpu")
+    if ckpt.get("format") != PACKED_FORMAT:
+        raise ValueError("not a qdiff packed checkpoint")
+    dev = _model_device(qnn)
+    named = dict(qnn.model.named_modules())
+    missing = [n for n in ckpt["modules"] if not isinstance(named.get(n), QuantModule)]
+    if missing:
+        raise KeyError(f"packed checkpoint has layers this model lacks: {missing[:4]}...")
+    for name, entry in ckpt["modules"].items():
+        m = named[name]
+        if entry["split"]:
+            m._note_split(entry["split"])
+    named = dict(qnn.model.named_modules())                      # split created act_quantizer_0 / weight_quantizer_0
+    for name, st in ckpt["quantizers"].items():
+        qz = named[name]
+        d = st["delta"]
+        d = d.to(dev) if torch.is_tensor(d) else torch.tensor(float(d), device=dev)
+        if isinstance(getattr(qz, "delta", None), nn.Parameter) or "delta" in qz._parameters:
+            del qz.delta
+        qz.delta = nn.Parameter(d) if qz.leaf_param else d
+        z = st["zero_point"]
+        if "zero_point" in qz._parameters:
+            del qz.zero_point
+        qz.zero_point = z.to(dev) if torch.is_tensor(z) else z
+        qz.inited = True
+    own = qnn.model.state_dict()
+    qnn.model.load_state_dict({k: v for k, v in ckpt["tensors"].items() if k in own}, strict=False)
+    for name, entry in ckpt["modules"].items():
+        m = named[name]
+        gp = engine.pack_from_dict(entry["geglu_pack"], dev) if "geglu_pack" in entry else None
+        m.load_packed(engine.pack_from_dict(entry["pack"], dev), gp)
+        if free_weights:
+            m.weight.data = torch.empty(0, device=dev)
+            m.org_weight = torch.empty(0, device=dev)
+            for wq in m._weight_quantizers():
+                if isinstance(wq, AdaRoundQuantizer):
+                    wq.alpha.data = torch.empty(0, device=dev)
+    qnn.set_quant_state(True, True)
+    return qnn

@@ -136,3 +136,27 @@ def test_quant_state_can_flip_between_forwards(cuda):
     _run(qnn, fx, cuda)
     qnn.set_quant_state(True, True)
     assert torch.equal(_run(qnn, fx, cuda), y1)
+
+
+@pytest.mark.parametrize("name", ["sd_tiny", "cifar_tiny"])
+def test_packed_checkpoint_round_trip_on_gpu(cuda, name, tmp_path):
+    """save_packed_ckpt -> load_packed_ckpt into a model with different fp32 weights: identical output on the GPU
+    (the packed codes are what the kernels read; nothing is re-quantised) and the fp32 weights are released."""
+    import qdiff
+    from qdiff.utils import load_packed_ckpt, save_packed_ckpt
+    fx = load_fixture(f"model_{name}.pt")
+    qnn = _resume(fx, cuda)
+    y0 = _run(qnn, fx, cuda)
+    path = str(tmp_path / "packed.pth")
+    save_packed_ckpt(qnn, path)
+    spec = fx["spec"]
+    wq, aq = quant_params(spec)
+    other = build_engine_model(spec).to(cuda)
+    with torch.no_grad():
+        for p in other.parameters():
+            p.add_(torch.randn_like(p) * 0.5)
+    q2 = qdiff.QuantModel(other, wq, aq, sm_abit=spec["sm_abit"]).to(cuda).eval()
+    load_packed_ckpt(q2, path)
+    y1 = _run(q2, fx, cuda)
+    assert torch.equal(y0, y1)
+    assert all(m.weight.numel() == 0 for m in q2.modules() if isinstance(m, qdiff.QuantModule))

@@ -277,3 +277,36 @@ def test_standalone_qk_smv_matmuls_on_emulator(emu):
         assert (w - c["weight"]).abs().max() <= 2e-5 * c["weight"].abs().max()
         a = smv(torch.softmax(c["weight"].float(), dim=-1), c["v"])
     assert (a - c["out"]).abs().max() <= 2e-5 * c["out"].abs().max()
+
+
+@pytest.mark.parametrize("name", ["cifar_tiny", "ldm_tiny", "sd_tiny"])
+def test_packed_checkpoint_round_trip(emu, name, tmp_path):
+    """export_packed_ckpt -> load_packed_ckpt into a model with DIFFERENT fp32 weights reproduces the original
+    integer-path output bit for bit, the fp32 weights of the quantised layers are released, and the file is several
+    times smaller than the reference-format state dict."""
+    import qdiff
+    from qdiff.utils import export_cali_state_dict, load_packed_ckpt, save_packed_ckpt
+    fx = load_fixture(f"model_{name}.pt")
+    qnn = _resume_cpu(fx)
+    x, t, c = fixture_inputs(fx, "test")
+    run = lambda m: m(x, t, c) if c is not None else m(x, t)
+    with torch.no_grad():
+        y0 = run(qnn)
+    path = tmp_path / "packed.pth"
+    save_packed_ckpt(qnn, path)
+    ref_bytes = sum(v.numel() * v.element_size() for v in export_cali_state_dict(qnn).values())
+    assert os.path.getsize(path) < 0.45 * ref_bytes
+
+    spec = fx["spec"]
+    wq, aq = quant_params(spec)
+    other = build_engine_model(spec)
+    with torch.no_grad():
+        for p in other.parameters():
+            p.add_(torch.randn_like(p) * 0.5)                      # nothing of the fp32 weights may matter
+    q2 = qdiff.QuantModel(other, wq, aq, sm_abit=spec["sm_abit"]).eval()
+    load_packed_ckpt(q2, str(path))
+    with torch.no_grad():
+        y1 = run(q2)
+    assert torch.equal(y0, y1)
+    mods = [m for m in q2.modules() if isinstance(m, qdiff.QuantModule)]
+    assert mods and all(m.weight.numel() == 0 for m in mods)
