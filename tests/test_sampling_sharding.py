@@ -53,6 +53,24 @@ def test_generalized_steps_matches_reference():
     assert torch.equal(out, fx["out"])
 
 
+@pytest.mark.parametrize("key", ["dpm10", "dpm20"])
+def test_dpm_solver_matches_reference_sampler(key):
+    """DPM-Solver++(2M) as txt2img.py --dpm_solver runs it (DPMSolverSampler.sample): bit for bit, S model calls on the
+    CFG-doubled batch with float timestep labels; 10 steps exercise lower_order_final."""
+    from qdiff import sampling
+    fx = load_fixture("samplers.pt")[key]
+    calls = []
+
+    def unet(x, t, c=None):
+        assert t.dtype == torch.float32
+        calls.append(x.shape[0])
+        return stub_eps(x, t, c)
+    acp = torch.tensor(np.cumprod(1.0 - sampling.ldm_betas(fx["ls"], fx["le"]), axis=0), dtype=torch.float32)
+    out = sampling.dpm_solver_sample(unet, fx["xT"], acp, fx["steps"], cond=fx["c"], uncond=fx["uc"], scale=fx["scale"])
+    assert len(calls) == fx["calls"] == fx["steps"] and all(b == 6 for b in calls)
+    assert torch.equal(out, fx["out"])
+
+
 def test_shard_bounds_cover_batch():
     from qdiff.sampling import shard_bounds
     for gb in (1, 7, 8, 64, 65):

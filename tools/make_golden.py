@@ -382,6 +382,15 @@ def make_sampler_fixtures():
     x0 = torch.randn(2, 3, 8, 8, generator=g)
     xs, _ = generalized_steps(x0, seq, lambda xx, tt: stub_eps(xx, tt), betas, eta=0.0)
     fx["generalized"] = dict(x=x0, seq=seq, out=xs[-1])
+    # DPM-Solver++(2M) exactly as DPMSolverSampler.sample drives it (dpm_solver/sampler.py:63-80), CFG on
+    from ldm.models.diffusion.dpm_solver.sampler import DPMSolverSampler
+    for S in (10, 20):                                   # 10 < 15 exercises lower_order_final
+        m = Stub(0.00085, 0.0120)
+        xT4 = torch.randn(3, 4, 8, 8, generator=g)
+        c4, uc4 = torch.randn(3, 5, 6, generator=g), torch.randn(3, 5, 6, generator=g)
+        out, _ = DPMSolverSampler(m).sample(S=S, conditioning=c4, batch_size=3, shape=[4, 8, 8], verbose=False,
+                                            unconditional_guidance_scale=7.5, unconditional_conditioning=uc4, x_T=xT4)
+        fx[f"dpm{S}"] = dict(xT=xT4, c=c4, uc=uc4, scale=7.5, steps=S, ls=0.00085, le=0.0120, out=out, calls=m.calls)
     torch.Tensor.to = real_to
     torch.save(fx, os.path.join(OUT, "samplers.pt"))
     print("[golden] samplers.pt", {k: tuple(v["out"].shape) for k, v in fx.items()}, "plms calls", fx["plms"]["calls"])
