@@ -254,6 +254,7 @@ def test_conv_split_two_segments(cuda):
 SPLITK_CASES = [
     # name, B, Cin, H, W, Cout, k     (M = B*H*W small, K long: the layers the library contracts split-K)
     ("emb_m16",      16, 1280, 1, 1, 1280, 1),     # time-embedding Linear: M=16
+    ("emb_m1",        1, 320, 1, 1, 1280, 1),      # a single sample: M=1
     ("mid_8x8",       4, 640, 8, 8, 1280, 3),      # 8x8 middle-block conv: M=256, K=5760
     ("ctx_kv",        2, 768, 1, 77, 320, 1),      # cross-attention k/v projection of 77 context tokens
     ("m1024_ragged",  1, 352, 30, 33, 224, 3),     # ragged M (990), K tail (352 = 5.5 * 64), NT=7
