@@ -1,6 +1,6 @@
 """HIP-graph replay of a whole quantised UNet evaluation.
 
-One SD UNet evaluation is ~1.9k kernel launches (282 integer contractions + producers + attention);
+One SD UNet evaluation is ~0.85k kernel launches (282 integer contractions + producers + attention);
 at sampling batch sizes the host cannot issue them fast enough through Python, so the launch-bound
 inner loop of the samplers (reference plms.py:142, ddim.py:143, denoising.py:16) is captured once per
 input shape into a hipGraph and replayed.  Everything the kernels read (packed weights, scales, zero

@@ -160,3 +160,26 @@ def test_packed_checkpoint_round_trip_on_gpu(cuda, name, tmp_path):
     y1 = _run(q2, fx, cuda)
     assert torch.equal(y0, y1)
     assert all(m.weight.numel() == 0 for m in q2.modules() if isinstance(m, qdiff.QuantModule))
+
+
+@pytest.mark.parametrize("name", ["sd_tiny", "ldm_tiny"])
+def test_hip_graph_replay_equals_eager(cuda, name):
+    """bench.py measures HIP-graph replay: the replayed evaluation must equal the eager one bit for bit, for inputs
+    different from the ones the graph was captured with (shared operand buffers, split-K scratch, statistics buffers)."""
+    fx = load_fixture(f"model_{name}.pt")
+    qnn = _resume(fx, cuda)
+    x, t, c = (a.to(cuda) if a is not None else None for a in fixture_inputs(fx, "test"))
+    g = torch.Generator(device=cuda).manual_seed(5)
+    x2 = torch.randn(x.shape, device=cuda, generator=g)
+    t2 = (t + 37) % 1000
+    c2 = torch.randn(c.shape, device=cuda, generator=g) if c is not None else None
+    run = lambda a, b, cc: (qnn(a, b, cc) if cc is not None else qnn(a, b)).clone()
+    with torch.no_grad():
+        e1, e2 = run(x, t, c), run(x2, t2, c2)
+        qnn.enable_hip_graphs(True)
+        g1 = run(x, t, c)            # captures
+        g2 = run(x2, t2, c2)         # replays with new inputs
+        g1b = run(x, t, c)
+        qnn.enable_hip_graphs(False)
+    torch.cuda.synchronize()
+    assert torch.equal(e1, g1) and torch.equal(e2, g2) and torch.equal(g1, g1b)
