@@ -70,8 +70,18 @@ class StepTable:
     def __len__(self):
         return len(self.timesteps)
 
+    def _sqrt_at_tensor(self, index, device):
+        """sqrt(a_t) as a 0-dim fp32 tensor on `device`: the reference divides by a TENSOR (plms.py:207-211, ddim.py:203-208),
+        i.e. a true fp32 division; dividing by a Python float lets PyTorch's GPU kernel multiply by a host-computed
+        reciprocal instead, which differs in the last bit."""
+        cache = self.__dict__.setdefault("_sqrt_at_dev", {})
+        t = cache.get(device)
+        if t is None:
+            t = cache[device] = torch.tensor(self.sqrt_at, dtype=torch.float32, device=device)
+        return t[index]
+
     def update(self, x, e, index, noise=None):
-        pred_x0 = (x - self.sqrt_one_minus_at[index] * e) / self.sqrt_at[index]
+        pred_x0 = (x - self.sqrt_one_minus_at[index] * e) / self._sqrt_at_tensor(index, x.device)
         x_prev = self.sqrt_aprev[index] * pred_x0 + self.dir_coef[index] * e
         if noise is not None and self.sigma[index] != 0.0:
             x_prev = x_prev + self.sigma[index] * noise
@@ -120,6 +130,94 @@ def plms_sample(unet, x_T, table, cond=None, uncond=None, scale=1.0, callback=No
         if callback:
             callback(i)
     return x
+
+
+class DevicePLMS:
+    """PLMS sampling with a device-resident loop state: the step counter, the per-step coefficients
+    and the multistep history live in device tensors, so a whole sampler step — UNet evaluation on the CFG-doubled batch,
+    guidance, multistep combination, x update — contains no host-dependent scalar and can be captured once and replayed
+    as ONE HIP graph per step (`use_graph=True`; four graphs: the first three steps have shorter histories, the first one
+    costs two evaluations, as plms.py:222-240).  Same arithmetic, in the same order, as plms_sample: bit-identical samples.
+    `unet` must be capturable (a QuantModel in (True, True) state with its own graph replay switched off)."""
+
+    def __init__(self, unet, table, x_T, cond=None, uncond=None, scale=1.0, use_graph=False):
+        dev = x_T.device
+        self.unet, self.cond, self.uncond, self.scale = unet, cond, uncond, scale
+        self.total = len(table)
+        order = np.flip(table.timesteps).copy()
+        row = lambda vals: torch.tensor([vals[self.total - i - 1] for i in range(self.total)], dtype=torch.float32, device=dev)
+        self.ts = torch.tensor(order, dtype=torch.long, device=dev)
+        self.ts_next = torch.tensor([order[min(i + 1, self.total - 1)] for i in range(self.total)], dtype=torch.long, device=dev)
+        self.c1, self.c2 = row(table.sqrt_one_minus_at), row(table.sqrt_at)
+        self.c3, self.c4 = row(table.sqrt_aprev), row(table.dir_coef)
+        self.i = torch.zeros(1, dtype=torch.long, device=dev)            # device-side step counter
+        self.x = x_T.clone()
+        self.hist = [torch.zeros_like(x_T) for _ in range(3)]            # e_{k-1}, e_{k-2}, e_{k-3}
+        self.use_graph = bool(use_graph) and dev.type == "cuda"
+        self.graphs = {}
+
+    def _coef(self, c):
+        return c.index_select(0, self.i).reshape(())
+
+    def _update(self, e):
+        pred_x0 = (self.x - self._coef(self.c1) * e) / self._coef(self.c2)
+        return self._coef(self.c3) * pred_x0 + self._coef(self.c4) * e
+
+    def _eps(self, x, ts):
+        t = ts.index_select(0, self.i).expand(x.shape[0])
+        return guided_eps(self.unet, x, t, self.cond, self.uncond, self.scale)
+
+    def _step(self, nold):
+        e = self._eps(self.x, self.ts)
+        o1, o2, o3 = self.hist
+        if nold == 0:
+            e_next = self._eps(self._update(e), self.ts_next)
+            e_prime = (e + e_next) / 2
+        elif nold == 1:
+            e_prime = (3 * e - o1) / 2
+        elif nold == 2:
+            e_prime = (23 * e - 16 * o1 + 5 * o2) / 12
+        else:
+            e_prime = (55 * e - 59 * o1 + 37 * o2 - 9 * o3) / 24
+        self.x.copy_(self._update(e_prime))
+        o3.copy_(o2)
+        o2.copy_(o1)
+        o1.copy_(e)
+        self.i += 1
+
+    @torch.no_grad()
+    def step(self, k):
+        nold = min(k, 3)
+        if not self.use_graph:
+            return self._step(nold)
+        g = self.graphs.get(nold)
+        if g is None:
+            # capture advances the state once; snapshot and restore so that the replay below performs THIS step
+            snap = [self.x.clone(), self.i.clone()] + [h.clone() for h in self.hist]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._step(nold)                                            # warm-up outside capture (plan caches, allocator)
+            torch.cuda.current_stream().wait_stream(side)
+            self._restore(snap)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step(nold)
+            self._restore(snap)
+            self.graphs[nold] = g
+        g.replay()
+
+    def _restore(self, snap):
+        self.x.copy_(snap[0])
+        self.i.copy_(snap[1])
+        for h, s_ in zip(self.hist, snap[2:]):
+            h.copy_(s_)
+
+    @torch.no_grad()
+    def run(self):
+        for k in range(self.total):
+            self.step(k)
+        return self.x
 
 
 class DPMSolverTable:
@@ -181,11 +279,14 @@ def dpm_solver_sample(unet, x_T, alphas_cumprod, steps, cond=None, uncond=None, 
     tb = alphas_cumprod if isinstance(alphas_cumprod, DPMSolverTable) else DPMSolverTable(alphas_cumprod, steps, order)
     x = x_T
     b, dev = x.shape[0], x.device
+    alpha_dev = tb.alpha.to(dev)
 
     def data_pred(xx, i):
         tt = torch.full((b,), float(tb.t_input[i]), device=dev, dtype=torch.float32)
         eps = guided_eps(unet, xx, tt, cond, uncond, scale)
-        return (xx - float(tb.sigma[i]) * eps) / float(tb.alpha[i])              # x0 prediction (dpm_solver.py:386-392)
+        # x0 prediction (dpm_solver.py:386-392); a TENSOR divisor = true fp32 division as in the reference (a Python float
+        # would be turned into a reciprocal multiply by the GPU kernel: last-bit differences)
+        return (xx - float(tb.sigma[i]) * eps) / alpha_dev[i]
 
     hist = [data_pred(x, 0)]                                                       # model outputs at the previous grid points
     for i in range(1, tb.steps + 1):

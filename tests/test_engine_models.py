@@ -183,3 +183,21 @@ def test_hip_graph_replay_equals_eager(cuda, name):
         qnn.enable_hip_graphs(False)
     torch.cuda.synchronize()
     assert torch.equal(e1, g1) and torch.equal(e2, g2) and torch.equal(g1, g1b)
+
+
+def test_whole_step_graph_plms_equals_eager_sampler(cuda):
+    """One HIP graph per PLMS step (UNet on the CFG batch + guidance + multistep update, DevicePLMS) reproduces the eager
+    plms_sample loop bit for bit on a quantised SD-style UNet."""
+    from qdiff import sampling
+    fx = load_fixture("model_sd_tiny.pt")
+    qnn = _resume(fx, cuda)
+    x, t, c = (a.to(cuda) for a in fixture_inputs(fx, "test"))
+    g = torch.Generator(device=cuda).manual_seed(9)
+    uc = torch.randn(c.shape, device=cuda, generator=g)
+    table = sampling.StepTable(sampling.ldm_betas(0.00085, 0.0120), 6, eta=0.0)
+    unet = lambda xx, tt, cc=None: qnn(xx, tt, cc)
+    with torch.no_grad():
+        want = sampling.plms_sample(unet, x, table, cond=c, uncond=uc, scale=3.0)
+        got = sampling.DevicePLMS(unet, table, x, cond=c, uncond=uc, scale=3.0, use_graph=True).run()
+    torch.cuda.synchronize()
+    assert torch.isfinite(want).all() and torch.equal(got, want)

@@ -53,6 +53,21 @@ def test_generalized_steps_matches_reference():
     assert torch.equal(out, fx["out"])
 
 
+def test_device_resident_plms_matches_reference_sampler():
+    """DevicePLMS (step counter, coefficients and multistep history on the device: one capturable step) == the reference's
+    PLMSSampler trajectory, bit for bit."""
+    from qdiff import sampling
+    fx = load_fixture("samplers.pt")["plms"]
+    calls = []
+
+    def unet(x, t, c=None):
+        calls.append(x.shape[0])
+        return stub_eps(x, t, c)
+    table = sampling.StepTable(sampling.ldm_betas(fx["ls"], fx["le"]), fx["steps"], eta=0.0)
+    out = sampling.DevicePLMS(unet, table, fx["xT"], cond=fx["c"], uncond=fx["uc"], scale=fx["scale"]).run()
+    assert len(calls) == 51 and torch.equal(out, fx["out"])
+
+
 @pytest.mark.parametrize("key", ["dpm10", "dpm20"])
 def test_dpm_solver_matches_reference_sampler(key):
     """DPM-Solver++(2M) as txt2img.py --dpm_solver runs it (DPMSolverSampler.sample): bit for bit, S model calls on the
