@@ -115,6 +115,39 @@ def measure_igemm(qnn, args):
     return dict(launches=len(records), total_ms=ms, ops=ops, event_overhead_us=1000.0 * overhead)
 
 
+def gpu_denominators(qnn, margs, k=3):
+    """The two GPU-side denominators of SURVEY.md §8(d) / BASELINE.json north_star, same UNet, same batch, same
+    GPU, same run: (a) the fp32 PyTorch-ROCm UNet — quantisation off, `org_weight` path of
+    reference qdiff/quant_layer.py:273-276, library (MIOpen / rocBLAS) fp32 kernels; (b) the reference's fake-quant
+    SIMULATION in fp32 torch ops (quant_layer.py:256-272, quant_block.py:190-221) on the GPU.  (b) runs this
+    repo's restatement of that arithmetic, which caches the fake-quantised weights per quantiser state (the
+    reference re-quantises them on every forward), so it flatters the reference."""
+    from qdiff import engine
+
+    def timed():
+        with torch.no_grad():
+            qnn.model(*margs)                          # warm: MIOpen find, allocator
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                qnn.model(*margs)
+            torch.cuda.synchronize()
+        return 1000.0 * (time.perf_counter() - t0) / k
+    graphs, qnn._graphs = qnn._graphs, None
+    res = {"evals_timed": k}
+    try:
+        qnn.set_quant_state(False, False)
+        res["fp32_unet_ms"] = round(timed(), 3)
+        qnn.set_quant_state(True, True)
+        engine.SIMULATE = True
+        res["fake_quant_sim_ms"] = round(timed(), 3)
+    finally:
+        engine.SIMULATE = False
+        qnn.set_quant_state(True, True)
+        qnn._graphs = graphs
+    return res
+
+
 def cpu_baseline(qnn, qspec, kind, cfg):
     from oracle import unet_ref as U
     from qdiff import synthetic
@@ -141,6 +174,7 @@ def main():
     ap.add_argument("--model", default="sd", choices=["sd", "ldm", "cifar"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-denominators", action="store_true", help="skip the fp32 / fake-quant GPU denominators")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

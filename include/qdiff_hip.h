@@ -22,8 +22,9 @@
  *   stored byte      a' = q - off,  off = 128 for unsigned 8-bit grids, 0 for signed grids
  *   "true zero"      z' = zp - off  (the byte that dequantises to 0.0; used for conv padding)
  *   weight code      W  = clamp(floor(w/dw)+(alpha>=0)+zw, 0, 2^b-1)   (adaptive_rounding.py:49-59)
- *   stored weight    w' = W - zw (int4 path, unpacked in-kernel) or W - 128 (int8 path, with the
- *                    per-channel remainder zw-128 folded into the epilogue through row sums).
+ *   stored weight    w' = W (int4 path: the raw nibble, unpacked in-kernel) or W - 128 (int8 path); the
+ *                    per-channel remainder zw resp. zw-128 is restored in the epilogue through activation
+ *                    row sums (qd_conv_seg.zw).
  */
 #ifndef QDIFF_HIP_H
 #define QDIFF_HIP_H
@@ -34,7 +35,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 9
+#define QD_ABI_VERSION 10
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -95,20 +96,20 @@ int qd_pack_weights(const float* w, const float* alpha, const float* delta, cons
 typedef struct {
     int32_t        c0;       /* first channel of the segment inside an x row (bytes)              */
     int32_t        clen;     /* channel count, multiple of 16 (padded)                            */
-    int32_t        kofs;     /* offset of the segment inside a weight tap row (elements)          */
-    int32_t        kstep0;   /* w_tiled: index of the segment's first 64-wide K-step in the tiled weight array */
-    const int8_t*  wzp;     /* [Cout] weight zero point subtracted at nibble unpack (wbits=4), or NULL */
+    int32_t        kofs;     /* reserved (row-major weight layouts of ABI <= 9); ignored                */
+    int32_t        kstep0;   /* index of the segment's first 64-wide K-step in the tiled weight array    */
+    const int8_t*  wzp;     /* reserved (ABI <= 9); ignored                                              */
     const float*   scale;    /* [Cout]  delta_x * delta_w[n]                                       */
     const int32_t* zc;       /* [Cout]  z' * Wsum[n]            or NULL (symmetric activations)    */
-    const int32_t* zw;       /* [Cout]  zw[n]-128 (int8 rows) | zw[n] (w_tiled int4) | NULL (row-major int4 / direct s8) */
+    const int32_t* zw;       /* [Cout]  zw[n]-128 (int8 tiles) | zw[n] (int4 tiles)                          */
     const int32_t* zfill;    /* [2] {z', K_seg*z'} device scalars or NULL (= 0)                    */
-    const int8_t*  fill16;   /* w_tiled: 16 bytes of z' — the source of out-of-image taps for the
-                                LDS-DMA loader — or NULL (= zeros)                                 */
+    const int8_t*  fill16;   /* 16 bytes of z' — the source of out-of-image taps for the LDS-DMA loader —
+                                or NULL (= zeros)                                                  */
 } qd_conv_seg;
 
 typedef struct {
     const int8_t*  x;        /* [B][H][W][ldx] stored activation bytes                            */
-    const uint8_t* w;        /* [Cout][taps][ldk] s8, or nibbles [Cout][taps][ldk/2] when wbits=4  */
+    const uint8_t* w;        /* MFMA-tile-ordered weights of qd_pack_weights_t4 (wbits=4) / _t8 (wbits=8) */
     void*          out;      /* [M][ldo]                                                           */
     const float*   bias;     /* [Cout] or NULL                                                     */
     const float*   rowbias;  /* [B][ld_rowbias] per-sample per-channel add (timestep emb) or NULL  */
@@ -119,7 +120,7 @@ typedef struct {
     int32_t        wbits;    /* 8 or 4                                                             */
     int32_t        out_dtype;/* QD_F32 / QD_F16                                                    */
     int32_t        nseg;     /* 1 or 2                                                             */
-    int32_t        w_tiled;  /* 1: w is the MFMA-tile-ordered nibble array of qd_pack_weights_t4   */
+    int32_t        w_tiled;  /* must be 1 (the row-major layouts of ABI <= 9 are gone)                  */
     int32_t        epilogue; /* QD_EPI_LINEAR, or QD_EPI_GEGLU_I8 (w_tiled only): the weight rows were packed
                                 interleaved per 32 (value tile, gate tile, value tile, ...); the epilogue computes
                                 value*gelu(gate) (ldm/modules/attention.py:42-44) and writes it QUANTISED with

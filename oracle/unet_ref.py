@@ -23,11 +23,20 @@ class QuantCkpt:
         self.w_bits, self.a_bits, self.a_sym, self.sm_abit = w_bits, a_bits, a_sym, sm_abit
         self.use_wq, self.use_aq = use_wq, use_aq
         self.trace = None            # set to a list to record (name, tensor) at block boundaries
+        self.blocks = None           # set to a list to record (kind, module path, inputs dict, output) of every block
+                                     # (teacher-forced per-block parity: tests/test_block_parity.py)
 
     def note(self, name, t):
         if self.trace is not None:
             self.trace.append((name, t.detach().clone()))
         return t
+
+    def block(self, kind, name, out, **inputs):
+        """Record one block evaluation: `name` is the module path inside the UNet (state-dict prefix)."""
+        if self.blocks is not None:
+            keep = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in inputs.items()}
+            self.blocks.append((kind, name, keep, out.detach().clone()))
+        return out
 
     def get(self, name):
         return self.sd[self.prefix + name]
@@ -112,9 +121,10 @@ def _cifar_resblock(Q, p, x, temb, cin, cout, split=0):
     h = Q.conv(p + ".conv1", _swish(Q.gn(p + ".norm1", x, 1e-6)), 1, 1)
     h = h + Q.linear(p + ".temb_proj", _swish(temb))[:, :, None, None]
     h = Q.conv(p + ".conv2", _swish(Q.gn(p + ".norm2", h, 1e-6)), 1, 1)      # dropout: eval mode
+    x0 = x
     if cin != cout:
         x = Q.conv(p + ".nin_shortcut", x, 1, 0, split=split)
-    return x + h
+    return Q.block("cifar_res", p, x + h, x=x0, emb=temb, split=split)
 
 
 def _cifar_attn(Q, p, x):
@@ -136,7 +146,7 @@ def _cifar_attn(Q, p, x):
         v = R.uaq_forward(v, **Q.act_q(p + ".act_quantizer_v"))
         w_ = R.uaq_forward(w_, **Q.act_q(p + ".act_quantizer_w", n_bits=Q.sm_abit))
     h_ = torch.bmm(v, w_).reshape(b, c, h, w)
-    return x + Q.conv(p + ".proj_out", h_)
+    return Q.block("cifar_attn", p, x + Q.conv(p + ".proj_out", h_), x=x)
 
 
 def cifar_forward(Q, cfg, x, t, split_shortcut=True):
@@ -190,8 +200,8 @@ def _ldm_resblock(Q, p, x, emb, cin, cout, split=0):
     h = h + e[..., None, None]
     h = Q.conv(p + ".out_layers.3", F.silu(Q.gn(p + ".out_layers.0", h, 1e-5)), 1, 1)
     if cin == cout:
-        return x + h
-    return Q.conv(p + ".skip_connection", x, 1, 0, split=split) + h
+        return Q.block("ldm_res", p, x + h, x=x, emb=emb, split=0)
+    return Q.block("ldm_res", p, Q.conv(p + ".skip_connection", x, 1, 0, split=split) + h, x=x, emb=emb, split=split)
 
 
 def _cross_attn(Q, p, x, context, heads):
@@ -234,7 +244,7 @@ def _spatial_transformer(Q, p, x, context, heads):
     t = t.permute(0, 2, 3, 1).reshape(b, h * w, t.shape[1])
     t = _transformer_block(Q, p + ".transformer_blocks.0", t, context, heads)
     t = t.reshape(b, h, w, t.shape[-1]).permute(0, 3, 1, 2)
-    return Q.conv(p + ".proj_out", t) + x
+    return Q.block("sd_transformer", p, Q.conv(p + ".proj_out", t) + x, x=x, context=context)
 
 
 def _attention_block(Q, p, x, heads):
@@ -259,7 +269,7 @@ def _attention_block(Q, p, x, heads):
         v = R.uaq_forward(v, **Q.act_q(p + ".attention.smv_matmul.act_quantizer_v"))
     a = torch.einsum("bts,bcs->bct", weight, v).reshape(bs, -1, length)
     h = Q.conv1d(p + ".proj_out", a)
-    return (xf + h).reshape(b, c, *spatial)
+    return Q.block("ldm_attn", p, (xf + h).reshape(b, c, *spatial), x=x)
 
 
 def ldm_forward(Q, cfg, x, t, context=None, split=True):
@@ -278,8 +288,10 @@ def ldm_forward(Q, cfg, x, t, context=None, split=True):
         return _attention_block(Q, p, h, heads_at(ch))
 
     emb = Q.note("time_embed", Q.linear("time_embed.2", F.silu(Q.linear("time_embed.0", R.timestep_embedding_ldm(t, mc)))))
+    Q.block("ldm_time_embed", "time_embed", emb, t=t)
     hs = []
     h = Q.note("input_blocks.0", Q.conv("input_blocks.0.0", x.float(), 1, 1))
+    Q.block("conv", "input_blocks.0.0", h, x=x.float())
     hs.append(h)
     ch, ds, idx = mc, 1, 1
     chans = [mc]
@@ -295,7 +307,7 @@ def ldm_forward(Q, cfg, x, t, context=None, split=True):
             chans.append(ch)
             idx += 1
         if level != len(mult) - 1:
-            h = Q.note(f"input_blocks.{idx}", Q.conv(f"input_blocks.{idx}.0.op", h, 2, 1))
+            h = Q.note(f"input_blocks.{idx}", Q.block("conv", f"input_blocks.{idx}.0.op", Q.conv(f"input_blocks.{idx}.0.op", h, 2, 1), x=h))
             hs.append(h)
             chans.append(ch)
             idx += 1
@@ -316,8 +328,8 @@ def ldm_forward(Q, cfg, x, t, context=None, split=True):
                 h = attn(f"output_blocks.{idx}.{j}", h, ch)
                 j += 1
             if level and i == nrb:
-                h = Q.conv(f"output_blocks.{idx}.{j}.conv", F.interpolate(h, scale_factor=2, mode="nearest"), 1, 1)
+                h = Q.block("ldm_upsample", f"output_blocks.{idx}.{j}", Q.conv(f"output_blocks.{idx}.{j}.conv", F.interpolate(h, scale_factor=2, mode="nearest"), 1, 1), x=h)
                 ds //= 2
             Q.note(f"output_blocks.{idx}", h)
             idx += 1
-    return Q.conv("out.2", F.silu(Q.gn("out.0", h, 1e-5)), 1, 1)
+    return Q.block("ldm_head", "out", Q.conv("out.2", F.silu(Q.gn("out.0", h, 1e-5)), 1, 1), x=h)

@@ -10,8 +10,6 @@ typedef int   v16i __attribute__((ext_vector_type(16)));
 typedef float v4f  __attribute__((ext_vector_type(4)));
 
 void qd_set_error(const char* fmt, ...);
-// csrc/igemm_dma.hip: LDS-DMA kernel for tile-ordered int4 weights (d->w_tiled)
-int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream);
 
 #define QD_REQUIRE(cond, ...)                 \
     do {                                      \

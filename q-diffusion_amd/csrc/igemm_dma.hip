@@ -1,28 +1,41 @@
-// igemm_dma.hip — second-generation K3/K4 kernel for int4 weights: LDS-DMA fed, 3-stage ring.
+// igemm_dma.hip — K3/K4: integer implicit-GEMM convolution / linear on v_mfma_i32_32x32x32_i8, LDS-DMA fed.
 //
-// Same contraction and epilogue as igemm_i8.hip (reference qdiff/quant_layer.py:256-276), different
-// data path.  What limited the first kernel was latency, not the matrix pipe: one K-step of
-// register-staged prefetch and a barrier per step.  Here
-//   * both operands are copied global -> LDS by the DMA path (global_load_lds, 16 B/lane, no VGPR
-//     round trip): activations per (tap, 64-channel step) with the im2col gather expressed in the
-//     per-lane SOURCE address — out-of-image taps read a 16-byte buffer of the "true zero" byte z',
-//     K-tail / M-tail lanes read zeros — and the LDS destination is lane-linear, so the XOR bank
-//     swizzle of the A tile is applied to the source chunk index instead;
-//   * weights are pre-tiled at pack time (qd_pack_weights_t4): one K-step x 32 output channels is a
-//     contiguous 1-KB block already in fragment order, so the B copy is a straight memcpy and the
-//     fragment read is a conflict-free ds_read_b64; the RAW nibbles are unpacked at fragment-read time
-//     (two AND/shift per 8 weights — the weight zero point is restored in the epilogue through the
-//     activation row sums), which keeps 4-bit weights 4-bit all the way into LDS;
-//   * a 3-deep LDS ring keeps two K-steps in flight across the single barrier per step
-//     (counted s_waitcnt vmcnt(N), raw s_barrier: cdna_hip_programming.md §5 "Pipelining across
-//     barriers").
-// Block = 4 waves stacked along M; wave tile = (32*MT) x (32*NT) of 32x32x32 MFMAs, BN = 32*NT
-// (NT=5 -> 160 divides every SD-v1 width 320/640/1280/..., NT=7 -> 224 for LDM-4).
+// Replaces F.conv2d / F.conv1d(k=1) / F.linear on fake-quantised fp32 operands (reference
+// qdiff/quant_layer.py:256-276) by an exact int32 contraction of the stored codes and a fused dequantising
+// epilogue (per-out-channel scale, zero-point restoration, bias, timestep-embedding row bias, residual, the
+// split-shortcut second segment of quant_layer.py:257-269, optional fused consumers).
+//
+// GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = taps * channels.  Data path:
+//   * both operands are copied global -> LDS by the DMA path (global_load_lds_dwordx4, 16 B/lane, no VGPR round
+//     trip): activations per (tap, 64-channel K-step) with the im2col gather expressed in the per-lane SOURCE
+//     address — out-of-image taps read a 16-byte buffer of the "true zero" byte z', K-tail / M-tail lanes read
+//     zeros — and the LDS destination is lane-linear, so the XOR bank swizzle of the A tile is applied to the
+//     source chunk index (cdna_hip_programming.md §5.4 rule 21);
+//   * weights are pre-tiled at pack time (qd_pack_weights_t4 / _t8): one K-step x 32 output channels is a
+//     contiguous 1-KB (int4) / 2-KB (int8) block already in MFMA B-fragment order, so the B copy is a straight
+//     memcpy and the fragment read is one conflict-free ds_read_b64 / b128; RAW nibbles are unpacked at
+//     fragment-read time (the weight zero point is restored in the epilogue through activation row sums), so
+//     4-bit weights stay 4-bit all the way into LDS;
+//   * a 3-deep LDS ring keeps two K-steps in flight across the single barrier per step (counted
+//     s_waitcnt vmcnt(N), raw s_barrier).
+// Round-2 rewrite of the main loop and the epilogue (what the round-1 counters and ISA showed: 26 % MFMA-busy on
+// the long-K convolutions — every B fragment was read, waited for with lgkmcnt(0), unpacked and consumed before
+// the next read was issued, every DMA sat behind a scalar kernarg load and its own branch — and 4-byte-per-lane
+// epilogue traffic that made the short-K projections store-issue bound):
+//   * the K-step body is ONE basic block: the last two steps (which prefetch nothing) are peeled, all loader
+//     state lives in registers, a DMA costs ~6 VALU + 2 SALU and no branch, surplus B-tile DMAs of a wave
+//     re-copy a tile another wave also copies (same bytes, same destination) instead of being predicated;
+//   * fragments are software-pipelined: B fragments are read two MFMA groups ahead, the A fragments of the
+//     second K half while the first half is being contracted;
+//   * the epilogue goes through LDS: accumulators are dequantised in the MFMA C layout (one output channel per
+//     lane: per-channel constants are scalars of the lane), transposed through a per-wave 4-KB LDS tile, and
+//     leave row-major with 16 bytes per lane — residual / row-bias loads and output stores are 4x fewer, full
+//     128-byte row segments; int8 consumers (GEGLU, attention operand rows) store 4..16 bytes per lane instead of 1.
+// Block = 4 waves as WM x WN; wave tile = (32*MT) x (32*NT) of 32x32x32 MFMAs.
 #include "common.h"
 #include <type_traits>
 
 typedef __attribute__((address_space(3))) void* qd_lds_ptr;
-typedef const __attribute__((address_space(1))) void* qd_gbl_ptr;
 
 namespace {
 
@@ -32,7 +45,7 @@ struct SegD {
     int c0, clen, kstep0, nsteps_tap;
     const float*  scale;
     const int*    zc;
-    const int*    zw;       // [Cout] weight zero point (raw nibbles are the stored operand)
+    const int*    zw;       // [Cout] weight zero point of the stored operand (raw nibble: zw; s8 byte W-128: zw-128)
     const int*    zfill;
     const int8_t* fill16;
 };
@@ -48,8 +61,9 @@ struct ConvD {
     long ldx, ldo, ldr, ldrb;
     int B, H, W, Ho, Wo, Cout, kh, kw, stride, pad_t, pad_l;
     int M, taps, nseg, nblk_m, nblk_n, ntiles;
+    int vec;                  // 1: every row-major access of the epilogue may use 16-byte (4-element) vectors
     SegD seg[2];
-    const float* oq;          // O_GEGLU: {delta, zero_point} of the output quantiser
+    const float* oq;          // O_GEGLU / O_HROWS / O_HTR: {delta, zero_point} of the output quantiser
     float oqmin, oqmax;
     int   oqoff;
     int   it_per;             // O_PART: K-steps per split (blockIdx.y = split index)
@@ -74,22 +88,18 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// 16-byte-per-lane global -> LDS DMA, issued through inline asm ON PURPOSE: with the builtin, hipcc
-// cannot prove that the pending LDS writes do not alias the next ds_read and inserts
-// `s_waitcnt vmcnt(0)` in front of every K-step's first LDS read, which drains the whole ring
-// (seen in the ISA of the first version of this kernel).  An asm DMA is invisible to the compiler's
-// waitcnt bookkeeping; completion is tracked by hand (wait_vmcnt<N> + s_barrier below).
-// LDS destination = lds_base (wave-uniform, bytes) + lane*16; M0 is written in the same statement
-// that reads it and restored (cdna_hip_programming.md §5.7).
+// 16-byte-per-lane global -> LDS DMA, issued through inline asm ON PURPOSE: with the builtin, hipcc cannot prove
+// that the pending LDS writes do not alias the next ds_read and drains vmcnt(0) in front of every K-step's first
+// LDS read.  An asm DMA is invisible to the compiler's waitcnt bookkeeping; completion is tracked by hand
+// (wait_vmcnt<N> + s_barrier).  LDS destination = lds_base (wave-uniform, bytes) + lane*16; M0 is written in the
+// same statement that reads it (cdna_hip_programming.md §5.7).
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
-    // M0 is not live across statements in this kernel (no movrel / GWS / sendmsg / builtin LDS-DMA), so it is
-    // written and consumed inside the one statement and not restored.
     asm volatile(
         "s_mov_b32 m0, %1\n\t"
         "s_nop 0\n\t"
         "global_load_lds_dwordx4 %0, off"
         :
-        : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_base))
+        : "v"(gsrc), "s"(lds_base)
         : "memory");
 }
 
@@ -104,18 +114,23 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(qd_lds_ptr)(p);
 }
 
-// WB = weight bits of the tile-ordered operand: 4 (raw nibbles, 1 KB per K-step x 32 channels, qd_pack_weights_t4) or
-// 8 (s8 bytes W-128, 2 KB, qd_pack_weights_t8); everything but the B tile size and the fragment read is shared.
-template <int MT, int NT, bool SPLIT, int OUT, int WB>
-__global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const ConvD p) {
+__device__ __forceinline__ constexpr int crow(int r) { return (r & 3) + 8 * (r >> 2); }   // C-layout row of register r (+ 4*half)
+
+// WB = weight bits of the tile-ordered operand: 4 (raw nibbles, 1 KB per K-step x 32 channels) or 8 (s8 bytes W-128,
+// 2 KB); everything but the B tile size and the fragment read is shared.
+template <int MT, int NT, int WM, int WN, bool SPLIT, int OUT, int WB>
+__global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : 2) void igemm_kernel(const ConvD p) {
     static_assert(WB == 4 || WB == 8, "weight bits");
-    constexpr int BM = 128 * MT, BN = 32 * NT;
+    static_assert(WM * WN == 4, "four waves per block");
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, NTB = NT * WN;
     constexpr int TB = 256 * WB;                  // bytes of one (K-step, 32-channel) weight tile
-    constexpr int A_BYTES = BM * 64, B_BYTES = NT * TB;
+    constexpr int A_BYTES = BM * 64, B_BYTES = NTB * TB;
     constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int NA = 2 * MT;                    // A DMA instructions per wave per stage (16 rows each)
-    constexpr int NB = (NT * TB / 64 + 63) / 64;  // B DMA instructions per wave per stage (NT*TB/4 bytes per wave)
-    constexpr int PER = NA + NB;
+    constexpr int NA = BM / 64;                   // A DMA instructions per wave per stage (16 rows each)
+    constexpr int NBI = B_BYTES / 1024;           // B DMA instructions per stage, all waves together
+    constexpr int NBW = (NBI + 3) / 4;            // ... per wave (surplus ones duplicate the last instruction: same bytes)
+    constexpr int PER = NA + NBW;
+    constexpr int WCOLS = 32 * NT;                // columns of one wave
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE + 2 * BM * 4 + 4 * BN * 4];
     int* sRowB = reinterpret_cast<int*>(smem + 3 * STAGE);
@@ -129,6 +144,7 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
     const int frow = lane & 31, fhalf = lane >> 5;
 
     const int nblk    = p.nblk_m * p.nblk_n;
@@ -136,10 +152,11 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
     const int mb = logical / p.nblk_n, nb = logical % p.nblk_n;
     const int m0 = mb * BM, n0 = nb * BN;
 
-    // ---- loader rows: DMA instruction q covers tile rows q*16 .. q*16+15, lane -> (row, slot) ----
+    // ---- loader: DMA instruction q covers tile rows q*16 .. q*16+15, lane -> (row, 16-B slot) ----------------
     const int lr16 = lane >> 2, slot = lane & 3;
-    const int8_t* a_img[NA];                      // image origin (b, 0, 0, 0) of the row this lane feeds
-    int  a_ih0[NA], a_iw0[NA], a_chunk[NA];
+    const int a_chunk = (slot ^ ((lr16 >> 2) & 3)) * 16;   // source byte offset inside a 64-B K-step landing in this lane's slot
+    const int8_t* a_org[NA];                      // pixel (ho*stride - pad_t, wo*stride - pad_l) of this lane's row, + a_chunk
+    unsigned a_mask[NA];                          // bit t: tap t of that row lies inside the image
     bool a_valid[NA];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
@@ -151,36 +168,48 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
         const int b  = mm / HoWo;
         const int rem = mm - b * HoWo;
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-        a_img[i]   = p.x + (long)b * p.H * p.W * p.ldx;
-        a_ih0[i]   = ho * p.stride - p.pad_t;
-        a_iw0[i]   = wo * p.stride - p.pad_l;
-        a_chunk[i] = (slot ^ ((r >> 2) & 3)) * 16;   // source byte offset (within a 64-B K-step) landing in this lane's LDS slot
+        const int ih0 = ho * p.stride - p.pad_t, iw0 = wo * p.stride - p.pad_l;
+        a_org[i] = p.x + ((long)b * p.H * p.W + (long)ih0 * p.W + iw0) * p.ldx + a_chunk;
+        unsigned msk = 0;
+        for (int t = 0; t < p.taps; ++t) {
+            const int ih = ih0 + t / p.kw, iw = iw0 + t % p.kw;
+            if (a_valid[i] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) msk |= 1u << t;
+        }
+        a_mask[i] = msk;
         if (slot == 0) sRowB[r] = b;
     }
 
-    // ---- loader state (uniform) + per-lane running source pointers ------------------------------
+    // ---- loader state (uniform) + per-lane running source pointers -------------------------------------------
     int it_begin = 0;                             // first K-step of this block (split-K partials only)
     if constexpr (OUT == O_PART) it_begin = blockIdx.y * p.it_per;
     int ls = 0;
-    int ltap = it_begin / p.seg[0].nsteps_tap, lc = it_begin - ltap * p.seg[0].nsteps_tap;
+    int seg_c0 = p.seg[0].c0, seg_clen = p.seg[0].clen, seg_nst = p.seg[0].nsteps_tap;
+    const int8_t* zero16 = reinterpret_cast<const int8_t*>(qd_zero16);
+    const int8_t* seg_fill = p.seg[0].fill16 ? p.seg[0].fill16 : zero16;
+    int ltap = it_begin / seg_nst, lc = it_begin - ltap * seg_nst;
     int lrr = ltap / p.kw, lq = ltap - lrr * p.kw;
+    int krem = seg_clen - lc * 64;                // channels left in this tap from the next K-step on (>= 64: no K tail in it)
     const int8_t* a_cur[NA];                      // source of the NEXT K-step for DMA instruction i
     int           a_inc[NA];                      // 64 for real pixels, 0 for fill / zero sources
-    const uint8_t* b_cur = p.wt + ((long)(p.seg[0].kstep0 + it_begin) * p.ntiles + (long)nb * NT) * TB + wave * (NT * TB / 4) + lane * 16;
-    const long b_inc = (long)p.ntiles * TB;
-    const int8_t* zero16 = reinterpret_cast<const int8_t*>(qd_zero16);
-    bool b_ok[NB];                                // the last N-block may cover n-tiles that do not exist
+    const uint8_t* b_cur[NBW];
+    int            b_inc[NBW];
+    unsigned       b_dst[NBW];
 #pragma unroll
-    for (int r = 0; r < NB; ++r) b_ok[r] = nb * NT + (wave * (NT * TB / 4) + r * 1024 + lane * 16) / TB < p.ntiles;
+    for (int r = 0; r < NBW; ++r) {
+        const int bi = min(wave + 4 * r, NBI - 1);
+        const bool ok = nb * NTB + bi * 1024 / TB < p.ntiles;   // the last N-block may cover n-tiles that do not exist
+        b_cur[r] = ok ? p.wt + ((long)(p.seg[0].kstep0 + it_begin) * p.ntiles + (long)nb * NTB) * TB + bi * 1024 + lane * 16
+                      : reinterpret_cast<const uint8_t*>(zero16);
+        b_inc[r] = ok ? p.ntiles * TB : 0;
+        b_dst[r] = A_BYTES + bi * 1024;
+    }
 
     auto set_tap = [&]() __attribute__((always_inline)) {
-        const SegD& sg = p.seg[ls];
-        const int8_t* fill = sg.fill16 ? sg.fill16 : zero16;
+        const long tap_off = ((long)lrr * p.W + lq) * p.ldx + seg_c0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int ih = a_ih0[i] + lrr, iw = a_iw0[i] + lq;
-            const bool inb = a_valid[i] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            a_cur[i] = inb ? a_img[i] + ((long)ih * p.W + iw) * p.ldx + sg.c0 + a_chunk[i] : (a_valid[i] ? fill : zero16);
+            const bool inb = (a_mask[i] >> ltap) & 1u;
+            a_cur[i] = inb ? a_org[i] + tap_off : (a_valid[i] ? seg_fill : zero16);
             a_inc[i] = inb ? 64 : 0;
         }
     };
@@ -190,39 +219,58 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
         for (int i = 0; i < NA; ++i) a_cur[i] += lc * a_inc[i];
     }
 
-    // issue DMA instruction d of the current loader step into ring stage ST (compile-time LDS addresses)
-    auto issue_one = [&](unsigned stage_base, int d) __attribute__((always_inline)) {
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+
+    // DMA instruction d of the current loader step into the ring stage at byte offset `stage`
+    auto issue_one = [&](unsigned stage, int d) __attribute__((always_inline)) {
         if (d < NA) {
 #pragma unroll
             for (int i = 0; i < NA; ++i)
                 if (i == d) {
-                    const int8_t* src = a_cur[i];
                     // K tail: the last 64-wide step of a tap may run past the segment's channels
-                    if (lc * 64 + a_chunk[i] >= p.seg[ls].clen) src = zero16;
-                    glds16(src, stage_base + (wave + 4 * i) * 1024);
+                    const int8_t* src = a_chunk < krem ? a_cur[i] : zero16;
+                    glds16(src, lds0 + stage + (wave + 4 * i) * 1024);
                     a_cur[i] += a_inc[i];
                 }
         } else {
-            const int r = d - NA;
 #pragma unroll
-            for (int rr = 0; rr < NB; ++rr)
-                if (rr == r && rr * 64 + lane < NT * TB / 64)
-                    glds16(b_ok[rr] ? (const void*)(b_cur + rr * 1024) : (const void*)zero16,
-                           stage_base + A_BYTES + wave * (NT * TB / 4) + rr * 1024);
+            for (int r = 0; r < NBW; ++r)
+                if (r == d - NA) {
+                    glds16(b_cur[r], lds0 + stage + b_dst[r]);
+                    b_cur[r] += b_inc[r];
+                }
         }
     };
+    // Every K-step prefetches — past the end of the K range the sources are switched to the 16 zero bytes (the copies
+    // land in a ring stage nobody reads again), which keeps the K-step body free of "is there a step it+2" branches and
+    // the vmcnt bookkeeping uniform.
+    int lleft = 0;                                // K-steps the loader still has to issue (set below, once `total` is known)
     auto advance = [&]() __attribute__((always_inline)) {
-        b_cur += b_inc;
         ++lc;
-        if (lc == p.seg[ls].nsteps_tap) {
+        krem -= 64;
+        if (--lleft <= 0) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) { a_cur[i] = zero16; a_inc[i] = 0; }
+#pragma unroll
+            for (int r = 0; r < NBW; ++r) { b_cur[r] = reinterpret_cast<const uint8_t*>(zero16); b_inc[r] = 0; }
+            lc = -(1 << 30);                      // never reaches a tap boundary again
+            krem = 64;
+        } else if (lc == seg_nst) {
             lc = 0; ++ltap; ++lq;
             if (lq == p.kw) { lq = 0; ++lrr; }
-            if (ltap == p.taps) { ltap = 0; lrr = 0; lq = 0; ++ls; }
+            if (ltap == p.taps) {
+                ltap = 0; lrr = 0; lq = 0; ++ls;
+                if (ls < p.nseg) {
+                    seg_c0 = p.seg[1].c0; seg_clen = p.seg[1].clen; seg_nst = p.seg[1].nsteps_tap;
+                    seg_fill = p.seg[1].fill16 ? p.seg[1].fill16 : zero16;
+                }
+            }
+            krem = seg_clen;
             if (ls < p.nseg) set_tap();
         }
     };
 
-    // ---- accumulators ---------------------------------------------------------------------------
+    // ---- accumulators ------------------------------------------------------------------------------------
     v16i acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -243,11 +291,12 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
 #pragma unroll
     for (int i = 0; i < MT; ++i) asum[i] = 0;
 
+    const int wrow0 = wm * (32 * MT);             // first tile row of this wave
     auto publish_asum = [&]() __attribute__((always_inline)) {                 // row sums of this wave's rows -> LDS (both k-halves combined)
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             int v = asum[i] + __shfl_xor(asum[i], 32);
-            if (fhalf == 0) sAsum[wave * (32 * MT) + i * 32 + frow] = v;
+            if (fhalf == 0) sAsum[wrow0 + i * 32 + frow] = v;               // waves sharing rows (WN > 1) write identical values
             asum[i] = 0;
         }
     };
@@ -255,18 +304,18 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
     const int nst0  = p.taps * p.seg[0].nsteps_tap;
     const int total_all = nst0 + (p.nseg == 2 ? p.taps * p.seg[1].nsteps_tap : 0);
     const int total = OUT == O_PART ? min(p.it_per, total_all - it_begin) : total_all;
-    const unsigned lds0 = lds_addr(smem);
+    lleft = total;
 
     // lane-invariant fragment offsets inside a stage
-    int a_off[MT][2];
+    unsigned a_off[MT][2];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int row = wave * (32 * MT) + i * 32 + frow;
+            const int row = wrow0 + i * 32 + frow;
             a_off[i][ks] = row * 64 + (((ks * 2 + fhalf) ^ ((row >> 2) & 3)) * 16);
         }
-    const int b_off = (fhalf * 32 + frow) * (WB * 2);   // + ks*(TB/2) + j*TB
+    const unsigned b_off = A_BYTES + wn * NT * TB + (fhalf * 32 + frow) * (WB * 2);   // + ks*(TB/2) + j*TB
 
     float pr_scale = 0.f, pr_bias = 0.f;
     int   pr_zc = 0, pr_zw = 0;
@@ -281,15 +330,13 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
         }
     }
 
-    // ---- prologue: two stages in flight ----------------------------------------------------------
+    // ---- prologue: two stages in flight ------------------------------------------------------------------------
 #pragma unroll
-    for (int d = 0; d < PER; ++d) issue_one(lds0, d);
+    for (int d = 0; d < PER; ++d) issue_one(0, d);
     advance();
-    if (total > 1) {
 #pragma unroll
-        for (int d = 0; d < PER; ++d) issue_one(lds0 + STAGE, d);
-        advance();
-    }
+    for (int d = 0; d < PER; ++d) issue_one(STAGE, d);
+    advance();
     if ((int)threadIdx.x < BN) {                       // visible to every wave after the main loop's barriers
         sScale[threadIdx.x] = pr_scale;
         sZc[threadIdx.x]    = pr_zc;
@@ -304,7 +351,7 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
         const int kz = sg.zfill ? sg.zfill[1] : 0;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int n = n0 + j * 32 + frow;
+            const int n = n0 + wn * WCOLS + j * 32 + frow;
             const bool nok = n < p.Cout;
             const float sc = nok ? sg.scale[n] : 0.f;
             const int zc_n = (nok && sg.zc) ? sg.zc[n] : 0;
@@ -313,7 +360,7 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int rowl = wave * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                    const int rowl = wrow0 + i * 32 + crow(r) + 4 * fhalf;
                     const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rowl] - kz);
                     facc[SPLIT ? i : 0][SPLIT ? j : 0][r] = (float)I * sc;
                     acc[i][j][r] = 0;
@@ -322,277 +369,381 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void igemm_dma_kernel(const Con
         __syncthreads();                               // sAsum is reused by the second segment
     };
 
-    // one K-step on ring stage ST (compile-time), prefetching step it+2 into stage (ST+2)%3
-    auto step = [&](auto st_tag, int it) __attribute__((always_inline)) {
-        constexpr int ST = decltype(st_tag)::value;
-        constexpr int PST = (ST + 2) % 3;
-        if (it + 1 < total) wait_vmcnt<PER>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();                  // stage ST landed for every wave; stage ST-1 fully consumed
-        const bool prefetch = it + 2 < total;
-        const unsigned char* cA = smem + ST * STAGE;
-        const unsigned char* cB = cA + A_BYTES;
-        int dslot = 0;
+    // ---- one K-step on the ring stage at byte offset `cur`, prefetching step it+2 into the stage at `nxt` ------------
+    typedef typename std::conditional<WB == 4, uint2, v4i>::type braw_t;
+    auto step = [&](unsigned cur, unsigned nxt) __attribute__((always_inline)) {
+        wait_vmcnt<PER>();
+        __builtin_amdgcn_s_barrier();                  // stage `cur` landed for every wave; the stage before it is fully consumed
+        const unsigned char* cS = smem + cur;
+        constexpr int S = 2 * NT;                      // (k-half, n-tile) MFMA groups of this step
+        auto bread = [&](int s) __attribute__((always_inline)) {
+            return *reinterpret_cast<const braw_t*>(cS + b_off + (s / NT) * (TB / 2) + (s % NT) * TB);
+        };
+        v4i af[2][MT];
+        braw_t raw[S];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            v4i af[MT];
+        for (int i = 0; i < MT; ++i) af[0][i] = *reinterpret_cast<const v4i*>(cS + a_off[i][0]);
+        raw[0] = bread(0);
+        raw[1] = bread(1);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                af[i] = *reinterpret_cast<const v4i*>(cA + a_off[i][ks]);
-                asum[i] += bytesum16(af[i]);
+        for (int s = 0; s < S; ++s) {
+            const int ks = s / NT, j = s % NT;
+            // software pipeline: the B fragment of group s+2 and (once) the A fragments of the second K half are read
+            // here, two MFMA groups ahead of their use; the scheduling barrier keeps the compiler from sinking the reads
+            // back next to their consumers (which is what it does to save registers, exposing the LDS latency)
+            if (s + 2 < S) raw[s + 2] = bread(s + 2);
+            if (s == (NT >= 2 ? NT - 2 : 0)) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) af[1][i] = *reinterpret_cast<const v4i*>(cS + a_off[i][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            v4i bf;
+            if constexpr (WB == 4) {
+                bf = v4i{(int)(raw[s].x & 0x0F0F0F0Fu), (int)((raw[s].x >> 4) & 0x0F0F0F0Fu),
+                         (int)(raw[s].y & 0x0F0F0F0Fu), (int)((raw[s].y >> 4) & 0x0F0F0F0Fu)};
+            } else {
+                bf = raw[s];
             }
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                v4i bf;
-                if constexpr (WB == 4) {
-                    const uint2 pk = *reinterpret_cast<const uint2*>(cB + b_off + ks * (TB / 2) + j * TB);
-                    bf = v4i{(int)(pk.x & 0x0F0F0F0Fu), (int)((pk.x >> 4) & 0x0F0F0F0Fu),
-                             (int)(pk.y & 0x0F0F0F0Fu), (int)((pk.y >> 4) & 0x0F0F0F0Fu)};
-                } else {
-                    bf = *reinterpret_cast<const v4i*>(cB + b_off + ks * (TB / 2) + j * TB);
-                }
+            for (int i = 0; i < MT; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks][i], bf, acc[i][j], 0, 0, 0);
+            if (j == 0) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf, acc[i][j], 0, 0, 0);
-                if (dslot < PER) { if (prefetch) issue_one(lds0 + PST * STAGE, dslot); }
-                ++dslot;
+                for (int i = 0; i < MT; ++i) asum[i] += bytesum16(af[ks][i]);
             }
+            if (s < PER) issue_one(nxt, s);
         }
-        if (prefetch) {
 #pragma unroll
-            for (int d = 2 * NT; d < PER; ++d) issue_one(lds0 + PST * STAGE, d);
-            advance();
-        }
-        if (SPLIT && p.nseg == 2 && it == nst0 - 1) flush_segment0();
+        for (int d = S; d < PER; ++d) issue_one(nxt, d);
+        advance();
     };
 
-    for (int it = 0; it < total; it += 3) {
-        step(std::integral_constant<int, 0>{}, it);
-        if (it + 1 < total) step(std::integral_constant<int, 1>{}, it + 1);
-        if (it + 2 < total) step(std::integral_constant<int, 2>{}, it + 2);
+    {
+        unsigned cur = 0, nxt = 2 * STAGE;
+        for (int it = 0; it < total; ++it) {
+            step(cur, nxt);
+            if (SPLIT && p.nseg == 2 && it == nst0 - 1) flush_segment0();
+            nxt = cur;
+            cur = cur == 2 * STAGE ? 0 : cur + STAGE;
+        }
+        wait_vmcnt<0>();                               // the last two steps' dummy prefetches: the ring is reused below
     }
 
-    // ---- epilogue --------------------------------------------------------------------------------
+    // ---- epilogue ----------------------------------------------------------------------------------------------
     publish_asum();
-    __syncthreads();                                   // sAsum / sRowB visible to every wave
+    __syncthreads();                                   // sAsum / sRowB visible to every wave; the ring is dead from here on
     const SegD& sg = p.seg[p.nseg - 1];
     const int kz = sg.zfill ? sg.zfill[1] : 0;
-    // Addressing: every global access of the epilogue is (uniform 64-bit base of this block) + (32-bit lane
-    // offset), and the 16 rows a lane owns differ by compile-time multiples of the row stride, so an element
-    // costs one v_add_u32 instead of a 64-bit multiply-add.  zw * Asum uses the 24-bit multiplier (both
-    // factors fit: |zw| <= 128, |Asum - kz| <= 2 * 128 * K < 2^23, checked on the host).
+    // Per-wave transposition tile (the ring is dead): 32 rows x 32 dwords.  Phase 1 writes one MFMA tile in the C layout
+    // (lane = column, 16 rows per lane: conflict-free ds_write_b32), phase 2 reads it back row-major, 16 B per lane:
+    // lane -> (row = pass*8 + lane/8, 4 columns from (lane%8)*4); zw * Asum uses the 24-bit multiplier (both factors
+    // fit: |zw| <= 128, |Asum - kz| <= 2 * 128 * K < 2^23, checked on the host).
+    unsigned* tb = reinterpret_cast<unsigned*>(smem + wave * 4096);
+    const int rr0 = lane >> 3, c4 = (lane & 7) * 4;
+    const int wcol0 = n0 + wn * WCOLS;                 // first global column of this wave
+
     if constexpr (OUT == O_GEGLU) {
-        // weight rows were packed (value tile, gate tile) interleaved: tiles 2jp / 2jp+1 of this lane hold
-        // the value and the gate of output feature nb*(BN/2) + jp*32 + frow.  y = value * gelu(gate)
-        // (erf GELU, ldm/modules/attention.py:42-44), then the next Linear's act quantiser, 1 byte out.
+        // weight rows were packed (value tile, gate tile) interleaved: tiles 2jp / 2jp+1 of this lane hold the value
+        // and the gate of output feature (wcol0/2) + jp*32 + frow.  y = value * gelu(gate) (erf GELU,
+        // ldm/modules/attention.py:42-44), then the next Linear's act quantiser; bytes leave 16 per lane.
         static_assert(NT % 2 == 0, "GEGLU epilogue pairs n-tiles");
+        constexpr int ROWB = 16 * NT;                  // output bytes per row of this wave
+        constexpr int LPR = ROWB / 16;                 // lanes per row in phase 2
+        constexpr int RPP = 64 / LPR;                  // rows per pass
         const float od = p.oq[0], oz = p.oq[1];
-        int8_t* o8 = reinterpret_cast<int8_t*>(p.out) + (long)m0 * p.ldo + nb * (BN / 2);
-        const unsigned ldo = (unsigned)p.ldo;
+        int8_t* tb8 = reinterpret_cast<int8_t*>(tb);   // [32 rows][ROWB]  (<= 4 KB for NT <= 8)
         const int Fout = p.Cout >> 1;
+        const int f0 = (wcol0 >> 1);                   // first output feature of this wave
+        int8_t* o8 = reinterpret_cast<int8_t*>(p.out) + f0;
 #pragma unroll
-        for (int jp = 0; jp < NT / 2; ++jp) {
-            const int lv = (2 * jp) * 32 + frow, lg = lv + 32;            // tile-local channel of value / gate
-            const int cl = jp * 32 + frow;
-            const bool ok = nb * (BN / 2) + cl < Fout && n0 + lg < p.Cout;
-            const float sv = sScale[lv], sgt = sScale[lg];
-            const int zcv = sZc[lv], zcg = sZc[lg];
-            const int zwv = sZw[lv], zwg = sZw[lg];
-            const float bv = sBias[lv], bg = sBias[lg];
+        for (int i = 0; i < MT; ++i) {
+            const int rbase = wrow0 + i * 32;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int rbase = wave * (32 * MT) + i * 32 + 4 * fhalf;
-                const unsigned o0 = (unsigned)rbase * ldo + cl;
+            for (int jp = 0; jp < NT / 2; ++jp) {
+                const int lv = wn * WCOLS + (2 * jp) * 32 + frow, lg = lv + 32;     // tile-local channel of value / gate
+                const float sv = sScale[lv], sgt = sScale[lg];
+                const int zcv = sZc[lv], zcg = sZc[lg];
+                const int zwv = sZw[lv], zwg = sZw[lg];
+                const float bv = sBias[lv], bg = sBias[lg];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int cr = (r & 3) + 8 * (r >> 2);
-                    const int rowl = rbase + cr;
-                    const int as = sAsum[rowl] - kz;
+                    const int rl = crow(r) + 4 * fhalf;
+                    const int as = sAsum[rbase + rl] - kz;
                     const float val = (float)(acc[i][2 * jp][r] - zcv - __mul24(zwv, as)) * sv + bv;
                     const float gate = (float)(acc[i][2 * jp + 1][r] - zcg - __mul24(zwg, as)) * sgt + bg;
                     const float y = val * (0.5f * gate * (1.0f + qd_erff(gate * 0.70710678118654752440f)));
-                    const int8_t code = (int8_t)(qd_code(y, od, oz, p.oqmin, p.oqmax) - p.oqoff);
-                    if (ok && m0 + rowl < p.M) o8[o0 + (unsigned)cr * ldo] = code;      // only the store is predicated
+                    tb8[rl * ROWB + jp * 32 + frow] = (int8_t)(qd_code(y, od, oz, p.oqmin, p.oqmax) - p.oqoff);
+                }
+            }
+#pragma unroll
+            for (int ps = 0; ps < 32 / RPP; ++ps) {
+                const int rl = ps * RPP + lane / LPR, cb = (lane % LPR) * 16;
+                const v4i v = *reinterpret_cast<const v4i*>(tb8 + rl * ROWB + cb);
+                const long m = m0 + rbase + rl;
+                if (m < p.M && f0 + cb < Fout) *reinterpret_cast<v4i*>(o8 + m * p.ldo + cb) = v;
+            }
+        }
+        return;
+    }
+    if constexpr (OUT == O_HROWS) {
+        // rows m = b*T + t, columns n = h*d + dd (d % 4 == 0).  The host guarantees T % BM == 0 and M % T == 0: a block
+        // lies inside one sample and has no ragged rows.  Pad bytes (dd >= d) are never written: the operand buffers are
+        // zero-initialised once and reused.  Phase 1 writes the fp32 projection, phase 2 adds the optional fp32 residual
+        // (H = 1, d = Cout turns this epilogue into "Linear + residual -> the next Linear's int8 rows": the FF output of
+        // a transformer block feeding SpatialTransformer.proj_out), quantises and stores 4 codes per lane.
+        const float od = p.oq[0], oz = p.oq[1];
+        int8_t* o8 = reinterpret_cast<int8_t*>(p.out);
+        const int bidx = m0 / p.hdT, t0 = m0 - bidx * p.hdT;
+        const bool hres = p.residual != nullptr;
+        const float* rf = reinterpret_cast<const float*>(p.residual);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int cl = wn * WCOLS + j * 32 + frow;
+            const float sc = sScale[cl];
+            const int zc_n = sZc[cl], zw_n = sZw[cl];
+            const float bias_n = sBias[cl];
+            const int n4 = wcol0 + j * 32 + c4;        // first of this lane's 4 columns in phase 2
+            const bool nok = n4 < p.Cout;
+            const int nn = nok ? n4 : 0;
+            const int h = nn / p.hdd, dd = nn - h * p.hdd;
+            int8_t* ob = o8 + (((long)bidx * p.hdH + h) * p.hdTpad + t0) * p.hddpad + dd;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int rbase = wrow0 + i * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = crow(r) + 4 * fhalf;
+                    const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rbase + rl] - kz);
+                    tb[rl * 32 + frow] = __float_as_uint((float)I * sc + bias_n);
+                }
+                v4f rs[4];
+                if (hres) {
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps)
+                        rs[ps] = *reinterpret_cast<const v4f*>(rf + (long)(m0 + rbase + ps * 8 + rr0) * p.ldr + nn);
+                }
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int rl = ps * 8 + rr0;
+                    v4f v = *reinterpret_cast<const v4f*>(tb + rl * 32 + c4);
+                    if (hres) v += rs[ps];
+                    unsigned w = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        w |= (unsigned)((qd_code(v[e] * p.oqpre, od, oz, p.oqmin, p.oqmax) - p.oqoff) & 0xff) << (8 * e);
+                    if (nok) *reinterpret_cast<unsigned*>(ob + (long)(rbase + rl) * p.hddpad) = w;
                 }
             }
         }
         return;
     }
-    if constexpr (OUT == O_HROWS || OUT == O_HTR) {
-        // rows m = b*T + t, columns n = h*d + dd.  The host guarantees T % BM == 0 and M % T == 0: a block
-        // lies inside one sample and has no ragged rows.  Pad bytes (dd >= d) are never written: the operand
-        // buffers are zero-initialised once and reused.
+    if constexpr (OUT == O_HTR) {
         const float od = p.oq[0], oz = p.oq[1];
         int8_t* o8 = reinterpret_cast<int8_t*>(p.out);
         const int bidx = m0 / p.hdT, t0 = m0 - bidx * p.hdT;
-        int* sPart = reinterpret_cast<int*>(smem);            // [4][BN] column-sum partials (the ring is dead by now)
+        int* sPart = reinterpret_cast<int*>(smem);            // [4][WCOLS] column-sum partials (the ring is dead by now)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int cl = j * 32 + frow;
+            const int cl = wn * WCOLS + j * 32 + frow;
             const bool nok = n0 + cl < p.Cout;
             const int nn = nok ? n0 + cl : 0;
             const int h = nn / p.hdd, dd = nn - h * p.hdd;
             const float sc = sScale[cl];
-            const int zc_n = sZc[cl];
-            const int zw_n = sZw[cl];
+            const int zc_n = sZc[cl], zw_n = sZw[cl];
             const float bias_n = sBias[cl];
-            if constexpr (OUT == O_HROWS) {
-                int8_t* ob = o8 + (((long)bidx * p.hdH + h) * p.hdTpad + t0) * p.hddpad + dd;
-                // optional fp32 residual (H = 1, d = Cout turns this epilogue into "Linear + residual -> the next
-                // Linear's int8 rows": the FF output of a transformer block feeding SpatialTransformer.proj_out)
-                const bool hres = p.residual != nullptr;
-                const float* rfh = reinterpret_cast<const float*>(p.residual) + (long)m0 * p.ldr + n0;
+            int8_t* ob = o8 + (((long)bidx * p.hdH + h) * p.hddpad + dd) * p.hdTpad + t0 + fhalf * 16;
+            int csum = 0;
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int rbase = wave * (32 * MT) + i * 32 + 4 * fhalf;
-                    float rs[16];
-                    if (hres) {
-                        const unsigned r0 = (unsigned)rbase * (unsigned)p.ldr + (nok ? cl : 0);
+            for (int i = 0; i < MT; ++i) {
+                const int tile0 = wrow0 + i * 32;      // first row of this 32-key tile inside the block
+                v4i pk;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) rs[r] = rfh[r0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.ldr];
-                    }
+                for (int g = 0; g < 4; ++g) {
+                    unsigned w = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rowl = rbase + (r & 3) + 8 * (r >> 2);
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        const int rowl = tile0 + 4 * fhalf + crow(r);
                         const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rowl] - kz);
-                        float v = (float)I * sc + bias_n;
-                        if (hres) v += rs[r];
-                        const int8_t code = (int8_t)(qd_code(v * p.oqpre, od, oz, p.oqmin, p.oqmax) - p.oqoff);
-                        if (nok) ob[(unsigned)rowl * (unsigned)p.hddpad] = code;
+                        const float v = (float)I * sc + bias_n;
+                        const int code = qd_code(v * p.oqpre, od, oz, p.oqmin, p.oqmax) - p.oqoff;
+                        csum += code;
+                        w |= (unsigned)(code & 0xff) << (8 * e);
                     }
+                    pk[g] = (int)w;
                 }
-            } else {
-                int8_t* ob = o8 + (((long)bidx * p.hdH + h) * p.hddpad + dd) * p.hdTpad + t0 + fhalf * 16;
-                int csum = 0;
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int tile0 = wave * (32 * MT) + i * 32;   // first row of this 32-key tile inside the block
-                    v4i pk;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        unsigned w = 0;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int r = 4 * g + e;
-                            const int rowl = tile0 + 4 * fhalf + (r & 3) + 8 * (r >> 2);
-                            const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rowl] - kz);
-                            const float v = (float)I * sc + bias_n;
-                            const int code = qd_code(v * p.oqpre, od, oz, p.oqmin, p.oqmax) - p.oqoff;
-                            csum += code;
-                            w |= (unsigned)(code & 0xff) << (8 * e);
-                        }
-                        pk[g] = (int)w;
-                    }
-                    // key slot p = half*16 + r  <->  key (r&3) + 8*(r>>2) + 4*half of the tile (attn_i8.hip): the
-                    // MFMA C layout IS the permuted order, so a lane's 16 codes are 16 contiguous bytes
-                    if (nok) *reinterpret_cast<v4i*>(ob + tile0) = pk;
-                }
-                csum += __shfl_xor(csum, 32);
-                if (fhalf == 0) sPart[wave * BN + cl] = nok ? csum : 0;
+                // key slot p = half*16 + r  <->  key (r&3) + 8*(r>>2) + 4*half of the tile (attn_i8.hip): the
+                // MFMA C layout IS the permuted order, so a lane's 16 codes are 16 contiguous bytes
+                if (nok) *reinterpret_cast<v4i*>(ob + tile0) = pk;
             }
+            csum += __shfl_xor(csum, 32);
+            if (fhalf == 0) sPart[wave * WCOLS + j * 32 + frow] = nok ? csum : 0;
         }
-        if constexpr (OUT == O_HTR) {
-            __syncthreads();
-            const int c = threadIdx.x;
-            if (c < BN && n0 + c < p.Cout) {
-                const int tot = sPart[c] + sPart[BN + c] + sPart[2 * BN + c] + sPart[3 * BN + c];
-                const int n = n0 + c, h = n / p.hdd, dd = n - h * p.hdd;
-                atomicAdd(&p.hdsum[((long)bidx * p.hdH + h) * p.hddpad + dd], tot);
-            }
+        __syncthreads();
+        const int c = threadIdx.x;
+        if (c < BN && n0 + c < p.Cout) {
+            const int wnc = c / WCOLS, cw = c - wnc * WCOLS;
+            int tot = 0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) tot += sPart[(w * WN + wnc) * WCOLS + cw];
+            const int n = n0 + c, h = n / p.hdd, dd = n - h * p.hdd;
+            atomicAdd(&p.hdsum[((long)bidx * p.hdH + h) * p.hddpad + dd], tot);
         }
         return;
     }
-    // Branch-free per 32x32 tile: out-of-range rows/columns are handled by CLAMPING the offsets of the
-    // residual / row-bias loads (and predicating only the stores), so the 16 loads of a tile are issued
-    // back to back.  (With a per-element `if (...) continue;` every load sat in its own basic block and the
-    // epilogue paid one memory latency per element: layers with a residual ran 2-3x slower.)
+
+    // ---- linear epilogues: fp32 / fp16 rows, raw int32 (test hook), split-K partials ----------------------------------------
+    constexpr bool INT_OUT = OUT == O_PART || OUT == O_I32;
     const bool has_rb = p.rowbias != nullptr, has_res = p.residual != nullptr;
-    const unsigned ldo = (unsigned)p.ldo, ldr = (unsigned)p.ldr, ldc = (unsigned)p.Cout;
-    float*  const of = reinterpret_cast<float*>(p.out) + (long)m0 * p.ldo + n0;
-    __half* const oh = reinterpret_cast<__half*>(p.out) + (long)m0 * p.ldo + n0;
-    const float*  const rf = reinterpret_cast<const float*>(p.residual) + (long)m0 * p.ldr + n0;
-    const __half* const rh = reinterpret_cast<const __half*>(p.residual) + (long)m0 * p.ldr + n0;
-    int32_t* const oi = p.iout + ((OUT == O_PART ? (long)blockIdx.y * p.M : 0L) + m0) * p.Cout + n0;
-    // optional GroupNorm statistics of the tensor being written (consumed by qd_groupnorm_silu_quant instead of
-    // its own pass over HBM): per-column partials in registers -> cross-half shuffle -> fixed-order LDS reduction
-    // over the waves of each 128-row chunk -> one {sum, sumsq} pair per (chunk, channel).  Deterministic.
+    const bool vec = p.vec != 0;
+    float*  const of = reinterpret_cast<float*>(p.out);
+    __half* const oh = reinterpret_cast<__half*>(p.out);
+    const float*  const rf = reinterpret_cast<const float*>(p.residual);
+    const __half* const rh = reinterpret_cast<const __half*>(p.residual);
+    int32_t* const oi = p.iout + (OUT == O_PART ? (long)blockIdx.y * p.M * p.Cout : 0L);
+    // optional GroupNorm statistics of the tensor being written (consumed by qd_groupnorm_silu_quant instead of its own
+    // pass over HBM): per-column partials of the lane's rows -> butterfly over the 8 lanes that share the columns ->
+    // fixed-order LDS reduction over the waves of each 128-row chunk -> one {sum, sumsq} pair per (chunk, channel).
     const bool gn = OUT == O_F32 && p.gnpart != nullptr;
-    float* sGn = reinterpret_cast<float*>(smem);          // [4 waves][BN][2]  (the ring is dead by now)
+    float* sGn = reinterpret_cast<float*>(smem + 4 * 4096);       // [4 waves][WCOLS][2], behind the transposition tiles
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int cl = j * 32 + frow;
-        const bool nok = n0 + cl < p.Cout;
-        const int clc = nok ? cl : 0;
-        float gs = 0.f, gq = 0.f;
+        const int cl = wn * WCOLS + j * 32 + frow;
         const float sc = sScale[cl];
-        const int zc_n = sZc[cl];
-        const int zw_n = sZw[cl];
+        const int zc_n = sZc[cl], zw_n = sZw[cl];
         const float bias_n = sBias[cl];
+        const int n4 = wcol0 + j * 32 + c4;            // this lane's 4 columns in phase 2
+        const bool nok4 = n4 + 3 < p.Cout;             // all four exist (the vector path); else per element
+        const int n4c = n4 < p.Cout ? n4 : 0;
+        float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const int rbase = wave * (32 * MT) + i * 32 + 4 * fhalf;        // rowl = rbase + (r&3) + 8*(r>>2)
-            if constexpr (OUT == O_PART || OUT == O_I32) {
-                const unsigned o0 = (unsigned)rbase * ldc + cl;
+            const int rbase = wrow0 + i * 32;
+            // phase 1: dequantise in the C layout, park the tile in LDS
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int cr = (r & 3) + 8 * (r >> 2);
-                    const int rowl = rbase + cr;
-                    const int v = OUT == O_PART ? acc[i][j][r] - __mul24(zw_n, sAsum[rowl])
-                                                : acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rowl] - kz);
-                    if (nok && m0 + rowl < p.M) oi[o0 + (unsigned)cr * ldc] = v;
-                }
-            } else {
-                float rb[16], rs[16];
-                if (has_rb) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) rb[r] = p.rowbias[(long)sRowB[rbase + (r & 3) + 8 * (r >> 2)] * p.ldrb + n0 + clc];
-                }
-                if (has_res) {
-                    const unsigned r0 = (unsigned)rbase * ldr + clc;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int cr = (r & 3) + 8 * (r >> 2);
-                        const unsigned off = (m0 + rbase + cr < p.M) ? r0 + (unsigned)cr * ldr : (unsigned)clc;   // row m0 always exists
-                        if (OUT == O_F32) rs[r] = rf[off];
-                        else rs[r] = __half2float(rh[off]);
-                    }
-                }
-                const unsigned o0 = (unsigned)rbase * ldo + cl;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int cr = (r & 3) + 8 * (r >> 2);
-                    const int rowl = rbase + cr;
-                    const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rowl] - kz);
+            for (int r = 0; r < 16; ++r) {
+                const int rl = crow(r) + 4 * fhalf;
+                if constexpr (INT_OUT) {
+                    const int v = OUT == O_PART ? acc[i][j][r] - __mul24(zw_n, sAsum[rbase + rl])
+                                                : acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rbase + rl] - kz);
+                    tb[rl * 32 + frow] = (unsigned)v;
+                } else {
+                    const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rbase + rl] - kz);
                     float v = (float)I * sc;
                     if (SPLIT) v += facc[SPLIT ? i : 0][SPLIT ? j : 0][r];
-                    v += bias_n;
-                    if (has_rb) v += rb[r];
-                    if (has_res) v += rs[r];
-                    if (nok && m0 + rowl < p.M) {
-                        if (OUT == O_F32) of[o0 + (unsigned)cr * ldo] = v;
-                        else oh[o0 + (unsigned)cr * ldo] = __float2half(v);
-                        if (gn) { gs += v; gq += v * v; }
+                    tb[rl * 32 + frow] = __float_as_uint(v + bias_n);
+                }
+            }
+            // phase 2: row-major, 4 columns per lane
+            if constexpr (INT_OUT) {
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int rl = ps * 8 + rr0;
+                    const long m = m0 + rbase + rl;
+                    const v4i v = *reinterpret_cast<const v4i*>(tb + rl * 32 + c4);
+                    if (m < p.M) {
+                        int32_t* dst = oi + m * p.Cout + n4;
+                        if (vec && nok4) *reinterpret_cast<v4i*>(dst) = v;
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (n4 + e < p.Cout) dst[e] = v[e];
+                        }
+                    }
+                }
+            } else {
+                v4f rb[4], rs[4];
+                long mrow[4];
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int rl = ps * 8 + rr0;
+                    const long m = m0 + rbase + rl;
+                    mrow[ps] = m < p.M ? m : m0;       // row m0 always exists: loads are clamped, only stores predicated
+                    if (has_rb) {
+                        const float* src = p.rowbias + (long)sRowB[rbase + rl] * p.ldrb + n4c;
+                        if (vec && nok4) rb[ps] = *reinterpret_cast<const v4f*>(src);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) rb[ps][e] = n4 + e < p.Cout ? src[e] : 0.f;
+                        }
+                    }
+                    if (has_res) {
+                        if (OUT == O_F32) {
+                            const float* src = rf + mrow[ps] * p.ldr + n4c;
+                            if (vec && nok4) rs[ps] = *reinterpret_cast<const v4f*>(src);
+                            else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) rs[ps][e] = n4 + e < p.Cout ? src[e] : 0.f;
+                            }
+                        } else {
+                            const __half* src = rh + mrow[ps] * p.ldr + n4c;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) rs[ps][e] = n4 + e < p.Cout ? __half2float(src[e]) : 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int rl = ps * 8 + rr0;
+                    const bool mok = m0 + rbase + rl < p.M;
+                    v4f v = *reinterpret_cast<const v4f*>(tb + rl * 32 + c4);
+                    if (has_rb) v += rb[ps];
+                    if (has_res) v += rs[ps];
+                    if (mok) {
+                        if (OUT == O_F32) {
+                            float* dst = of + mrow[ps] * p.ldo + n4;
+                            if (vec && nok4) *reinterpret_cast<v4f*>(dst) = v;
+                            else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) if (n4 + e < p.Cout) dst[e] = v[e];
+                            }
+                        } else {
+                            __half* dst = oh + mrow[ps] * p.ldo + n4;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (n4 + e < p.Cout) dst[e] = __float2half(v[e]);
+                        }
+                        if (gn) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
+                        }
                     }
                 }
             }
         }
         if (gn) {
-            gs += __shfl_xor(gs, 32);
-            gq += __shfl_xor(gq, 32);
-            if (fhalf == 0) { sGn[(wave * BN + cl) * 2] = gs; sGn[(wave * BN + cl) * 2 + 1] = gq; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int sh = 8; sh < 64; sh <<= 1) {
+                    gs[e] += __shfl_xor(gs[e], sh);
+                    gq[e] += __shfl_xor(gq[e], sh);
+                }
+            }
+            if (lane < 8) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sGn[(wave * WCOLS + j * 32 + c4 + e) * 2] = gs[e];
+                    sGn[(wave * WCOLS + j * 32 + c4 + e) * 2 + 1] = gq[e];
+                }
+            }
         }
     }
     if (gn) {
         __syncthreads();
         const int c = threadIdx.x;
         if (c < BN && n0 + c < p.Cout) {
-            constexpr int WPC = 4 / MT;                       // waves per 128-row chunk
+            constexpr int WPC = 4 / MT;                       // waves (along M) per 128-row chunk
+            const int wnc = c / WCOLS, cw = c - wnc * WCOLS;
 #pragma unroll
-            for (int ch = 0; ch < MT; ++ch) {
+            for (int ch = 0; ch < BM / 128; ++ch) {
                 const int mrow = m0 + ch * 128;
                 if (mrow >= p.M) break;
                 float ts = 0.f, tq = 0.f;
 #pragma unroll
-                for (int w = 0; w < WPC; ++w) { ts += sGn[((ch * WPC + w) * BN + c) * 2]; tq += sGn[((ch * WPC + w) * BN + c) * 2 + 1]; }
+                for (int w = 0; w < WPC; ++w) {
+                    const int wv = (ch * WPC + w) * WN + wnc;
+                    ts += sGn[(wv * WCOLS + cw) * 2];
+                    tq += sGn[(wv * WCOLS + cw) * 2 + 1];
+                }
                 const int b = mrow / HoWo, chunk = (mrow - b * HoWo) >> 7;
                 float* dst = p.gnpart + (((long)b * p.gn_nchunk + chunk) * p.Cout + n0 + c) * 2;
                 dst[0] = ts;
@@ -728,34 +879,35 @@ __global__ __launch_bounds__(256) void pack_t8_kernel(const float* __restrict__ 
     if (wsum && sum != 0) atomicAdd(&wsum[n], sum);
 }
 
-template <int MT, int NT, int WB = 4>
+// tile shapes (MT, NT, WM, WN): block = (32*MT*WM) x (32*NT*WN)
+template <int MT, int NT, int WM, int WN, int WB = 4>
 int dispatch(ConvD& k, bool split, int out, hipStream_t st, int nsplit = 1) {
-    constexpr int BM = 128 * MT, BN = 32 * NT;
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     k.nblk_m = (k.M + BM - 1) / BM;
     k.nblk_n = (k.Cout + BN - 1) / BN;
     dim3 grid(k.nblk_m * k.nblk_n, nsplit), block(256);
-#define QD_CASE(SP, O)                                                                      \
-    if (split == SP && out == O) {                                                          \
-        hipLaunchKernelGGL((igemm_dma_kernel<MT, NT, SP, O, WB>), grid, block, 0, st, k);   \
-        return 0;                                                                           \
+#define QD_CASE(SP, O)                                                                              \
+    if (split == SP && out == O) {                                                                  \
+        hipLaunchKernelGGL((igemm_kernel<MT, NT, WM, WN, SP, O, WB>), grid, block, 0, st, k);       \
+        return 0;                                                                                   \
     }
-    QD_CASE(false, O_F32) QD_CASE(false, O_F16) QD_CASE(false, O_I32)
-    if constexpr (WB == 4) { QD_CASE(false, O_HROWS) QD_CASE(false, O_HTR) }
-    if constexpr (MT == 1) { QD_CASE(true, O_F32) QD_CASE(true, O_F16) QD_CASE(false, O_PART) }
-    if constexpr (NT == 4 && WB == 4) { QD_CASE(false, O_GEGLU) }
+    QD_CASE(false, O_F32) QD_CASE(false, O_F16)
+    if constexpr (MT == 1 && WM == 4) { QD_CASE(false, O_I32) QD_CASE(true, O_F32) QD_CASE(true, O_F16) QD_CASE(false, O_PART) }
+    if constexpr (WB == 4 && WM == 4) { QD_CASE(false, O_HROWS) QD_CASE(false, O_HTR) }
+    if constexpr (NT == 4 && WB == 4 && WM == 4) { QD_CASE(false, O_GEGLU) }
 #undef QD_CASE
-    qd_set_error("qd_conv2d_i8 (tiled): unsupported variant split=%d out=%d MT=%d", (int)split, out, MT);
+    qd_set_error("qd_conv2d_i8: unsupported variant split=%d out=%d tile %dx%d", (int)split, out, BM, BN);
     return 1;
 }
 
-// N-tile count of the MT=1 kernel the dispatcher would pick for this width
+// N-tile count of the 128-row kernel the dispatcher would pick for this width
 int nt_for(int N) { return N % 160 == 0 ? 5 : (N % 224 == 0 ? 7 : (N > 64 ? 4 : 2)); }
 
 // Split-K policy.  Worth it only when the plain launch cannot fill the chip (<= 1 block per CU) AND the
 // K loop is long enough that the extra int32 partial traffic (2 * 4 * M * N bytes per split) is paid back.
 int choose_splitk(const qd_conv_desc* d, int* it_per) {
     *it_per = 0;
-    if (!d->w_tiled || d->nseg != 1 || d->epilogue != QD_EPI_LINEAR) return 1;
+    if (d->nseg != 1 || d->epilogue != QD_EPI_LINEAR) return 1;
     const long M = (long)d->B * d->Ho * d->Wo;
     const int  N = d->Cout, bn = 32 * (d->wbits == 8 ? (N > 64 ? 4 : 2) : nt_for(N));
     const long blocks0 = ((M + 127) / 128) * ((N + bn - 1) / bn);
@@ -771,20 +923,19 @@ int choose_splitk(const qd_conv_desc* d, int* it_per) {
     return (total + *it_per - 1) / *it_per;
 }
 
-}  // namespace
-
-extern "C" int64_t qd_conv2d_i8_splitk_ws_bytes(const qd_conv_desc* d) {
-    if (!d) return 0;
-    int it_per;
-    const int S = choose_splitk(d, &it_per);
-    return S < 2 ? 0 : (int64_t)S * d->B * d->Ho * d->Wo * d->Cout * 4;
-}
-
-int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
-    QD_REQUIRE(d->wbits == 4 || d->wbits == 8, "tiled weights are int4 or int8");
+int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
+    QD_REQUIRE(d != nullptr, "qd_conv2d_i8: null descriptor");
+    QD_REQUIRE(d->x && d->w && (d->out || iout), "qd_conv2d_i8: null tensor pointer");
+    QD_REQUIRE(d->w_tiled, "qd_conv2d_i8: weights must be in the tile order of qd_pack_weights_t4 / _t8 (w_tiled = 1)");
+    QD_REQUIRE(d->wbits == 4 || d->wbits == 8, "qd_conv2d_i8: wbits must be 4 or 8 (got %d)", d->wbits);
+    QD_REQUIRE(d->out_dtype == QD_F32 || d->out_dtype == QD_F16, "qd_conv2d_i8: out_dtype must be f32/f16");
+    QD_REQUIRE(d->nseg == 1 || d->nseg == 2, "qd_conv2d_i8: nseg must be 1 or 2");
+    QD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, "qd_conv2d_i8: bad shape");
+    QD_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->kh * d->kw <= 32, "qd_conv2d_i8: bad kernel/stride (at most 32 taps)");
+    QD_REQUIRE((long)d->B * d->Ho * d->Wo < (1L << 31), "qd_conv2d_i8: M overflows int32");
     const bool w8 = d->wbits == 8;
-    QD_REQUIRE(!w8 || d->epilogue == QD_EPI_LINEAR, "qd_conv2d_i8 (tiled): the fused GEGLU / head-layout epilogues are int4-weight only");
-    QD_REQUIRE(d->ldx % 16 == 0 && qd_aligned(d->x, 16) && qd_aligned(d->w, 16), "qd_conv2d_i8 (tiled): x/w must be 16-byte aligned, ldx %% 16 == 0");
+    QD_REQUIRE(!w8 || d->epilogue == QD_EPI_LINEAR, "qd_conv2d_i8: the fused GEGLU / head-layout epilogues are int4-weight only");
+    QD_REQUIRE(d->ldx % 16 == 0 && qd_aligned(d->x, 16) && qd_aligned(d->w, 16), "qd_conv2d_i8: x/w must be 16-byte aligned, ldx %% 16 == 0");
     ConvD k{};
     k.x = d->x; k.wt = d->w; k.out = d->out; k.iout = iout;
     k.bias = d->bias; k.rowbias = d->rowbias; k.residual = d->residual;
@@ -795,42 +946,50 @@ int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
     k.ntiles = (d->Cout + 31) / 32;
     for (int s = 0; s < d->nseg; ++s) {
         const qd_conv_seg& g = d->seg[s];
-        QD_REQUIRE(g.clen > 0 && g.clen % 16 == 0 && g.c0 % 16 == 0, "qd_conv2d_i8 (tiled): segment %d c0/clen must be multiples of 16", s);
-        QD_REQUIRE(g.scale != nullptr, "qd_conv2d_i8 (tiled): segment %d has no scale vector", s);
-        QD_REQUIRE(!g.fill16 || qd_aligned(g.fill16, 16), "qd_conv2d_i8 (tiled): fill16 must be 16-byte aligned");
+        QD_REQUIRE(g.clen > 0 && g.clen % 16 == 0 && g.c0 % 16 == 0, "qd_conv2d_i8: segment %d c0/clen must be multiples of 16", s);
+        QD_REQUIRE(g.c0 + g.clen <= d->ldx, "qd_conv2d_i8: segment %d exceeds the activation row", s);
+        QD_REQUIRE(g.scale != nullptr, "qd_conv2d_i8: segment %d has no scale vector", s);
+        QD_REQUIRE(!g.fill16 || qd_aligned(g.fill16, 16), "qd_conv2d_i8: fill16 must be 16-byte aligned");
         k.seg[s] = SegD{g.c0, g.clen, g.kstep0, (g.clen + 63) / 64, g.scale, g.zc, g.zw, g.zfill, g.fill16};
     }
     QD_REQUIRE((long)d->kh * d->kw * (d->seg[0].clen + (d->nseg == 2 ? d->seg[1].clen : 0)) < 32768,
-               "qd_conv2d_i8 (tiled): K too long for the 24-bit zero-point multiply");
-    QD_REQUIRE(d->ldo < (1 << 22) && d->ldr < (1 << 22) && d->Cout < (1 << 22), "qd_conv2d_i8 (tiled): row strides must be < 2^22 elements");
+               "qd_conv2d_i8: K too long for the 24-bit zero-point multiply");
     const bool split = d->nseg == 2;
     const bool geglu = d->epilogue == QD_EPI_GEGLU_I8;
     const bool heads = d->epilogue == QD_EPI_HEADS_I8 || d->epilogue == QD_EPI_HEADS_T_I8;
     const int out = geglu ? O_GEGLU : heads ? (d->epilogue == QD_EPI_HEADS_I8 ? O_HROWS : O_HTR)
                                             : (iout ? O_I32 : (d->out_dtype == QD_F16 ? O_F16 : O_F32));
+    // 16-byte row-major accesses in the epilogue: every base and row stride a multiple of 4 elements
+    const size_t esz = d->out_dtype == QD_F16 ? 2 : 4;
+    k.vec = d->Cout % 4 == 0 && (iout ? qd_aligned(iout, 16)
+                                      : (d->ldo % 4 == 0 && qd_aligned(d->out, 4 * esz) && d->out_dtype == QD_F32 &&
+                                         (!d->residual || (d->ldr % 4 == 0 && qd_aligned(d->residual, 16))) &&
+                                         (!d->rowbias || (d->ld_rowbias % 4 == 0 && qd_aligned(d->rowbias, 16)))));
     if (heads) {
-        QD_REQUIRE(!iout && d->nseg == 1 && d->oq_params && d->out, "qd_conv2d_i8 (tiled): heads epilogue needs one segment, oq_params and out");
-        QD_REQUIRE(d->oq_max - d->oq_off <= 127 && d->oq_min - d->oq_off >= -128, "qd_conv2d_i8 (tiled): heads output grid does not fit int8");
-        QD_REQUIRE(d->hd_H > 0 && d->hd_d > 0 && d->hd_H * d->hd_d == d->Cout, "qd_conv2d_i8 (tiled): heads epilogue: H*d must equal Cout");
-        QD_REQUIRE(d->hd_T > 0 && d->hd_T % 128 == 0 && k.M % d->hd_T == 0, "qd_conv2d_i8 (tiled): heads epilogue: tokens per sample (%d) must be a multiple of 128 dividing M", d->hd_T);
-        QD_REQUIRE(d->hd_Tpad % 32 == 0 && d->hd_Tpad >= d->hd_T && d->hd_dpad % 32 == 0 && d->hd_dpad >= d->hd_d, "qd_conv2d_i8 (tiled): heads epilogue: bad padded dims");
-        QD_REQUIRE(qd_aligned(d->out, 16) && (d->epilogue != QD_EPI_HEADS_T_I8 || d->hd_sum), "qd_conv2d_i8 (tiled): heads epilogue: out unaligned or hd_sum missing");
-        QD_REQUIRE(!d->rowbias && (!d->residual || (d->epilogue == QD_EPI_HEADS_I8 && d->out_dtype == QD_F32)),
-                   "qd_conv2d_i8 (tiled): heads epilogue takes no rowbias; an fp32 residual only with QD_EPI_HEADS_I8");
+        QD_REQUIRE(!iout && d->nseg == 1 && d->oq_params && d->out, "qd_conv2d_i8: heads epilogue needs one segment, oq_params and out");
+        QD_REQUIRE(d->oq_max - d->oq_off <= 127 && d->oq_min - d->oq_off >= -128, "qd_conv2d_i8: heads output grid does not fit int8");
+        QD_REQUIRE(d->hd_H > 0 && d->hd_d > 0 && d->hd_H * d->hd_d == d->Cout, "qd_conv2d_i8: heads epilogue: H*d must equal Cout");
+        QD_REQUIRE(d->hd_d % 4 == 0 && d->hd_dpad % 4 == 0, "qd_conv2d_i8: heads epilogue: head dim and its padding must be multiples of 4");
+        QD_REQUIRE(d->hd_T > 0 && d->hd_T % 128 == 0 && k.M % d->hd_T == 0, "qd_conv2d_i8: heads epilogue: tokens per sample (%d) must be a multiple of 128 dividing M", d->hd_T);
+        QD_REQUIRE(d->hd_Tpad % 32 == 0 && d->hd_Tpad >= d->hd_T && d->hd_dpad >= d->hd_d, "qd_conv2d_i8: heads epilogue: bad padded dims");
+        QD_REQUIRE(qd_aligned(d->out, 16) && (d->epilogue != QD_EPI_HEADS_T_I8 || d->hd_sum), "qd_conv2d_i8: heads epilogue: out unaligned or hd_sum missing");
+        QD_REQUIRE(!d->rowbias && (!d->residual || (d->epilogue == QD_EPI_HEADS_I8 && d->out_dtype == QD_F32 && d->ldr % 4 == 0 && qd_aligned(d->residual, 16))),
+                   "qd_conv2d_i8: heads epilogue takes no rowbias; an fp32 residual (16-byte aligned rows) only with QD_EPI_HEADS_I8");
         k.oq = d->oq_params; k.oqmin = (float)d->oq_min; k.oqmax = (float)d->oq_max; k.oqoff = d->oq_off;
         k.hdH = d->hd_H; k.hdd = d->hd_d; k.hdT = d->hd_T; k.hdTpad = d->hd_Tpad; k.hddpad = d->hd_dpad;
         k.oqpre = d->oq_prescale; k.hdsum = d->hd_sum;
     }
     if (d->gn_part) {
-        QD_REQUIRE(!iout && !heads && !geglu && d->out_dtype == QD_F32, "qd_conv2d_i8 (tiled): gn_part needs the plain fp32 epilogue");
-        QD_REQUIRE((d->Ho * d->Wo) % 128 == 0, "qd_conv2d_i8 (tiled): gn_part needs Ho*Wo %% 128 == 0 (a 128-row chunk stays inside one sample)");
+        QD_REQUIRE(!iout && !heads && !geglu && d->out_dtype == QD_F32, "qd_conv2d_i8: gn_part needs the plain fp32 epilogue");
+        QD_REQUIRE((d->Ho * d->Wo) % 128 == 0, "qd_conv2d_i8: gn_part needs Ho*Wo %% 128 == 0 (a 128-row chunk stays inside one sample)");
         k.gnpart = d->gn_part;
         k.gn_nchunk = d->Ho * d->Wo / 128;
     }
     const bool mt2_ok = !heads || d->hd_T % 256 == 0;            // a block must stay inside one sample
     if (geglu) {
-        QD_REQUIRE(!iout && d->nseg == 1 && d->oq_params && d->Cout % 64 == 0, "qd_conv2d_i8 (tiled): GEGLU epilogue needs one segment, oq_params and Cout %% 64 == 0");
-        QD_REQUIRE(d->oq_max - d->oq_off <= 127 && d->oq_min - d->oq_off >= -128, "qd_conv2d_i8 (tiled): GEGLU output grid does not fit int8");
+        QD_REQUIRE(!iout && d->nseg == 1 && d->oq_params && d->Cout % 64 == 0, "qd_conv2d_i8: GEGLU epilogue needs one segment, oq_params and Cout %% 64 == 0");
+        QD_REQUIRE(d->oq_max - d->oq_off <= 127 && d->oq_min - d->oq_off >= -128, "qd_conv2d_i8: GEGLU output grid does not fit int8");
+        QD_REQUIRE(d->ldo % 16 == 0 && qd_aligned(d->out, 16), "qd_conv2d_i8: GEGLU output rows must be 16-byte aligned");
         k.oq = d->oq_params; k.oqmin = (float)d->oq_min; k.oqmax = (float)d->oq_max; k.oqoff = d->oq_off;
     }
     QD_REQUIRE(!(iout && split), "qd_conv2d_i8_acc: single segment only");
@@ -842,15 +1001,16 @@ int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
     int it_per = 0;
     const int nsplit = (iout || !d->splitk_ws || d->gn_part) ? 1 : choose_splitk(d, &it_per);   // gn_part: fused epilogue only
     if (nsplit >= 2 && d->splitk_ws_bytes >= (int64_t)nsplit * M * N * 4) {
-        QD_REQUIRE(qd_aligned(d->splitk_ws, 16), "qd_conv2d_i8 (tiled): splitk_ws must be 16-byte aligned");
+        QD_REQUIRE(qd_aligned(d->splitk_ws, 16), "qd_conv2d_i8: splitk_ws must be 16-byte aligned");
         k.iout = reinterpret_cast<int32_t*>(d->splitk_ws);
         k.it_per = it_per;
-        if (w8) rc = N > 64 ? dispatch<1, 4, 8>(k, false, O_PART, st, nsplit) : dispatch<1, 2, 8>(k, false, O_PART, st, nsplit);
+        k.vec = N % 4 == 0;
+        if (w8) rc = N > 64 ? dispatch<1, 4, 4, 1, 8>(k, false, O_PART, st, nsplit) : dispatch<1, 2, 4, 1, 8>(k, false, O_PART, st, nsplit);
         else switch (nt_for(N)) {
-            case 5:  rc = dispatch<1, 5>(k, false, O_PART, st, nsplit); break;
-            case 7:  rc = dispatch<1, 7>(k, false, O_PART, st, nsplit); break;
-            case 4:  rc = dispatch<1, 4>(k, false, O_PART, st, nsplit); break;
-            default: rc = dispatch<1, 2>(k, false, O_PART, st, nsplit); break;
+            case 5:  rc = dispatch<1, 5, 4, 1>(k, false, O_PART, st, nsplit); break;
+            case 7:  rc = dispatch<1, 7, 4, 1>(k, false, O_PART, st, nsplit); break;
+            case 4:  rc = dispatch<1, 4, 4, 1>(k, false, O_PART, st, nsplit); break;
+            default: rc = dispatch<1, 2, 4, 1>(k, false, O_PART, st, nsplit); break;
         }
         if (rc) return rc;
         const SegD& sg = k.seg[0];
@@ -862,41 +1022,60 @@ int qd_conv2d_i8_tiled(const qd_conv_desc* d, int32_t* iout, void* stream) {
         else
             hipLaunchKernelGGL(splitk_finalize_kernel<float>, grid, block, 0, st, k.iout, nsplit, MN, N, d->Ho * d->Wo, sg.scale, sg.zc, sg.zw,
                                sg.zfill, k.bias, k.rowbias, k.ldrb, (const float*)k.residual, k.ldr, (float*)k.out, k.ldo);
-        QD_LAUNCH_CHECK("qd_conv2d_i8 (tiled, split-K)");
+        QD_LAUNCH_CHECK("qd_conv2d_i8 (split-K)");
         return 0;
     }
     static const int force_mt = getenv("QD_TILE_MT") ? atoi(getenv("QD_TILE_MT")) : 0;       // tuning knob: 1 / 2, 0 = heuristic
     static const int force_gmt = getenv("QD_GEGLU_MT") ? atoi(getenv("QD_GEGLU_MT")) : 0;
+    static const int mt2_mink = getenv("QD_MT2_MINK") ? atoi(getenv("QD_MT2_MINK")) : 0;
+    const long Ktot = (long)k.taps * d->seg[0].clen;
+    const bool linear_out = out == O_F32 || out == O_F16;
+    // 256-row tiles (two 32-row tiles per wave: half the B-fragment reads and nibble unpacks per MFMA) whenever they still
+    // give every CU a block
+    auto want_mt2 = [&](int bn) {
+        if (split || !mt2_ok || out == O_I32) return false;
+        if (force_mt) return force_mt == 2;
+        return Ktot >= mt2_mink && blocks(256, bn) >= 256;
+    };
     if (w8) {                                      // int8 weights (CIFAR W8A8): 128-wide N tiles
         if (N > 64) {
-            if (!split && blocks(256, 128) >= 512) rc = dispatch<2, 4, 8>(k, split, out, st);
-            else rc = dispatch<1, 4, 8>(k, split, out, st);
+            if (linear_out && want_mt2(128)) rc = dispatch<2, 4, 4, 1, 8>(k, split, out, st);
+            else rc = dispatch<1, 4, 4, 1, 8>(k, split, out, st);
         } else {
-            rc = dispatch<1, 2, 8>(k, split, out, st);
+            rc = dispatch<1, 2, 4, 1, 8>(k, split, out, st);
         }
     } else if (geglu) {
-        // 128-row tiles by default: the erf/quantise epilogue is VALU-heavy and overlaps better with other
-        // blocks' main loops at 4 waves per SIMD (measured -0.24 ms per SD evaluation vs 256-row tiles)
-        if (force_gmt == 2) rc = dispatch<2, 4>(k, split, out, st);
-        else rc = dispatch<1, 4>(k, split, out, st);
+        if (force_gmt == 2) rc = dispatch<2, 4, 4, 1>(k, split, out, st);
+        else rc = dispatch<1, 4, 4, 1>(k, split, out, st);
     } else if (N % 160 == 0) {
-        // 256-row tiles only pay off when the K loop is long: short-K layers are bound by their output stream and
-        // run better as twice as many 128-row blocks whose load / store phases interleave (measured on SD, -0.3 ms)
-        static const int mt2_mink = getenv("QD_MT2_MINK") ? atoi(getenv("QD_MT2_MINK")) : 2048;
-        const long Ktot = (long)k.taps * d->seg[0].clen;
-        if (!split && mt2_ok && Ktot >= mt2_mink && (force_mt ? force_mt == 2 : blocks(256, 160) >= 512)) rc = dispatch<2, 5>(k, split, out, st);      // >= 2 blocks per CU
-        else rc = dispatch<1, 5>(k, split, out, st);
+        if (want_mt2(160)) rc = dispatch<2, 5, 4, 1>(k, split, out, st);
+        else rc = dispatch<1, 5, 4, 1>(k, split, out, st);
     } else if (N % 224 == 0) {
-        rc = dispatch<1, 7>(k, split, out, st);
+        rc = dispatch<1, 7, 4, 1>(k, split, out, st);
     } else if (N > 64) {
-        if (!split && mt2_ok && blocks(256, 128) >= 512) rc = dispatch<2, 4>(k, split, out, st);
-        else rc = dispatch<1, 4>(k, split, out, st);
+        if (want_mt2(128)) rc = dispatch<2, 4, 4, 1>(k, split, out, st);
+        else rc = dispatch<1, 4, 4, 1>(k, split, out, st);
     } else {
-        rc = dispatch<1, 2>(k, split, out, st);
+        rc = dispatch<1, 2, 4, 1>(k, split, out, st);
     }
     if (rc) return rc;
-    QD_LAUNCH_CHECK("qd_conv2d_i8 (tiled)");
+    QD_LAUNCH_CHECK("qd_conv2d_i8");
     return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t qd_conv2d_i8_splitk_ws_bytes(const qd_conv_desc* d) {
+    if (!d) return 0;
+    int it_per;
+    const int S = choose_splitk(d, &it_per);
+    return S < 2 ? 0 : (int64_t)S * d->B * d->Ho * d->Wo * d->Cout * 4;
+}
+
+extern "C" int qd_conv2d_i8(const qd_conv_desc* d, void* stream) { return run(d, nullptr, stream); }
+extern "C" int qd_conv2d_i8_acc(const qd_conv_desc* d, int32_t* iout, void* stream) {
+    if (!iout) { qd_set_error("qd_conv2d_i8_acc: null iout"); return 1; }
+    return run(d, iout, stream);
 }
 
 extern "C" int qd_pack_weights_t4(const float* w, const float* alpha, const float* delta, const float* zp, int Cout,

@@ -11,16 +11,13 @@ import math
 
 import torch
 
-import os
-
 from . import hip
 from .hip import Grid, pad16, pad32
 
-# int4 weight layout: "tiled" (MFMA-tile order, LDS-DMA kernel csrc/igemm_dma.hip) or "rows"
-# (row-major nibbles, register-staged kernel csrc/igemm_i8.hip; kept for A/B measurements)
-W4_LAYOUT = os.environ.get("QDIFF_W4_LAYOUT", "tiled")
-# 8-bit weights: "tiled" = the same LDS-DMA kernel with 2-KB s8 tiles (qd_pack_weights_t8), "rows" = first-generation kernel
-W8_LAYOUT = os.environ.get("QDIFF_W8_LAYOUT", "tiled")
+# True: every (True, True) module / block runs the reference's fp32 fake-quant simulation instead of the integer
+# kernels.  Never set by the product path; bench.py uses it to time the simulation on the GPU (the "fake-quant on
+# GPU" denominator of SURVEY.md §8d) and tests use it to compare EMA range tracking with the fused path.
+SIMULATE = False
 
 
 # ------------------------------------------------------------------------------------------------
@@ -47,6 +44,21 @@ def qparams_of(quantizer, device):
     d = _scalar_tensor(quantizer.delta, device)
     z = _scalar_tensor(quantizer.zero_point, device)
     return torch.stack([d, z])
+
+
+def check_act_zero_point(quantizer, grid):
+    """The kernels keep activations as bytes a' = code - off and the "true zero" as z' = zp - off: zp must lie on the
+    grid's own code range [qmin, qmax] or z' does not fit int8 and the quantiser kernels would wrap it silently
+    (the reference handles any zp in floating point: quant_layer.py:82-88).  One host read per plan build; skipped
+    while a HIP graph is being captured (plans are built during the warm-up evaluations)."""
+    z = quantizer.zero_point
+    if torch.is_tensor(z):
+        if z.is_cuda and torch.cuda.is_current_stream_capturing():
+            return
+        z = float(z.detach().reshape(-1)[0].item())
+    if not (grid.qmin <= float(z) <= grid.qmax):
+        raise hip.HipEngineError(f"activation zero point {z} lies outside the integer grid [{grid.qmin}, {grid.qmax}]: its stored "
+                                 "byte zp - off does not fit int8 (set qdiff.engine.SIMULATE = True for the fp32 simulation)")
 
 
 def quantizer_key(q):
@@ -105,17 +117,19 @@ def pack_module_weights(weight, quantizers, split, row_perm=None):
         zps = [z.index_select(0, row_perm) for z in zps]
     zall = torch.cat(zps)
     zmin, zmax = int(zall.min().item()), int(zall.max().item())  # one-time host read at pack time
-    if levels <= 16 and zmin >= 0 and zmax <= 127:
-        mode = 4
-    elif zmin >= 0 and zmax <= 128 and levels - 1 - zmin <= 127:
-        mode = 0
-    else:
-        mode = 8
+    if any(getattr(q, "sym", False) for q in quantizers):
+        # a symmetric weight grid is [-n_levels-1, n_levels] (reference quant_layer.py:84-85); the packers implement the
+        # asymmetric [0, 2^b - 1] grid every reference configuration uses (weight_quant_params never set `symmetric`)
+        raise hip.HipEngineError("symmetric weight quantisers are not supported by the integer engine (the packers clamp "
+                                 "to [0, n_levels-1]); set qdiff.engine.SIMULATE = True for the fp32 simulation")
+    if levels > 256 or zmin < -128 or zmax > 255:      # the epilogue's zw * Asum product must fit int32
+        raise hip.HipEngineError(f"weight quantiser with {levels} levels / zero points in [{zmin}, {zmax}] does not fit the int8 MFMA operand")
+    # MFMA-tile-ordered operands (csrc/igemm_dma.hip): raw nibbles W when the grid fits 4 bits (mode 4), else bytes W-128
+    # (mode 8); the zero point goes to the epilogue either way (zw resp. zw-128 times the activation row sums)
+    mode = 4 if levels <= 16 else 8
     pk = WeightPack()
     pk.Cout, pk.taps, pk.Cin = Cout, taps, Cin
-    pk.tiled = (mode == 4 and W4_LAYOUT == "tiled") or (mode != 4 and W8_LAYOUT == "tiled")
-    if pk.tiled and mode != 4:
-        mode = 8                                   # the tile order always stores W-128 (zw-128 goes to the epilogue)
+    pk.tiled = True
     pk.mode, pk.wbits = mode, (4 if mode == 4 else 8)
     kofs, segs = 0, []
     for (c0, c1) in bounds:
@@ -123,16 +137,12 @@ def pack_module_weights(weight, quantizers, split, row_perm=None):
         segs.append(dict(c0w=c0, clen=clen, clen_pad=pad16(clen), kofs=kofs))
         kofs += pad16(clen)
     pk.ldk = max(pad32(kofs), 32)
-    if pk.tiled:
-        # MFMA-tile-ordered nibbles for the LDS-DMA kernel: [kstep][n/32][1 KB], kstep = (segment, tap, 64-ch step)
-        ntiles, kstep = (Cout + 31) // 32, 0
-        for sg in segs:
-            sg["kstep0"] = kstep
-            kstep += taps * ((sg["clen_pad"] + 63) // 64)
-        pk.wq = torch.zeros(kstep * ntiles * (1024 if mode == 4 else 2048), dtype=torch.uint8, device=dev)
-    else:
-        nbytes = Cout * taps * pk.ldk // (2 if mode == 4 else 1)
-        pk.wq = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    # [kstep][n/32][1 KB | 2 KB], kstep = (segment, tap, 64-channel step)
+    ntiles, kstep = (Cout + 31) // 32, 0
+    for sg in segs:
+        sg["kstep0"] = kstep
+        kstep += taps * ((sg["clen_pad"] + 63) // 64)
+    pk.wq = torch.zeros(kstep * ntiles * (1024 if mode == 4 else 2048), dtype=torch.uint8, device=dev)
     for sg, q, z in zip(segs, quantizers, zps):
         delta = q.delta.detach().float().reshape(-1).to(dev).contiguous()
         if delta.numel() != Cout:
@@ -146,19 +156,14 @@ def pack_module_weights(weight, quantizers, split, row_perm=None):
             delta = delta.index_select(0, row_perm).contiguous()
             alpha = alpha.index_select(0, row_perm).contiguous() if alpha is not None else None
         wsum = torch.zeros(Cout, dtype=torch.int32, device=dev)
-        if pk.tiled:
-            (hip.pack_weights_t4 if mode == 4 else hip.pack_weights_t8)(
-                w, alpha, delta, z.contiguous(), Cout, Cin, taps, sg["c0w"], sg["clen"], levels,
-                pk.wq, sg["kstep0"], (Cout + 31) // 32, wsum)
-        else:
-            hip.pack_weights(w, alpha, delta, z.contiguous(), Cout, Cin, taps, sg["c0w"], sg["clen"], levels, mode,
-                             pk.wq, pk.ldk, sg["kofs"], wsum)
+        (hip.pack_weights_t4 if mode == 4 else hip.pack_weights_t8)(
+            w, alpha, delta, z.contiguous(), Cout, Cin, taps, sg["c0w"], sg["clen"], levels,
+            pk.wq, sg["kstep0"], (Cout + 31) // 32, wsum)
         sg["wsum"] = wsum
         sg["delta_w"] = delta
-        # epilogue-side weight zero point: stored operand is W-128 (mode 8) or the raw nibble W (tiled int4)
-        sg["zw"] = (z.to(torch.int32) - 128).contiguous() if mode == 8 else (z.to(torch.int32).contiguous() if pk.tiled else None)
-        # (tiled int4: raw nibbles, zw = zp; tiled / row-major int8: W-128, zw = zp-128; row-major int4 / direct s8: none)
-        sg["wzp"] = z.to(torch.int8).contiguous() if (mode == 4 and not pk.tiled) else None
+        # epilogue-side weight zero point: the stored operand is the raw nibble W (zw = zp) or the byte W-128 (zw = zp-128)
+        sg["zw"] = (z.to(torch.int32) - (128 if mode == 8 else 0)).contiguous()
+        sg["wzp"] = None
     pk.segs = segs
     pk.row_perm = row_perm
     return pk
@@ -213,6 +218,7 @@ def build_conv_plan(pack, act_quantizers, kh, kw, stride, pad, bias):
     plan.segs, plan.grids, plan.qparams = [], [], []
     for sg, aq in zip(pack.segs, act_quantizers):
         grid = act_grid(aq.n_bits, aq.sym)
+        check_act_zero_point(aq, grid)
         qp = qparams_of(aq, dev)
         K = pack.taps * sg["clen_pad"]
         d = dict(c0=sg["kofs"], clen=sg["clen_pad"], kofs=sg["kofs"], scale=(qp[0] * sg["delta_w"]).contiguous(),

@@ -312,9 +312,18 @@ class QuantModule(nn.Module):
         return ks[0], ks[1], st[0], pd[0]
 
     def int_ready(self):
-        """True when this module will take the integer path on its next forward."""
-        return (self.use_weight_quant and self.use_act_quant and not self.disable_act_quant
-                and self.act_quant_mode == 'qdiff' and self._geometry() is not None)
+        """True when this module will take the integer path on its next forward.  A (True, True) module whose
+        configuration the integer kernels do not cover (groups, dilation, unequal stride / padding) raises instead of
+        silently running the fp32 simulation; `engine.SIMULATE = True` selects the simulation on purpose
+        (bench.py times it on the GPU as the reference fake-quant denominator)."""
+        if not (self.use_weight_quant and self.use_act_quant and not self.disable_act_quant
+                and self.act_quant_mode == 'qdiff') or engine.SIMULATE:
+            return False
+        if self._geometry() is None:
+            raise hip.HipEngineError(
+                f"QuantModule({self.kind}, {self.fwd_kwargs}): grouped / dilated / anisotropic convolutions have no integer "
+                "kernel; set qdiff.engine.SIMULATE = True to run the fp32 simulation explicitly")
+        return True
 
     def dequantized_weight(self):
         """fp32 weight after fake quantisation, cached per quantiser state (weights-only mode)."""
@@ -446,7 +455,7 @@ class QuantModule(nn.Module):
     # -- forward ------------------------------------------------------------------------------
     def forward(self, input: torch.Tensor, split: int = 0):
         self._note_split(split)
-        if self.int_ready() and not torch.is_grad_enabled():
+        if not torch.is_grad_enabled() and self.int_ready():
             return self.activation_function(self._forward_int(input))
         # simulated / floating-point states: (False, *), weights-only, or calibration under autograd
         if not self.disable_act_quant and self.use_act_quant and self.act_quant_mode == 'qdiff':

@@ -1,0 +1,112 @@
+"""Shared driver of the teacher-forced per-block parity tests (tests/test_block_parity.py on the GPU,
+tests/test_host_logic.py::test_blocks_teacher_forced_on_emulator on the CPU ABI emulator).  TEST INFRASTRUCTURE."""
+import torch
+import torch.nn.functional as F
+
+from golden_util import build_ckpt, fixture_inputs, oracle_cfg
+from oracle import quant_ref as R
+from oracle import unet_ref as U
+
+# kind -> (max fraction of elements beyond 1e-4*rng, max |diff| / rng, max mean|diff| / rng).
+# What moves an element beyond the bulk bound is a quantiser tie flip INSIDE the block (the engine's exact integer
+# accumulators and the oracle's fp32 ones differ by ~1e-7 relative, which flips a round() on a few inputs per million):
+# one flipped activation code feeding a 3x3 convolution moves 9 * Cout outputs by one quantisation step, so the
+# FRACTION of moved elements scales with the layer width (9 * C * flip rate) and says little on small maps; a defect of
+# a fused epilogue, on the other hand, hits whole tile columns / rows by far more than a step.  The discriminating
+# bounds are therefore the MEAN (sparse one-step moves: <= ~1e-5; a systematic error on >= 1/10 of the tile: >= 1e-3)
+# and the MAX (a few steps of one operand) per block; the fraction is reported and loosely capped.
+# Residual blocks hold two activation quantisers, attention / transformer blocks up to eleven in sequence plus the 16-bit
+# probability grid, whose codes depend on exp() to the last ulp, so their budgets differ.
+BOUNDS = {
+    "conv": (1e-3, 2e-3, 2e-6), "ldm_time_embed": (1e-3, 2e-3, 2e-6), "ldm_upsample": (1e-3, 2e-3, 2e-6),
+    "ldm_head": (0.10, 2e-2, 2e-4), "ldm_res": (0.10, 2e-2, 2e-4), "cifar_res": (0.10, 2e-2, 2e-4),
+    "sd_transformer": (0.30, 5e-2, 1e-3), "ldm_attn": (0.30, 5e-2, 1e-3), "cifar_attn": (0.30, 5e-2, 1e-3),
+}
+
+
+def _oracle_blocks(fx):
+    spec = fx["spec"]
+    Q = U.QuantCkpt(build_ckpt(fx), spec["w_bits"], spec["a_bits"], spec["a_sym"], spec["sm_abit"])
+    Q.blocks = []
+    x, t, c = fixture_inputs(fx, "test")
+    with torch.no_grad():
+        if spec["family"] == "cifar":
+            y = U.cifar_forward(Q, oracle_cfg(spec), x, t, split_shortcut=spec["split"])
+        else:
+            y = U.ldm_forward(Q, oracle_cfg(spec), x, t, c, split=spec["split"])
+    return Q, y
+
+
+def _engine_block(qnn, kind, name, inp, dev):
+    from qdiff.arch import ldm_unet
+    m = qnn.model if name == "" else qnn.model.get_submodule(name)
+    g = lambda v: v.to(dev) if torch.is_tensor(v) else v
+    with torch.no_grad():
+        if kind in ("ldm_res", "cifar_res"):
+            return m(g(inp["x"]), g(inp["emb"]), split=inp["split"])
+        if kind == "sd_transformer":
+            return m(g(inp["x"]), g(inp["context"]))
+        if kind == "ldm_time_embed":
+            return m(ldm_unet.timestep_embedding(g(inp["t"]), qnn.model.model_channels))
+        return m(g(inp["x"]))
+
+
+def _first_quantiser_flips(qnn, Q, kind, name, inp, dev):
+    """(#differing codes, #codes) of GroupNorm -> SiLU -> act quantiser of the block's first conv, engine vs oracle."""
+    from qdiff import quant_block as qb
+    m = qnn.model.get_submodule(name)
+    gn, conv, gname, cname, eps = ((m.in_layers[0], m.in_layers[-1], ".in_layers.0", ".in_layers.2", 1e-5) if kind == "ldm_res"
+                                  else (m.norm1, m.conv1, ".norm1", ".conv1", 1e-6))
+    x = inp["x"]
+    B, C, H, W = x.shape
+    with torch.no_grad():
+        rows = qb._nhwc_rows(x.to(dev))
+        xq = qb._gn_silu_to(conv, rows, B, H * W, C, gn)[:, :C].cpu().long()
+        aq = Q.act_q(name + cname + ".act_quantizer")
+        y = F.silu(Q.gn(name + gname, x, eps))
+        ref = R.uaq_codes(y, aq["delta"], aq["zero_point"], aq["n_bits"], aq["sym"]) - (0 if aq["sym"] else 128)
+    ref = ref.permute(0, 2, 3, 1).reshape(B * H * W, C)
+    return int((xq != ref).sum()), ref.numel()
+
+
+def run_block_parity(qnn, fx, dev, sync=None):
+    """Walk the oracle once, teacher-force every engine block; returns (report lines, failure lines)."""
+    name = fx["name"]
+    Q, y_oracle = _oracle_blocks(fx)
+    lines, failures = [], []
+    rng_out = fx["out_wa"].abs().max().item()
+    lines.append(f"[{name}] oracle whole-UNet vs stored reference output: "
+                 f"{(y_oracle - fx['out_wa']).abs().max().item() / rng_out:.2e} of range")
+    flips = total = 0
+    worst = {}
+    for kind, path, inp, want in Q.blocks:
+        got = _engine_block(qnn, kind, path, inp, dev).float().cpu().reshape(want.shape)
+        rng = want.abs().max().item()
+        d = (got - want).abs()
+        frac = (d > 1e-4 * rng).float().mean().item()
+        dmax = d.max().item() / rng
+        dmean = d.mean().item() / rng
+        w = worst.setdefault(kind, [0, 0.0, 0.0, 0.0, 0.0])
+        w[0] += 1
+        w[1] = max(w[1], frac)
+        w[2] = max(w[2], dmax)
+        w[3] = max(w[3], d.median().item() / rng)
+        w[4] = max(w[4], dmean)
+        fb, db, mb = BOUNDS[kind]
+        if frac > fb or dmax > db or dmean > mb:
+            failures.append(f"{kind} {path}: {frac:.3e} of elements beyond 1e-4*range (bound {fb}), max {dmax:.3e} (bound {db}), "
+                            f"mean {dmean:.3e} (bound {mb})")
+        if kind in ("ldm_res", "cifar_res"):
+            a, b = _first_quantiser_flips(qnn, Q, kind, path, inp, dev)
+            flips += a
+            total += b
+    if sync is not None:
+        sync()
+    for kind, (n, frac, dmax, med, mean) in sorted(worst.items()):
+        lines.append(f"[{name}] {kind:15s} x{n:3d}: worst fraction beyond 1e-4*range = {frac:.3e}, worst max|diff| = {dmax:.3e} "
+                     f"of range, worst mean = {mean:.1e}, worst median = {med:.1e}")
+    if total:
+        lines.append(f"[{name}] code-flip rate at the first quantiser of the residual blocks: {flips} / {total} = {flips / total:.3e}")
+        if flips / total > 2e-3:
+            failures.append(f"code-flip rate {flips / total:.3e} > 2e-3")
+    return lines, failures

@@ -397,6 +397,12 @@ ATTN_CASES = [
     ("cifar_c256_sym", 2, 1, 256, 256, 256, 8, True, 256 ** -0.5),
     ("cifar_mid_T16", 2, 1, 16, 16, 256, 8, True, 256 ** -0.5),
     ("ldm_d32", 2, 14, 64, 64, 32, 8, False, 1.0),
+    # the shape that takes 25 % of an SD evaluation: 64x64 self-attention, d = 40 padded to 64, 16-bit probabilities,
+    # asymmetric q (attn_kernel<2, P16, ASYM>): 128 key tiles per sweep, int64 hi/lo recombination with large code sums
+    ("sd_self_4096", 2, 8, 4096, 4096, 40, 16, False, 40 ** -0.5),
+    # q >= 0: its asymmetric zero point is 0, i.e. the stored zero point is -128 and -zq' = 128 does not fit one signed
+    # operand byte (the kernel's two-constant c1/c2 path); ragged T and S exercise the peeled tail tile with it
+    ("sd_qpos_zq-128", 2, 8, 200, 77, 40, 16, False, 40 ** -0.5),
 ]
 
 
@@ -412,11 +418,15 @@ def test_attention_fused(cuda, case):
     k = torch.randn(B, S, H * d, generator=g)
     v = torch.randn(B, S, H * d, generator=g)
     pre = (d ** -0.25) if name.startswith("ldm") else 1.0
+    if "qpos" in name:
+        q = q.abs()
 
     def mk(t, n_bits=8, s=sym, always_zero=False):
         dd, zz = R.uaq_init_scale(t, n_bits, s, False, "max", always_zero)
         return dict(delta=dd, zero_point=zz, n_bits=n_bits, sym=s)
     aq_q, aq_k, aq_v = mk(q * pre), mk(k * pre), mk(v)
+    if "qpos" in name:
+        assert int(aq_q["zero_point"]) == 0
     heads = lambda t, L: t.view(B, L, H, d).permute(0, 2, 1, 3).reshape(B * H, L, d)
     with torch.no_grad():
         sim = torch.einsum("bid,bjd->bij", heads(q, T) * pre, heads(k, S) * pre) * scale

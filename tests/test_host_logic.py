@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     from qdiff import hip
     assert sorted(hip.EXPORTS) == declared
     lib.qd_abi_version.restype = ctypes.c_int
-    assert lib.qd_abi_version() == 9
+    assert lib.qd_abi_version() == 10
     assert lib.qd_device_ok() in (0, 1)                  # no compute calls without a GPU
 
 
@@ -233,20 +233,30 @@ def test_packing_mode_selection(emu):
     assert engine.pack_module_weights(w, [mk(8, 131)], 0).mode == 8        # u8 codes: W-128 + row-sum correction
     pk = engine.pack_module_weights(w, [mk(6, 30)], 0)
     assert pk.mode == 8 and pk.tiled and pk.wbits == 8                    # tile order always stores W-128
-    assert engine.pack_module_weights(w, [mk(4, 200)], 0).mode == 8        # degenerate zero point: general path
+    assert engine.pack_module_weights(w, [mk(4, 200)], 0).mode == 4        # odd zero point: still nibbles (zw lives in the epilogue)
+    from qdiff import hip
+    with pytest.raises(hip.HipEngineError):                                # outside the epilogue's int32 budget
+        engine.pack_module_weights(w, [mk(8, 700)], 0)
+    sym = mk(8, 0)
+    sym.sym, sym.n_levels = True, 127
+    with pytest.raises(hip.HipEngineError):                                # signed weight grids are not packed
+        engine.pack_module_weights(w, [sym], 0)
 
 
-def test_packing_mode_selection_row_major_layout(emu, monkeypatch):
-    """QDIFF_W8_LAYOUT=rows keeps the first-generation row-major int8 kernel: there W - zp is stored directly when it fits."""
+def test_activation_zero_point_outside_the_stored_byte_raises(emu):
+    """An activation zero point whose stored form z' = zp - off leaves int8 (possible after EMA range updates with
+    x_min > 0, or a learned delta) would wrap silently in the quantiser kernels: the plan builder refuses it."""
     from types import SimpleNamespace as NS
-    from qdiff import engine
-    monkeypatch.setattr(engine, "W8_LAYOUT", "rows")
+    from qdiff import engine, hip
     w = torch.randn(8, 16, 1, 1)
-    mk = lambda bits, zp: NS(delta=torch.full((8, 1, 1, 1), 0.1), zero_point=torch.full((8, 1, 1, 1), float(zp)), n_levels=2 ** bits)
-    pk = engine.pack_module_weights(w, [mk(6, 30)], 0)
-    assert pk.mode == 0 and not pk.tiled
-    assert engine.pack_module_weights(w, [mk(8, 131)], 0).mode == 8
-
+    wq = NS(delta=torch.full((8, 1, 1, 1), 0.1), zero_point=torch.full((8, 1, 1, 1), 7.0), n_levels=16)
+    pack = engine.pack_module_weights(w, [wq], 0)
+    ok = NS(delta=torch.tensor(0.05), zero_point=255, n_bits=8, sym=False)
+    engine.build_conv_plan(pack, [ok], 1, 1, 1, 0, None)
+    for zp in (-1, 256, torch.tensor(300.0)):
+        bad = NS(delta=torch.tensor(0.05), zero_point=zp, n_bits=8, sym=False)
+        with pytest.raises(hip.HipEngineError):
+            engine.build_conv_plan(pack, [bad], 1, 1, 1, 0, None)
 
 
 def _standalone_matmul_modules(c):
@@ -310,3 +320,17 @@ def test_packed_checkpoint_round_trip(emu, name, tmp_path):
     assert torch.equal(y0, y1)
     mods = [m for m in q2.modules() if isinstance(m, qdiff.QuantModule)]
     assert mods and all(m.weight.numel() == 0 for m in mods)
+
+
+@pytest.mark.parametrize("name", ["cifar_tiny", "ldm_tiny", "sd_tiny"])
+def test_blocks_teacher_forced_on_emulator(emu, name):
+    """The teacher-forced per-block harness of tests/test_block_parity.py (GPU, full shapes) on the CPU ABI emulator:
+    every fused block wiring of qdiff/quant_block.py fed with the oracle's block inputs reproduces the oracle's block
+    outputs within the per-kind bounds."""
+    from block_parity_util import run_block_parity
+    fx = load_fixture(f"model_{name}.pt")
+    qnn = _resume_cpu(fx)
+    lines, failures = run_block_parity(qnn, fx, torch.device("cpu"))
+    print("\n" + "\n".join(lines))
+    assert lines[0].endswith("0.00e+00 of range"), "oracle trace run is not the reference run"
+    assert not failures, "\n".join(failures)

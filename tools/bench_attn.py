@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of qd_attn_i8 on the SD-v1 attention shapes (batch 16): us per call.
+Usage (GPU box): python tools/bench_attn.py [iters=5] [case substring]"""
+import os
+import sys
+from types import SimpleNamespace as NS
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "q-diffusion_amd"))
+from qdiff import engine  # noqa: E402
+
+CASES = [
+    # name, B, H, T, S, d, sm bits
+    ("sd self 64x64 d40", 16, 8, 4096, 4096, 40, 16),
+    ("sd cross 64x64 d40", 16, 8, 4096, 77, 40, 16),
+    ("sd self 32x32 d80", 16, 8, 1024, 1024, 80, 16),
+    ("sd self 16x16 d160", 16, 8, 256, 256, 160, 16),
+    ("ldm self 32x32 d32 (8-bit P)", 10, 14, 1024, 1024, 32, 8),
+]
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    only = sys.argv[2] if len(sys.argv) > 2 else None
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(0)
+    for name, B, H, T, S, d, smb in CASES:
+        if only and only not in name:
+            continue
+        aq = lambda delta, zp: NS(delta=torch.tensor(delta, device=dev), zero_point=zp, n_bits=8, sym=False)
+        aw = NS(delta=torch.tensor(1.0 / (2 ** smb - 1), device=dev), zero_point=0, n_bits=smb, sym=False)
+        ap = engine.build_attn_plan(aq(0.03, 120), aq(0.03, 131), aq(0.03, 125), aw, d ** -0.5, 1.0, dev)
+        Tp, Sp, dp = engine.pad32(T), engine.pad32(S), engine.pad32(d)
+        BH = B * H
+        q8 = torch.zeros((BH, Tp, dp), dtype=torch.int8, device=dev)
+        k8 = torch.zeros((BH, Sp, dp), dtype=torch.int8, device=dev)
+        v8 = torch.zeros((BH, dp, Sp), dtype=torch.int8, device=dev)
+        q8[:, :T, :d] = torch.randint(-128, 128, (BH, T, d), dtype=torch.int8, device=dev, generator=g)
+        k8[:, :S, :d] = torch.randint(-128, 128, (BH, S, d), dtype=torch.int8, device=dev, generator=g)
+        v8[:, :d, :S] = torch.randint(-128, 128, (BH, d, S), dtype=torch.int8, device=dev, generator=g)
+        vsum = v8.int().sum(-1).contiguous()
+        out = torch.empty((B * T, H * d), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1000.0 / iters
+        scores = BH * T * S
+        print(f"{name:32s} BH={BH:4d} T={T:5d} S={S:5d} d={d:4d}  {us:9.1f} us  {scores / us / 1e6:7.3f} T scores/s")
+
+
+if __name__ == "__main__":
+    main()

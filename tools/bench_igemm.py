@@ -48,7 +48,7 @@ def main():
             B, Cin, H, Cout, k, stride = (int(v) for v in spec.split(","))
             shapes.append((f"custom {spec}", B, Cin, H, Cout, k, stride))
     for name, B, Cin, H, Cout, k, stride in shapes:
-        if only and only not in name:
+        if only and not any(o in name for o in only.split("|")):
             continue
         w = torch.randn(Cout, Cin, k, k, device=dev, generator=g) * 0.05
         mx, mn = w.flatten(1).max(1)[0], w.flatten(1).min(1)[0]

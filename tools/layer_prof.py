@@ -34,11 +34,12 @@ def run(out_json, n):
                          geglu=call.epilogue == hip.EPI_GEGLU_I8, res=call.residual is not None))
         orig(call, acc_out)
     with torch.no_grad():
-        qnn.model(*args)
-        qnn.model(*args)
+        for _ in range(5):               # warm: plans, allocator, clocks
+            qnn.model(*args)
         torch.cuda.synchronize()
         hip.conv2d_i8 = spy
-        qnn.model(*args)                 # the LAST evaluation in the trace is the one that is joined
+        torch.cuda._sleep(int(6e8))      # the host enqueues the whole evaluation behind a spin kernel: kernels then run
+        qnn.model(*args)                 # back to back (the LAST evaluation in the trace is the one that is joined)
         torch.cuda.synchronize()
     hip.conv2d_i8 = orig
     json.dump(recs, open(out_json, "w"))
