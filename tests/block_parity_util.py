@@ -20,7 +20,7 @@ from oracle import unet_ref as U
 BOUNDS = {
     "conv": (1e-3, 2e-3, 2e-6), "ldm_time_embed": (1e-3, 2e-3, 2e-6), "ldm_upsample": (1e-3, 2e-3, 2e-6),
     "ldm_head": (0.10, 2e-2, 2e-4), "ldm_res": (0.10, 2e-2, 2e-4), "cifar_res": (0.10, 2e-2, 2e-4),
-    "sd_transformer": (0.30, 5e-2, 1e-3), "ldm_attn": (0.30, 5e-2, 1e-3), "cifar_attn": (0.30, 5e-2, 1e-3),
+    "sd_transformer": (0.30, 2e-2, 2e-4), "ldm_attn": (0.30, 2e-2, 2e-4), "cifar_attn": (0.30, 2e-2, 2e-4),
 }
 
 
@@ -69,11 +69,39 @@ def _first_quantiser_flips(qnn, Q, kind, name, inp, dev):
     return int((xq != ref).sum()), ref.numel()
 
 
+def _oracle_block(Q, fx, kind, path, inp):
+    """One block evaluated by the oracle `Q` (used with QuantCkpt64: the exact-arithmetic realisation of the same block)."""
+    spec = fx["spec"]
+    x = inp["x"].double() if "x" in inp else None
+
+    def heads_of(ch):
+        u = spec["unet"]
+        nhc, nh = u.get("num_head_channels", -1), u.get("num_heads", -1)
+        return nh if nhc == -1 else ch // nhc
+    with torch.no_grad():
+        if kind == "ldm_res":
+            cout = Q.get(path + ".out_layers.3.weight").shape[0]
+            return U._ldm_resblock(Q, path, x, inp["emb"].double(), x.shape[1], cout, split=inp["split"])
+        if kind == "cifar_res":
+            cout = Q.get(path + ".conv2.weight").shape[0]
+            return U._cifar_resblock(Q, path, x, inp["emb"].double(), x.shape[1], cout, split=inp["split"])
+        if kind == "sd_transformer":
+            return U._spatial_transformer(Q, path, x, inp["context"].double(), heads_of(x.shape[1]))
+        if kind == "ldm_attn":
+            return U._attention_block(Q, path, x, heads_of(x.shape[1]))
+        if kind == "cifar_attn":
+            return U._cifar_attn(Q, path, x)
+    return None
+
+
 def run_block_parity(qnn, fx, dev, sync=None):
     """Walk the oracle once, teacher-force every engine block; returns (report lines, failure lines)."""
     name = fx["name"]
     Q, y_oracle = _oracle_blocks(fx)
+    spec = fx["spec"]
+    Q64 = None
     lines, failures = [], []
+    n64 = 0
     rng_out = fx["out_wa"].abs().max().item()
     lines.append(f"[{name}] oracle whole-UNet vs stored reference output: "
                  f"{(y_oracle - fx['out_wa']).abs().max().item() / rng_out:.2e} of range")
@@ -94,8 +122,27 @@ def run_block_parity(qnn, fx, dev, sync=None):
         w[4] = max(w[4], dmean)
         fb, db, mb = BOUNDS[kind]
         if frac > fb or dmax > db or dmean > mb:
-            failures.append(f"{kind} {path}: {frac:.3e} of elements beyond 1e-4*range (bound {fb}), max {dmax:.3e} (bound {db}), "
-                            f"mean {dmean:.3e} (bound {mb})")
+            # Outside the direct bounds.  Long attention rows make the REFERENCE's own fp32 arithmetic the noisy side: its
+            # P.V sums over 4096 keys carry ~1e-4 relative error, which flips ~1 % of the 8-bit codes entering to_out and moves
+            # every output of those tokens.  Evaluate the same block in fp64 (exact arithmetic on the same fake-quant network):
+            # the engine — exact integer contractions — must be at least as close to it as the reference's fp32 run is.
+            if Q64 is None:
+                Q64 = U.QuantCkpt64(build_ckpt(fx), spec["w_bits"], spec["a_bits"], spec["a_sym"], spec["sm_abit"])
+            y64 = _oracle_block(Q64, fx, kind, path, inp)
+            ok = False
+            if y64 is not None:
+                n64 += 1
+                y64 = y64.reshape(want.shape)
+                e64 = (got.double() - y64).abs()
+                r64 = (want.double() - y64).abs()
+                em, rm = e64.mean().item() / rng, r64.mean().item() / rng
+                ex, rx = e64.max().item() / rng, r64.max().item() / rng
+                ok = em <= max(mb, 1.25 * rm) and ex <= max(db, 1.25 * rx)
+                lines.append(f"[{name}] {kind} {path}: vs fp32 oracle mean {dmean:.2e} max {dmax:.2e} | vs fp64 evaluation: engine mean "
+                             f"{em:.2e} max {ex:.2e}, reference fp32 mean {rm:.2e} max {rx:.2e}")
+            if not ok:
+                failures.append(f"{kind} {path}: {frac:.3e} of elements beyond 1e-4*range (bound {fb}), max {dmax:.3e} (bound {db}), "
+                                f"mean {dmean:.3e} (bound {mb}); not explained by the reference's own fp32-vs-fp64 distance")
         if kind in ("ldm_res", "cifar_res"):
             a, b = _first_quantiser_flips(qnn, Q, kind, path, inp, dev)
             flips += a
@@ -105,6 +152,8 @@ def run_block_parity(qnn, fx, dev, sync=None):
     for kind, (n, frac, dmax, med, mean) in sorted(worst.items()):
         lines.append(f"[{name}] {kind:15s} x{n:3d}: worst fraction beyond 1e-4*range = {frac:.3e}, worst max|diff| = {dmax:.3e} "
                      f"of range, worst mean = {mean:.1e}, worst median = {med:.1e}")
+    if n64:
+        lines.append(f"[{name}] {n64} block(s) were judged against the fp64 evaluation of the block (reference fp32 noise envelope)")
     if total:
         lines.append(f"[{name}] code-flip rate at the first quantiser of the residual blocks: {flips} / {total} = {flips / total:.3e}")
         if flips / total > 2e-3:
