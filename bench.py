@@ -13,9 +13,13 @@ timed region.  images/sec = N * n / (51 * seconds_per_step)   (51 evals per 50-s
 
 Extra objects on the JSON line:
   roofline     — the dominant kernel class (igemm int8 MFMA contraction): algorithmic int ops of every
-                 launch of one UNet evaluation / their HIP-event durations on the launch stream.
+                 launch of one UNet evaluation / their HIP-event durations on the launch stream; fractions against
+                 the nominal 5.0 POP/s and the 4.404 POP/s micro-benchmark ceiling; whole_step_* = all integer ops of
+                 the evaluation / wall time of the sampler step.
+  gpu_denominators — the same UNet at the same batch on the same GPU with quantisation off (fp32 PyTorch-ROCm) and as
+                 the reference's fp32 fake-quant simulation (rank 0, N=1 only).
   cpu_baseline — the oracle (CPU port of the reference fake-quant forward, oracle/unet_ref.py) timed on
-                 this box's host cores for ONE UNet evaluation at batch 2 (rank 0, N=1 only).
+                 this box's host cores: one warm-up + two timed UNet evaluations of one sample (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -29,7 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "q-diffusion_amd"))
 sys.path.insert(0, ROOT)
 
-I8_MFMA_PEAK_TOPS = 5000.0     # dense int8 MFMA = 2x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md); ubench ceiling 4404
+I8_MFMA_PEAK_TOPS = 5000.0     # dense int8 MFMA = 2x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md)
+I8_MFMA_UBENCH_TOPS = 4404.0   # measured ceiling of v_mfma_i32_32x32x32_i8 (cdna_hip_programming.md §3; SURVEY.md §8d formula)
 EVALS_PER_IMAGE_BATCH = 51     # PLMS S=50: 50 steps + 1 extra evaluation on the first step (plms.py:222-227)
 
 
@@ -69,6 +74,30 @@ def build_quantised_unet(kind, device, seed=0):
     for m in qnn.modules():
         if isinstance(m, AdaRoundQuantizer):
             m.alpha.data.copy_(torch.rand(m.alpha.shape, generator=g, device=device) * 2 - 1)
+    return qnn, dict(w_bits=wq["n_bits"], a_bits=8, a_sym=bool(aq.get("symmetric", False)), sm_abit=sm_abit)
+
+
+def build_skeleton(kind, device, seed=777):
+    """A QuantModel on the same architecture with UNRELATED weights and no calibration: what every rank but 0 holds
+    before sampling.broadcast_packed_model hands it the packed state (its fp32 weights are never read)."""
+    import qdiff
+    from qdiff import synthetic
+    from qdiff.arch import ddim_unet, ldm_unet
+    if kind == "sd":
+        model, sm_abit = ldm_unet.UNetModel(**ldm_unet.sd_v1_config()), 16
+        wq, aq = dict(n_bits=4, channel_wise=True, scale_method="max"), dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True)
+    elif kind == "ldm":
+        model, sm_abit = ldm_unet.UNetModel(**ldm_unet.lsun_beds_config()), 8
+        wq = dict(n_bits=4, channel_wise=True, scale_method="max")
+        aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True, symmetric=True)
+    else:
+        model, sm_abit = ddim_unet.Model(ddim_unet.cifar10_config(split_shortcut=True)), 8
+        wq = dict(n_bits=8, channel_wise=True, scale_method="max")
+        aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True, symmetric=True)
+    if kind != "cifar":
+        model.split = True
+    synthetic.load_synthetic_weights(model, seed=seed)
+    qnn = qdiff.QuantModel(model.to(device).eval(), wq, aq, sm_abit=sm_abit).to(device).eval()
     return qnn, dict(w_bits=wq["n_bits"], a_bits=8, a_sym=bool(aq.get("symmetric", False)), sm_abit=sm_abit)
 
 
@@ -115,7 +144,7 @@ def measure_igemm(qnn, args):
     return dict(launches=len(records), total_ms=ms, ops=ops, event_overhead_us=1000.0 * overhead)
 
 
-def gpu_denominators(qnn, margs, k=3):
+def gpu_denominators(qnn, margs, k=2):
     """The two GPU-side denominators of SURVEY.md §8(d) / BASELINE.json north_star, same UNet, same batch, same
     GPU, same run: (a) the fp32 PyTorch-ROCm UNet — quantisation off, `org_weight` path of
     reference qdiff/quant_layer.py:273-276, library (MIOpen / rocBLAS) fp32 kernels; (b) the reference's fake-quant
@@ -126,7 +155,8 @@ def gpu_denominators(qnn, margs, k=3):
 
     def timed():
         with torch.no_grad():
-            qnn.model(*margs)                          # warm: MIOpen find, allocator
+            for _ in range(2):                         # warm: MIOpen find + kernel compilation, allocator
+                qnn.model(*margs)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(k):
@@ -148,21 +178,29 @@ def gpu_denominators(qnn, margs, k=3):
     return res
 
 
-def cpu_baseline(qnn, qspec, kind, cfg):
+def cpu_baseline(qnn, qspec, kind, cfg, k=2):
+    """The reference's CPU fake-quant path, timed on this box's host cores: oracle/unet_ref.py — the restatement of the
+    reference forward, same ATen calls in the same order, pinned bit for bit to the real reference's outputs
+    (tests/test_oracle_golden.py) — because /root/reference does not exist on the GPU box.  One warm-up evaluation,
+    then k timed evaluations of ONE sample (batch 1; a CFG image needs two samples per evaluation)."""
     from oracle import unet_ref as U
     from qdiff import synthetic
     from qdiff.utils import export_cali_state_dict
-    sd = {k: v.cpu() for k, v in export_cali_state_dict(qnn).items()}
+    sd = {kk: v.cpu() for kk, v in export_cali_state_dict(qnn).items()}
     Q = U.QuantCkpt(sd, qspec["w_bits"], qspec["a_bits"], qspec["a_sym"], qspec["sm_abit"])
-    x, t, c = synthetic.synthetic_inputs(kind, 2, seed=7)
+    x, t, c = synthetic.synthetic_inputs(kind, 1, seed=7)
+
+    def one():
+        with torch.no_grad():
+            if kind == "cifar":
+                U.cifar_forward(Q, cfg, x, t, split_shortcut=True)
+            else:
+                U.ldm_forward(Q, cfg, x, t, c, split=True)
+    one()
     t0 = time.time()
-    with torch.no_grad():
-        if kind == "cifar":
-            U.cifar_forward(Q, cfg, x, t, split_shortcut=True)
-        else:
-            U.ldm_forward(Q, cfg, x, t, c, split=True)
-    dt = time.time() - t0
-    return dt
+    for _ in range(k):
+        one()
+    return (time.time() - t0) / k
 
 
 def main():
@@ -192,8 +230,10 @@ def main():
     hip.load()
 
     kind, n = a.model, a.images_per_gpu
-    qnn, qspec = build_quantised_unet(kind, dev)
-    nbytes = sampling.broadcast_quant_state(qnn, src=0)          # the only collective: packed quant state over xGMI
+    # rank 0 owns the calibrated model (synthetic here: data-dependent init + AdaRound conversion); every other rank
+    # builds the bare architecture with unrelated weights and receives the packed state — the ONLY collective of the run
+    qnn, qspec = build_quantised_unet(kind, dev) if rank == 0 else build_skeleton(kind, dev)
+    nbytes = sampling.broadcast_packed_model(qnn, src=0)
 
     from qdiff.arch import ldm_unet
     if kind == "sd":
@@ -282,24 +322,45 @@ def main():
         measure_igemm(qnn, margs)                      # warm (eager path, caches)
         r = measure_igemm(qnn, margs)
         ach = r["ops"] / (r["total_ms"] * 1e-3) / 1e12
-        # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs of this
-        # command); bench.py cannot collect counters itself, so it reports the committed summary, SD workload only
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_igemm_hbm_traffic.json")
-        if kind == "sd" and os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_call_corrected")
+        # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs of this command,
+        # tools/final_measure.sh); bench.py cannot collect counters itself, so it reports the committed summary of the
+        # same workload and says which file it read
+        traffic, traffic_src = None, None
+        for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(f"_{kind}_igemm_hbm_traffic.json")),
+                           reverse=True):
+            traffic = json.load(open(os.path.join(ROOT, "profiles", cand))).get("hbm_bytes_per_call_corrected")
+            traffic_src = "profiles/" + cand
+            break
+        # whole-step view: every integer op of the evaluation (contractions + attention, SURVEY.md §8d per-sample figures)
+        # against the wall clock of the timed sampler step
+        per_sample_gop = {"sd": 803.0, "ldm": 202.0, "cifar": 12.5}[kind]
+        step_top = per_sample_gop * 1e9 * (xb.shape[0] * (2 if guide != 1.0 else 1)) / (ms_per_step * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
-                           "frac": round(ach / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic,
-                           "kernel": "every qd_conv2d_i8 launch of one evaluation: igemm_dma_kernel<MT,NT,..> (+ splitk_finalize_kernel)", "launches_per_eval": r["launches"],
+                           "frac": round(ach / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                           "frac_of_ubench_ceiling_4404": round(ach / I8_MFMA_UBENCH_TOPS, 4),
+                           "whole_step_achieved": round(step_top, 2), "whole_step_frac": round(step_top / I8_MFMA_PEAK_TOPS, 4),
+                           "whole_step_frac_of_4404": round(step_top / I8_MFMA_UBENCH_TOPS, 4),
+                           "kernel": "every qd_conv2d_i8 launch of one evaluation: igemm_kernel<MT,NT,WM,WN,..> (+ splitk_finalize_kernel)",
+                           "launches_per_eval": r["launches"],
                            "avg_launch_us": round(1000.0 * r["total_ms"] / r["launches"], 2),
                            "igemm_ms_per_eval": round(r["total_ms"], 3), "algorithmic_GOP_per_eval": round(r["ops"] / 1e9, 1),
                            "event_pair_overhead_us": round(r["event_overhead_us"], 2)}
+        if world == 1 and not a.no_denominators:
+            # same UNet, same batch, same GPU, same run: the denominators of north_star's ">= 4x the reference fp32
+            # PyTorch-ROCm UNet" target
+            den = gpu_denominators(qnn, margs)
+            den["speedup_vs_fp32_unet"] = round(den["fp32_unet_ms"] / ms_per_step, 2)
+            den["speedup_vs_fake_quant_sim"] = round(den["fake_quant_sim_ms"] / ms_per_step, 2)
+            den["note"] = ("ms per UNet evaluation at the bench batch; fp32_unet = quantisation off (org_weight path, MIOpen/rocBLAS "
+                           "fp32); fake_quant_sim = the reference's fp32 simulation arithmetic on the GPU (fake-quantised weights cached)")
+            out["gpu_denominators"] = den
         if world == 1 and not a.no_cpu_baseline:
             dt = cpu_baseline(qnn, qspec, kind, ocfg)
-            # one eval at batch 2 = one image's CFG pair (SD) / two images (unconditional models)
-            imgs = 1 if guide != 1.0 else 2
-            out["cpu_baseline"] = {"value": round(imgs / (evals * dt), 6), "unit": "images/s", "cores": torch.get_num_threads(),
-                                   "kind": "port", "sample": f"1 UNet evaluation at batch 2 ({dt:.1f} s), extrapolated x{evals} evals per image"}
+            # dt = one sample through one UNet evaluation; an image needs `evals` evaluations of 2 samples (CFG) or 1
+            per_image = evals * (2 if guide != 1.0 else 1) * dt
+            out["cpu_baseline"] = {"value": round(1.0 / per_image, 6), "unit": "images/s", "cores": torch.get_num_threads(),
+                                   "kind": "port", "sample": f"UNet evaluations of one sample on the host cores: 1 warm-up + 2 timed, {dt:.1f} s "
+                                                             f"each; extrapolated to {evals} evaluations x {2 if guide != 1.0 else 1} samples per image"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -173,9 +173,9 @@ _PACK_SEG_TENSORS = ("wsum", "delta_w", "zw", "wzp")
 _PACK_SEG_INTS = ("c0w", "clen", "clen_pad", "kofs", "kstep0")
 
 
-def pack_to_dict(pk):
-    """WeightPack -> plain dict of CPU tensors / ints (what a packed checkpoint stores per layer)."""
-    cpu = lambda t: None if t is None else t.detach().cpu()
+def pack_to_dict(pk, to_cpu=True):
+    """WeightPack -> plain dict of (CPU) tensors / ints (what a packed checkpoint stores per layer)."""
+    cpu = (lambda t: None if t is None else t.detach().cpu()) if to_cpu else (lambda t: None if t is None else t.detach())
     segs = []
     for sg in pk.segs:
         e = {k: int(sg[k]) for k in _PACK_SEG_INTS if k in sg}
@@ -418,12 +418,15 @@ def attention(ap, q, k, v, B, T, S, H, d, q_strides, k_strides, v_strides, out=N
 _HEAD_BUFS = {}
 
 
-def head_buffers(device, BH, Tpad, Spad, dpad):
+def head_buffers(device, BH, T, S, d):
     """(q8 [BH][Tpad][dpad], k8 [BH][Spad][dpad], v8^T [BH][dpad][Spad], vsum [BH][dpad]): the int8 operands of
-    qd_attn_i8, zero-initialised ONCE and shared by every attention block of that shape on the device
-    (stream-ordered reuse; the projection epilogues never write pad bytes, so the pads stay zero, and a
-    captured HIP graph keeps pointing at stable addresses)."""
-    key = (device, BH, Tpad, Spad, dpad)
+    qd_attn_i8, zero-initialised ONCE and shared by every attention block of that LOGICAL shape on the device
+    (stream-ordered reuse: one evaluation runs on one stream; the projection epilogues never write pad bytes, so the
+    pads stay zero — two blocks that only agree on the padded sizes, e.g. d = 40 and d = 48, get separate buffers — and
+    a captured HIP graph keeps pointing at stable addresses, which is why the key does not include the stream: the
+    warm-up evaluations before a capture run on a side stream and must create the buffers the capture then reuses)."""
+    Tpad, Spad, dpad = pad32(T), pad32(S), pad32(d)
+    key = (device, BH, T, S, d)
     bufs = _HEAD_BUFS.get(key)
     if bufs is None:
         bufs = (torch.zeros((BH, Tpad, dpad), dtype=torch.int8, device=device),

@@ -63,13 +63,23 @@ def cat_channels(a, b):
     return out
 
 
+def _tracking(m):
+    """A QuantModule whose activation quantisers are in EMA range-tracking mode (QuantModel.set_running_stat(True),
+    the reference's calibration loop: txt2img.py:457-468, quant_layer.py:77-78,91-110)."""
+    return any(getattr(q, "running_stat", False) for q in m._act_quantizers()) if m.act_quant_mode == 'qdiff' else False
+
+
 def _int_mode(*modules):
-    """All given QuantModules take the integer path and autograd is off."""
-    return (not torch.is_grad_enabled()) and all(isinstance(m, QuantModule) and m.int_ready() for m in modules)
+    """All given QuantModules take the integer path, autograd is off and no activation quantiser is tracking its range:
+    range tracking updates delta / zero_point from every float input the quantiser sees, which only the simulation
+    composition feeds it — a fused block in that mode runs `_forward_sim` exactly as the reference does."""
+    return ((not torch.is_grad_enabled()) and all(isinstance(m, QuantModule) and m.int_ready() for m in modules)
+            and not any(_tracking(m) for m in modules))
 
 
 def _aq_ready(*quantizers):
-    return all(q.inited for q in quantizers)
+    """Initialised and not in EMA range-tracking mode (a tracking quantiser must see its float input: simulation path)."""
+    return all(q.inited and not q.running_stat for q in quantizers)
 
 
 def _gn_silu_to(conv, rows, B, S, C, gn, silu=True):
@@ -111,15 +121,24 @@ class _AttnQuant:
         return cache[1]
 
 
-def _reference_classes():
-    """The reference's own UNet classes, when its `ldm` / `ddim` packages are importable (drop-in
-    use inside the q-diffusion source tree): they are rewritten exactly like this repo's classes."""
+_REF_CACHE = {}
+
+
+def reference_classes():
+    """The reference's own UNet classes, when its `ldm` / `ddim` packages are importable (drop-in use inside the
+    q-diffusion source tree: `import qdiff` resolves to this package, `ldm` / `ddim` to the reference's): they are
+    rewritten exactly like this repo's classes.  Looked up lazily (and cached once found) so that the reference tree may
+    be put on sys.path after this module was imported."""
+    if _REF_CACHE.get("complete"):
+        return _REF_CACHE
     out = {}
     try:
         from ldm.modules.diffusionmodules import openaimodel as ref_oai
-        from ldm.modules.attention import BasicTransformerBlock as RefBTB
+        from ldm.modules import attention as ref_att
         out.update(ResBlock=ref_oai.ResBlock, AttentionBlock=ref_oai.AttentionBlock, QKMatMul=ref_oai.QKMatMul,
-                   SMVMatMul=ref_oai.SMVMatMul, BasicTransformerBlock=RefBTB, TimestepBlock=ref_oai.TimestepBlock)
+                   SMVMatMul=ref_oai.SMVMatMul, BasicTransformerBlock=ref_att.BasicTransformerBlock,
+                   TimestepBlock=ref_oai.TimestepBlock, SpatialTransformer=ref_att.SpatialTransformer,
+                   Upsample=ref_oai.Upsample, UNetModel=ref_oai.UNetModel)
     except Exception:  # noqa: BLE001 - optional dependency
         pass
     try:
@@ -127,12 +146,10 @@ def _reference_classes():
         out.update(ResnetBlock=ref_ddim.ResnetBlock, AttnBlock=ref_ddim.AttnBlock)
     except Exception:  # noqa: BLE001
         pass
-    return out
-
-
-_REF = _reference_classes()
-# QuantResBlock must be recognised as a TimestepBlock by whichever TimestepEmbedSequential hosts it
-_TIMESTEP_BASES = (ldm_unet.TimestepBlock,) + ((_REF["TimestepBlock"],) if "TimestepBlock" in _REF else ())
+    if out:
+        _REF_CACHE.update(out)
+        _REF_CACHE["complete"] = "ResBlock" in out and "ResnetBlock" in out
+    return out or _REF_CACHE
 
 
 # ------------------------------------------------------------------------------------------------
@@ -160,7 +177,7 @@ class BaseQuantBlock(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # LDM / SD residual block  (reference quant_block.py:44-111)
 # ------------------------------------------------------------------------------------------------
-class QuantResBlock(BaseQuantBlock, *_TIMESTEP_BASES):
+class QuantResBlock(BaseQuantBlock, ldm_unet.TimestepBlock):
     def __init__(self, res, act_quant_params: dict = {}):
         super().__init__(act_quant_params)
         for name in ("channels", "emb_channels", "dropout", "out_channels", "use_conv", "use_checkpoint",
@@ -289,9 +306,10 @@ class QuantAttentionBlock(BaseQuantBlock, _AttnQuant):
         if quant_matmuls:
             # quantised-activation mode: the two matmul modules inside QKVAttentionLegacy become their
             # quantised counterparts (what the reference's recursion does, quant_model.py:45-61)
-            if isinstance(getattr(self.attention, "qkv_matmul", None), ldm_unet.QKMatMul):
+            # (this repo's QKMatMul / SMVMatMul or the reference's: same names, same role)
+            if type(getattr(self.attention, "qkv_matmul", None)).__name__ == "QKMatMul":
                 self.attention.qkv_matmul = QuantQKMatMul(act_quant_params)
-            if isinstance(getattr(self.attention, "smv_matmul", None), ldm_unet.SMVMatMul):
+            if type(getattr(self.attention, "smv_matmul", None)).__name__ == "SMVMatMul":
                 self.attention.smv_matmul = QuantSMVMatMul(act_quant_params, sm_abit=sm_abit)
 
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
@@ -427,7 +445,7 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
             xk = xv = None
         inner = att.to_q.conv_plan().Cout
         d = inner // h
-        q8, k8, v8, vsum = engine.head_buffers(rows.device, B * h, engine.pad32(T), engine.pad32(S), engine.pad32(d))
+        q8, k8, v8, vsum = engine.head_buffers(rows.device, B * h, T, S, d)
 
         def operand(mod, codes, which, n_tok, buf):
             # projection -> attention operand bytes: inside the GEMM epilogue when the shape allows it, else
@@ -587,6 +605,19 @@ def _linear_like_conv2d(mod, rows, B, H, W, residual=None):
 # ------------------------------------------------------------------------------------------------
 # dispatch table  (reference quant_block.py:389-401)
 # ------------------------------------------------------------------------------------------------
+_REF_RESBLOCK = {}
+
+
+def _quant_resblock_for_reference(ref):
+    """The reference's TimestepEmbedSequential hands `emb` only to instances of ITS TimestepBlock (openaimodel.py:80-88):
+    the block that replaces a reference ResBlock must inherit from it (QuantResBlock itself inherits this repo's)."""
+    base = ref["TimestepBlock"]
+    cls = _REF_RESBLOCK.get(base)
+    if cls is None:
+        cls = _REF_RESBLOCK[base] = type("QuantResBlock", (QuantResBlock, base), {"__module__": QuantResBlock.__module__})
+    return cls
+
+
 def get_specials(quant_act=False):
     specials = {
         ldm_unet.ResBlock: QuantResBlock,
@@ -594,19 +625,23 @@ def get_specials(quant_act=False):
         ddim_unet.ResnetBlock: QuantResnetBlock,
         ddim_unet.AttnBlock: QuantAttnBlock,
     }
-    ref = _REF
-    for name, target in (("ResBlock", QuantResBlock), ("BasicTransformerBlock", QuantBasicTransformerBlock),
-                         ("ResnetBlock", QuantResnetBlock), ("AttnBlock", QuantAttnBlock)):
+    ref = reference_classes()
+    if "ResBlock" in ref:
+        specials[ref["ResBlock"]] = _quant_resblock_for_reference(ref)
+    for name, target in (("BasicTransformerBlock", QuantBasicTransformerBlock), ("ResnetBlock", QuantResnetBlock),
+                         ("AttnBlock", QuantAttnBlock)):
         if name in ref:
             specials[ref[name]] = target
     if quant_act:
         specials[ldm_unet.QKMatMul] = QuantQKMatMul
         specials[ldm_unet.SMVMatMul] = QuantSMVMatMul
-        # this repo's AttentionBlock is wrapped as well so that qkv -> attention -> proj runs fused
+        # the AttentionBlock is wrapped as well (this repo's and the reference's) so that qkv -> attention -> proj runs
+        # fused; the module tree and the state-dict keys stay those of the reference's recursion (quant_model.py:45-61)
         specials[ldm_unet.AttentionBlock] = QuantAttentionBlock
         if "QKMatMul" in ref:
             specials[ref["QKMatMul"]] = QuantQKMatMul
             specials[ref["SMVMatMul"]] = QuantSMVMatMul
+            specials[ref["AttentionBlock"]] = QuantAttentionBlock
     else:
         specials[ldm_unet.AttentionBlock] = QuantAttentionBlock
         if "AttentionBlock" in ref:

@@ -11,8 +11,10 @@ import logging
 import torch
 import torch.nn as nn
 
+from types import MethodType
+
 from .quant_block import (BaseQuantBlock, QuantAttentionBlock, QuantAttnBlock, QuantBasicTransformerBlock,
-                          QuantQKMatMul, QuantResBlock, QuantSMVMatMul, get_specials)
+                          QuantQKMatMul, QuantResBlock, QuantSMVMatMul, get_specials, reference_classes)
 from .quant_layer import QuantModule, StraightThrough
 from .arch import ldm_unet
 
@@ -32,6 +34,7 @@ class QuantModel(nn.Module):
         self.specials = get_specials(self.quant_act)
         self.quant_module_refactor(self.model, weight_quant_params, act_quant_params)
         self.quant_block_refactor(self.model, weight_quant_params, act_quant_params)
+        self._adopt_reference_modules()
         self._graphs = None
         self._quant_state = (False, False)
 
@@ -57,10 +60,59 @@ class QuantModel(nn.Module):
                 setattr(module, name, target(act_quant_params, sm_abit=self.sm_abit))
             elif target is QuantQKMatMul:
                 setattr(module, name, target(act_quant_params))
-            elif target is QuantAttentionBlock and isinstance(child, ldm_unet.AttentionBlock):
+            elif target is QuantAttentionBlock:
                 setattr(module, name, target(child, act_quant_params, sm_abit=self.sm_abit, quant_matmuls=self.quant_act))
             else:
                 setattr(module, name, target(child, act_quant_params))
+
+    def _adopt_reference_modules(self):
+        """Drop-in use on the REFERENCE's own UNet classes (scripts/txt2img.py:381-383 builds its LatentDiffusion UNet, then
+        wraps it): the glue modules this engine fuses around the quantised blocks keep the reference's class, attributes
+        and state-dict keys, and get this repo's forward bound onto them —
+          * SpatialTransformer: GroupNorm -> proj_in int8 rows, FF-out -> proj_out int8 rows, `+ x` in the epilogue;
+          * Upsample: quantise the small map, replicate int8 rows;
+          * the skip concatenation `th.cat([h, hs.pop()], dim=1)` of UNetModel.forward (openaimodel.py:776) drops the
+            GroupNorm statistics that travel with the two producers' outputs: hooks on the input / middle / output
+            blocks keep a shadow stack of them and re-attach the concatenated statistics to the block input."""
+        ref = reference_classes()
+        st, up = ref.get("SpatialTransformer"), ref.get("Upsample")
+        for m in self.model.modules():
+            if st is not None and type(m) is st:
+                m.forward = MethodType(ldm_unet.SpatialTransformer.forward, m)
+            elif up is not None and type(m) is up and getattr(m, "dims", 2) == 2:
+                m.forward = MethodType(ldm_unet.Upsample.forward, m)
+        unet = ref.get("UNetModel")
+        if unet is None or type(self.model) is not unet:
+            return
+        state = {"stack": [], "last": None}
+
+        def part_of(t):
+            return getattr(t, "qd_gn_part", None) if torch.is_tensor(t) else None
+
+        def reset(_m, _args):
+            state["stack"], state["last"] = [], None
+
+        def push(_m, _args, out):
+            state["stack"].append(part_of(out))
+
+        def keep_last(_m, _args, out):
+            state["last"] = part_of(out)
+
+        def reattach(_m, args):
+            pb = state["stack"].pop() if state["stack"] else None
+            pa, h = state["last"], args[0]
+            if pa is not None and pb is not None and torch.is_tensor(h) and pa.shape[0] * pa.shape[1] == pb.shape[0] * pb.shape[1] \
+                    and pa.shape[2] + pb.shape[2] == h.shape[1]:
+                n = pa.shape[0] * pa.shape[1]
+                h.qd_gn_part = torch.cat([pa.reshape(1, n, -1, 2), pb.reshape(1, n, -1, 2)], dim=2)
+
+        self.model.input_blocks[0].register_forward_pre_hook(reset)
+        for blk in self.model.input_blocks:
+            blk.register_forward_hook(push)
+        self.model.middle_block.register_forward_hook(keep_last)
+        for blk in self.model.output_blocks:
+            blk.register_forward_pre_hook(reattach)
+            blk.register_forward_hook(keep_last)
 
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
         self._quant_state = (bool(weight_quant), bool(act_quant))
@@ -107,7 +159,7 @@ class QuantModel(nn.Module):
 
     def set_grad_ckpt(self, grad_ckpt: bool):
         """reference :89-96 (transformer blocks only)."""
-        btb = tuple(t for t, q in self.specials.items() if q is QuantBasicTransformerBlock)
+        btb = tuple(t for t, q in self.specials.items() if q is QuantBasicTransformerBlock)  # unwrapped blocks, if any
         for _, m in self.model.named_modules():
             if isinstance(m, (QuantBasicTransformerBlock,) + btb):
                 m.checkpoint = grad_ckpt

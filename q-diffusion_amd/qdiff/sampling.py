@@ -375,50 +375,68 @@ def sharded_noise(shape, seed, world_size, rank, device, stream_id=0):
     return full[lo:hi].to(device)
 
 
-def quant_state_tensors(qnn):
-    """Every device tensor the integer engine reads at run time, in a deterministic order: packed
-    int4/int8 weights, per-channel scales / zero-point corrections, activation (delta, zp) pairs."""
-    from .quant_layer import QuantModule
-    out = []
-    for _, m in sorted(qnn.model.named_modules(), key=lambda kv: kv[0]):
-        if isinstance(m, QuantModule) and m._plan is not None:
-            pk = m._plan.pack
-            out.append(pk.wq)
-            for sg in pk.segs:
-                out += [t for t in (sg["wsum"], sg["delta_w"], sg["zw"], sg["wzp"]) if t is not None]
-            for sg, qp in zip(m._plan.segs, m._plan.qparams):
-                out += [t for t in (sg["scale"], sg["zc"], sg["zfill"], qp) if t is not None]
-            if m._plan.bias is not None:
-                out.append(m._plan.bias)
-        cache = m.__dict__.get("_attn_plan_cache")
-        if cache and cache[1] is not None:
-            out.append(cache[1].prm)
-    return out
+def _flatten_tensors(obj, out):
+    """Replace every tensor of a nested dict / list by a placeholder and collect the tensors in traversal order."""
+    if torch.is_tensor(obj):
+        out.append(obj)
+        return ("__tensor__", len(out) - 1, str(obj.dtype).replace("torch.", ""), tuple(obj.shape))
+    if isinstance(obj, dict):
+        return {k: _flatten_tensors(v, out) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)) and not (len(obj) == 4 and obj and obj[0] == "__tensor__"):
+        return [_flatten_tensors(v, out) for v in obj]
+    return obj
 
 
-def broadcast_quant_state(qnn, src=0, group=None):
-    """ONE collective at start-up: rank `src` owns the calibrated/packed quantisation state, every
-    other rank receives it in place (SD W4: ~0.43 GB of nibbles + a few MB of scales; over xGMI this is
-    milliseconds and the sampling loop itself has no communication).  Tensors are coalesced per dtype
-    into flat arenas so the wire sees a handful of large messages, not thousands of small ones."""
+def _restore_tensors(obj, arena, offsets):
+    if isinstance(obj, (list, tuple)) and len(obj) == 4 and obj[0] == "__tensor__":
+        _, idx, dtype, shape = obj
+        dt = getattr(torch, dtype)
+        n = 1
+        for d in shape:
+            n *= d
+        nbytes = n * torch.empty(0, dtype=dt).element_size()
+        return arena[offsets[idx]:offsets[idx] + nbytes].view(dt).view(shape)
+    if isinstance(obj, dict):
+        return {k: _restore_tensors(v, arena, offsets) for k, v in obj.items()}
+    if isinstance(obj, list):
+        return [_restore_tensors(v, arena, offsets) for v in obj]
+    return obj
+
+
+def broadcast_packed_model(qnn, src=0, group=None):
+    """The ONE collective of a sharded run (the reference has no counterpart): rank `src` holds the
+    calibrated model — it loaded a packed checkpoint (utils.load_packed_ckpt) or resumed / calibrated and packed — and
+    ships EVERYTHING the kernels read: tile-ordered int4/int8 weight codes (incl. the GEGLU-interleaved packs), their
+    per-channel constants, every activation / attention quantiser and the float parameters that are not quantised
+    weights (norms, biases), as ONE byte arena over RCCL/xGMI (SD-v1.4 W4: ~0.45 GB, milliseconds).  Every other rank
+    passes a QuantModel built on the same architecture with ANY weights (they are never read; load_packed_ckpt releases
+    them) and leaves with a model that evaluates bit-identically to rank `src`'s.  The sampling loop itself has no
+    collective.  Returns the arena size in bytes (0 in a single-process run)."""
     import torch.distributed as dist
+    from .utils import export_packed_ckpt, load_packed_ckpt
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return 0
-    tensors = quant_state_tensors(qnn)
-    by_dtype = {}
-    for t in tensors:
-        by_dtype.setdefault(t.dtype, []).append(t)
-    total = 0
-    for dtype, ts in sorted(by_dtype.items(), key=lambda kv: str(kv[0])):
-        flat = torch.cat([t.reshape(-1) for t in ts])
-        dist.broadcast(flat, src=src, group=group)
-        off = 0
-        for t in ts:
-            n = t.numel()
-            t.copy_(flat[off:off + n].view_as(t))
-            off += n
-        total += flat.numel() * flat.element_size()
-    return total
+    rank = dist.get_rank(group)
+    dev = next(qnn.parameters()).device
+    meta, tensors = [None], []
+    if rank == src:
+        meta[0] = _flatten_tensors(export_packed_ckpt(qnn, to_cpu=False), tensors)
+        offsets, off = [], 0
+        for t in tensors:
+            offsets.append(off)
+            off += (t.numel() * t.element_size() + 15) // 16 * 16          # 16-byte aligned slots
+        meta[0] = dict(tree=meta[0], offsets=offsets, total=off)
+    dist.broadcast_object_list(meta, src=src, group=group, device=dev if dev.type == "cuda" else None)
+    info = meta[0]
+    arena = torch.empty(info["total"], dtype=torch.uint8, device=dev)
+    if rank == src:
+        for t, o in zip(tensors, info["offsets"]):
+            flat = t.detach().contiguous().reshape(-1).view(torch.uint8)
+            arena[o:o + flat.numel()].copy_(flat.to(dev))
+    dist.broadcast(arena, src=src, group=group)
+    if rank != src:
+        load_packed_ckpt(qnn, _restore_tensors(info["tree"], arena, info["offsets"]))
+    return int(info["total"])
 
 
 def gather_samples(x_local, global_batch, group=None):

@@ -164,34 +164,37 @@ def export_cali_state_dict(qnn):
 PACKED_FORMAT = "qdiff-packed-v1"
 
 
-def export_packed_ckpt(qnn):
+def export_packed_ckpt(qnn, to_cpu=True):
     """Serializable inference state of a calibrated QuantModel in (True, True) state.  The reference's checkpoint keeps,
     per quantised layer, the fp32 weight, the fp32 AdaRound alpha of the same shape, delta and zero_point (SD-v1.4: ~7 GB);
     this one keeps the packed int4/int8 codes the kernels contract (tile-ordered), the per-channel constants and the
     activation quantisers (SD-v1.4 W4: ~0.45 GB).  Float parameters that are not quantised weights (norms, biases) are
-    stored as they are.  See load_packed_ckpt."""
+    stored as they are.  See load_packed_ckpt.  to_cpu=False keeps every tensor where it lives (no copies): the form
+    sampling.broadcast_packed_model ships over RCCL."""
     from . import engine
+    keep = (lambda t: t.detach().cpu().clone()) if to_cpu else (lambda t: t.detach())
     mods, quantizers, skip = {}, {}, set()
     for name, m in qnn.model.named_modules():
         if isinstance(m, QuantModule):
             if not m.int_ready():
                 raise ValueError(f"{name}: export_packed_ckpt needs set_quant_state(True, True) and initialised quantisers")
-            entry = dict(pack=engine.pack_to_dict(m.conv_plan().pack), split=int(m.split))
-            gc = m.__dict__.get("_geglu_cache")
-            if gc and gc[1] is not None:
-                entry["geglu_pack"] = engine.pack_to_dict(gc[1].pack)
+            entry = dict(pack=engine.pack_to_dict(m.conv_plan().pack, to_cpu), split=int(m.split))
+            if "_geglu_cache" in m.__dict__ or m.__dict__.get("_frozen_geglu_pack") is not None:
+                gp = m.geglu_plan()              # the layer runs as a fused GEGLU projection: refreshed for the CURRENT quantisers
+                if gp is not None:
+                    entry["geglu_pack"] = engine.pack_to_dict(gp.pack, to_cpu)
             mods[name] = entry
             skip.add(f"{name}.weight")
         if isinstance(m, UniformAffineQuantizer) and not isinstance(m, AdaRoundQuantizer) and "weight_quantizer" not in name \
                 and m.inited and m.delta is not None:
             z = m.zero_point
-            quantizers[name] = dict(delta=m.delta.detach().cpu().clone() if torch.is_tensor(m.delta) else float(m.delta),
-                                    zero_point=z.detach().cpu().clone() if torch.is_tensor(z) else float(z))
+            quantizers[name] = dict(delta=keep(m.delta) if torch.is_tensor(m.delta) else float(m.delta),
+                                    zero_point=keep(z) if torch.is_tensor(z) else float(z))
     tensors = {}
     for k, v in qnn.model.state_dict().items():
         if k in skip or "weight_quantizer" in k or "act_quantizer" in k:
             continue
-        tensors[k] = v.detach().cpu().clone()
+        tensors[k] = keep(v)
     return dict(format=PACKED_FORMAT, modules=mods, quantizers=quantizers, tensors=tensors)
 
 
