@@ -48,13 +48,24 @@ const char* qd_last_error(void);
 int         qd_device_ok(void);
 
 /* ------------------------------------------------------------------------------------------
+ * Quantiser parameters.  Every entry point below that takes `qparams` / `oq_params` expects a device float[4]
+ *     {delta, zero_point, rinv, fast} produced by qd_make_qparams from the reference's per-tensor delta / zero_point
+ *     (quant_layer.py:66-89; both read from DEVICE memory, no host round trip).  rinv is the correctly rounded
+ *     reciprocal of delta; fast != 0 certifies — by an exhaustive check over all 2^23 mantissas — that
+ *     y = x*rinv; e = fma(-y, delta, x); q = fma(e, rinv, y) equals the IEEE quotient x / delta bit for bit for this
+ *     delta, so the kernels may use it instead of the division that torch.round(x / delta) semantics require;
+ *     otherwise they divide.  Codes are bit-identical either way.
+ * ------------------------------------------------------------------------------------------ */
+int qd_make_qparams(const float* delta, const float* zero_point, float* out4, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * K1  activation quantiser.   Replaces UniformAffineQuantizer.forward on an *input activation*
  *     (qdiff/quant_layer.py:66-89) and the two-quantizer + torch.cat split path of
  *     QuantModule.forward (quant_layer.py:256-264).
  *
  *     x is a logical [B][C][S] tensor addressed by element strides (sb, sc, ss): NCHW-contiguous
  *     is (C*S, S, 1), channels_last / token-major is (S*C, 1, C).  Channels [c0, c0+clen) are
- *     quantised with qparams = {delta, zero_point} (two floats in device memory) and written as
+ *     quantised with qparams (qd_make_qparams) and written as
  *     int8 to out[(b*S+s)*ldo + oc0 + (c-c0)]; channels up to clen_pad are filled with the
  *     "true zero" byte so that padded K lanes contribute nothing.
  *     qmin/qmax/off describe the integer grid (see header comment).

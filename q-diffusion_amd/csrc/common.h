@@ -87,6 +87,27 @@ __device__ __forceinline__ float qd_erff(float a) {
     return t > 0.927734375f ? big : small;
 }
 
+// Quantiser parameters as the kernels receive them: device float[4] = {delta, zero_point, rinv, fast} written by
+// qd_make_qparams.  `fast` != 0 certifies (exhaustively, over all 2^23 mantissas of x) that the three-instruction
+// quotient  y = x*rinv;  e = fma(-y, delta, x);  q = fma(e, rinv, y)   equals the IEEE division x / delta BIT FOR BIT for
+// this delta (Markstein's correction: rinv is the correctly rounded reciprocal, e is exact); the kernels then skip the
+// ~10-instruction division sequence that torch.round(x / delta) semantics (quant_layer.py:82) otherwise cost per element.
+struct QP { float delta, zp, rinv; bool fast; };
+__device__ __forceinline__ QP qd_load_qp(const float* q) { return QP{q[0], q[1], q[2], q[3] != 0.f}; }
+__device__ __forceinline__ float qd_quot(float x, const QP& q) {
+    if (q.fast) {
+        const float y = x * q.rinv;
+        const float e = __builtin_fmaf(-y, q.delta, x);
+        return __builtin_fmaf(e, q.rinv, y);
+    }
+    return x / q.delta;
+}
+__device__ __forceinline__ int qd_code(float x, const QP& q, float qmin, float qmax) {
+    float r = rintf(qd_quot(x, q)) + q.zp;
+    r = fminf(fmaxf(r, qmin), qmax);
+    return (int)r;
+}
+
 // quantise one value to its stored byte: clamp(rint(x/delta)+zp, qmin, qmax) - off
 // (true IEEE division + round-half-even, as torch.round(x / delta): quant_layer.py:82)
 __device__ __forceinline__ int qd_code(float x, float delta, float zp, float qmin, float qmax) {

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : 2) void igemm_ke
         constexpr int ROWB = 16 * NT;                  // output bytes per row of this wave
         constexpr int LPR = ROWB / 16;                 // lanes per row in phase 2
         constexpr int RPP = 64 / LPR;                  // rows per pass
-        const float od = p.oq[0], oz = p.oq[1];
+        const QP oqp = qd_load_qp(p.oq);
         int8_t* tb8 = reinterpret_cast<int8_t*>(tb);   // [32 rows][ROWB]  (<= 4 KB for NT <= 8)
         const int Fout = p.Cout >> 1;
         const int f0 = (wcol0 >> 1);                   // first output feature of this wave
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : 2) void igemm_ke
                     const float val = (float)(acc[i][2 * jp][r] - zcv - __mul24(zwv, as)) * sv + bv;
                     const float gate = (float)(acc[i][2 * jp + 1][r] - zcg - __mul24(zwg, as)) * sgt + bg;
                     const float y = val * (0.5f * gate * (1.0f + qd_erff(gate * 0.70710678118654752440f)));
-                    tb8[rl * ROWB + jp * 32 + frow] = (int8_t)(qd_code(y, od, oz, p.oqmin, p.oqmax) - p.oqoff);
+                    tb8[rl * ROWB + jp * 32 + frow] = (int8_t)(qd_code(y, oqp, p.oqmin, p.oqmax) - p.oqoff);
                 }
             }
 #pragma unroll
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : 2) void igemm_ke
         // zero-initialised once and reused.  Phase 1 writes the fp32 projection, phase 2 adds the optional fp32 residual
         // (H = 1, d = Cout turns this epilogue into "Linear + residual -> the next Linear's int8 rows": the FF output of
         // a transformer block feeding SpatialTransformer.proj_out), quantises and stores 4 codes per lane.
-        const float od = p.oq[0], oz = p.oq[1];
+        const QP oqp = qd_load_qp(p.oq);
         int8_t* o8 = reinterpret_cast<int8_t*>(p.out);
         const int bidx = m0 / p.hdT, t0 = m0 - bidx * p.hdT;
         const bool hres = p.residual != nullptr;
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : 2) void igemm_ke
                     unsigned w = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        w |= (unsigned)((qd_code(v[e] * p.oqpre, od, oz, p.oqmin, p.oqmax) - p.oqoff) & 0xff) << (8 * e);
+                        w |= (unsigned)((qd_code(v[e] * p.oqpre, oqp, p.oqmin, p.oqmax) - p.oqoff) & 0xff) << (8 * e);
                     if (nok) *reinterpret_cast<unsigned*>(ob + (long)(rbase + rl) * p.hddpad) = w;
                 }
             }
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : 2) void igemm_ke
         return;
     }
     if constexpr (OUT == O_HTR) {
-        const float od = p.oq[0], oz = p.oq[1];
+        const QP oqp = qd_load_qp(p.oq);
         int8_t* o8 = reinterpret_cast<int8_t*>(p.out);
         const int bidx = m0 / p.hdT, t0 = m0 - bidx * p.hdT;
         int* sPart = reinterpret_cast<int*>(smem);            // [4][WCOLS] column-sum partials (the ring is dead by now)
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : 2) void igemm_ke
                         const int rowl = tile0 + 4 * fhalf + crow(r);
                         const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rowl] - kz);
                         const float v = (float)I * sc + bias_n;
-                        const int code = qd_code(v * p.oqpre, od, oz, p.oqmin, p.oqmax) - p.oqoff;
+                        const int code = qd_code(v * p.oqpre, oqp, p.oqmin, p.oqmax) - p.oqoff;
                         csum += code;
                         w |= (unsigned)(code & 0xff) << (8 * e);
                     }

@@ -93,15 +93,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const float4 ab0 = *reinterpret_cast<const float4*>(ab + (b * C + c) * 2);
     const float4 ab1 = *reinterpret_cast<const float4*>(ab + (b * C + c) * 2 + 4);
     const float a4[4] = {ab0.x, ab0.z, ab1.x, ab1.z}, s4[4] = {ab0.y, ab0.w, ab1.y, ab1.w};
-    float delta = 1.f, zp = 0.f;
-    if (out) { delta = qp[0]; zp = qp[1]; }
+    QP q{1.f, 0.f, 1.f, false};
+    if (out) q = qd_load_qp(qp);
     unsigned u = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float y = v[j] * a4[j] + s4[j];
         if (apply_silu) y = y * (1.0f / (1.0f + expf(-y)));
         if (yout) yout[row * ldy + c + j] = y;
-        if (out) u |= (unsigned)((qd_code(y, delta, zp, qmin, qmax) - off) & 0xff) << (8 * j);
+        if (out) u |= (unsigned)((qd_code(y, q, qmin, qmax) - off) & 0xff) << (8 * j);
     }
     if (out) *reinterpret_cast<unsigned*>(out + row * ldo + c) = u;
 }
@@ -173,9 +173,9 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(const T* __restrict__ x, 
     for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
         for (int r = 0; r < RPW; ++r) q[r] += __shfl_xor(q[r], o);
-    const float d0 = qp0[0], z0 = qp0[1];
-    const float d1 = nout > 1 ? qp1[0] : 1.f, z1 = nout > 1 ? qp1[1] : 0.f;
-    const float d2 = nout > 2 ? qp2[0] : 1.f, z2 = nout > 2 ? qp2[1] : 0.f;
+    const QP qa = qd_load_qp(qp0);
+    const QP qb = nout > 1 ? qd_load_qp(qp1) : QP{1.f, 0.f, 1.f, false};
+    const QP qc = nout > 2 ? qd_load_qp(qp2) : QP{1.f, 0.f, 1.f, false};
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         rstd[r] = 1.0f / sqrtf(q[r] / (float)C + eps);
@@ -189,9 +189,9 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(const T* __restrict__ x, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float y = (v[r][k][j] - mean[r]) * rstd[r] * g[k][j] + bt[k][j];
-                    u0 |= (unsigned)((qd_code(y, d0, z0, qmin.x, qmax.x) - off.x) & 0xff) << (8 * j);
-                    if (nout > 1) u1 |= (unsigned)((qd_code(y, d1, z1, qmin.y, qmax.y) - off.y) & 0xff) << (8 * j);
-                    if (nout > 2) u2 |= (unsigned)((qd_code(y, d2, z2, qmin.z, qmax.z) - off.z) & 0xff) << (8 * j);
+                    u0 |= (unsigned)((qd_code(y, qa, qmin.x, qmax.x) - off.x) & 0xff) << (8 * j);
+                    if (nout > 1) u1 |= (unsigned)((qd_code(y, qb, qmin.y, qmax.y) - off.y) & 0xff) << (8 * j);
+                    if (nout > 2) u2 |= (unsigned)((qd_code(y, qc, qmin.z, qmax.z) - off.z) & 0xff) << (8 * j);
                 }
                 *reinterpret_cast<unsigned*>(o0 + row * ldo + idx * 4) = u0;
                 if (nout > 1) *reinterpret_cast<unsigned*>(o1 + row * ldo + idx * 4) = u1;

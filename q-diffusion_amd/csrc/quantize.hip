@@ -22,8 +22,8 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const T* __restrict__ x
     if (gid >= rows * groups) return;
     long row = gid / groups;
     int  g   = (int)(gid - row * groups);
-    const float delta = qp[0], zp = qp[1];
-    const int ztrue = (int)zp - off;
+    const QP q = qd_load_qp(qp);
+    const int ztrue = (int)q.zp - off;
     long b = row / S, s = row - b * S;
     const int c = g * 4;
     unsigned u;
@@ -32,13 +32,13 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const T* __restrict__ x
         qd_ld4(x + b * sb + s * row_stride + c0 + c, vec != 0, v);
         u = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) u |= (unsigned)((qd_code(v[j], delta, zp, qmin, qmax) - off) & 0xff) << (8 * j);
+        for (int j = 0; j < 4; ++j) u |= (unsigned)((qd_code(v[j], q, qmin, qmax) - off) & 0xff) << (8 * j);
     } else {
         u = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int code = ztrue;
-            if (c + j < clen) code = qd_code(qd_ld(x + b * sb + s * row_stride + c0 + c + j), delta, zp, qmin, qmax) - off;
+            if (c + j < clen) code = qd_code(qd_ld(x + b * sb + s * row_stride + c0 + c + j), q, qmin, qmax) - off;
             u |= (unsigned)(code & 0xff) << (8 * j);
         }
     }
@@ -60,15 +60,15 @@ __global__ __launch_bounds__(256) void quant_strided_kernel(const T* __restrict_
     const int  ct = blockIdx.y * 64;
     const long b  = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float delta = qp[0], zp = qp[1];
-    const int ztrue = (int)zp - off;
+    const QP q = qd_load_qp(qp);
+    const int ztrue = (int)q.zp - off;
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
         int c = wave * 16 + i;
         int code = ztrue;
         if (ct + c < clen && s0 + lane < S) {
             float v = qd_ld(x + b * sb + (long)(c0 + ct + c) * sc + (s0 + lane) * ss);
-            code = qd_code(v, delta, zp, qmin, qmax) - off;
+            code = qd_code(v, q, qmin, qmax) - off;
         }
         tile[c][lane] = (signed char)code;
     }
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void geglu_quant_kernel(const T* __restrict__ 
     if (gid >= M * chunks) return;
     long row = gid / chunks;
     int ch = (int)(gid - row * chunks);
-    const float delta = qp[0], zp = qp[1];
+    const QP q = qd_load_qp(qp);
     const T* xa = h + row * ldh + ch * 16;
     const T* xg = xa + F;
     v4i v;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void geglu_quant_kernel(const T* __restrict__ 
         for (int j = 0; j < 4; ++j) {
             float a = qd_ld(xa + wd * 4 + j), g = qd_ld(xg + wd * 4 + j);
             float gl = 0.5f * g * (1.0f + qd_erff(g * 0.70710678118654752440f));
-            int code = qd_code(a * gl, delta, zp, qmin, qmax) - off;
+            int code = qd_code(a * gl, q, qmin, qmax) - off;
             u |= (unsigned)(code & 0xff) << (8 * j);
         }
         v[wd] = (int)u;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void quant_heads_rows_kernel(const T* __restri
     const long ntok = (long)B * Tn;
     for (int i = threadIdx.x; i < tpb * H; i += 256) ssum[i] = 0;
     __syncthreads();
-    const float delta = qp[0], zp = qp[1];
+    const QP q = qd_load_qp(qp);
     for (int idx = threadIdx.x; idx < tpb * gpr; idx += 256) {
         const int lt = idx / gpr, g = idx - lt * gpr;
         const long tok = tok0 + lt;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void quant_heads_rows_kernel(const T* __restri
         int sum = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int code = qd_code(v[j] * prescale, delta, zp, qmin, qmax) - off;
+            const int code = qd_code(v[j] * prescale, q, qmin, qmax) - off;
             sum += code;
             u |= (unsigned)(code & 0xff) << (8 * j);
         }
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void quant_heads_tr_kernel(const T* __restrict
     const int dd = dblk * 64 + (threadIdx.x & 63);
     const int sub = threadIdx.x >> 6;  // which 4 of the 16 slots
     if (dd >= dpad) return;
-    const float delta = qp[0], zp = qp[1];
+    const QP q = qd_load_qp(qp);
     const int tile = slot >> 1, half = slot & 1;
     unsigned u = 0;
     int sum = 0;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void quant_heads_tr_kernel(const T* __restrict
         int code = 0;
         if (t < Tn && dd < d) {
             float xv = qd_ld(x + b * sb + (long)t * st + hh * sh + dd * sd) * prescale;
-            code = qd_code(xv, delta, zp, qmin, qmax) - off;
+            code = qd_code(xv, q, qmin, qmax) - off;
             sum += code;
         }
         u |= (unsigned)(code & 0xff) << (8 * j);
@@ -281,6 +281,36 @@ __global__ __launch_bounds__(256) void quant_heads_tr_kernel(const T* __restrict
 }
 
 }  // namespace
+
+// qd_make_qparams: {delta, zero_point} -> {delta, zero_point, rinv, fast} (common.h QP).  One thread per mantissa of x
+// in [1, 2): the three-instruction quotient must equal the IEEE division for every one of them (scaling x by a power of
+// two scales every intermediate exactly, the sign is symmetric), else `fast` is cleared and the kernels divide.
+__global__ void qparams_init_kernel(const float* __restrict__ delta, const float* __restrict__ zp, float* __restrict__ out) {
+    const float d = delta[0];
+    out[0] = d;
+    out[1] = zp[0];
+    out[2] = (float)(1.0 / (double)d);
+    out[3] = (d > 0.f && d < 3.0e38f) ? 1.f : 0.f;
+}
+
+__global__ __launch_bounds__(256) void qparams_check_kernel(float* __restrict__ out) {
+    const unsigned m = blockIdx.x * 256u + threadIdx.x;            // 2^23 mantissas
+    const float x = __uint_as_float(0x3f800000u | m);
+    const float d = out[0], r = out[2];
+    const float y = x * r;
+    const float e = __builtin_fmaf(-y, d, x);
+    const float q = __builtin_fmaf(e, r, y);
+    if (__float_as_uint(q) != __float_as_uint(x / d)) out[3] = 0.f;   // idempotent store: no atomics needed
+}
+
+extern "C" int qd_make_qparams(const float* delta, const float* zero_point, float* out4, void* stream) {
+    QD_REQUIRE(delta && zero_point && out4 && qd_aligned(out4, 16), "qd_make_qparams: null / unaligned pointer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(qparams_init_kernel, dim3(1), dim3(1), 0, st, delta, zero_point, out4);
+    hipLaunchKernelGGL(qparams_check_kernel, dim3(1u << 15), dim3(256), 0, st, out4);
+    QD_LAUNCH_CHECK("qd_make_qparams");
+    return 0;
+}
 
 extern "C" int qd_quantize_act(const void* x, int x_dtype, int64_t B, int64_t C, int64_t S, int64_t sb, int64_t sc,
                                int64_t ss, int c0, int clen, int clen_pad, const float* qparams, int qmin, int qmax,

@@ -40,10 +40,11 @@ def _scalar_tensor(v, device):
 
 
 def qparams_of(quantizer, device):
-    """[delta, zero_point] as a 2-float device tensor (no host sync)."""
+    """Kernel-side parameters of a per-tensor quantiser: the device float[4] {delta, zero_point, rinv, fast} of
+    hip.make_qparams (no host sync)."""
     d = _scalar_tensor(quantizer.delta, device)
     z = _scalar_tensor(quantizer.zero_point, device)
-    return torch.stack([d, z])
+    return hip.make_qparams(d, z)
 
 
 def check_act_zero_point(quantizer, grid):

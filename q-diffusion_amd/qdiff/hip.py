@@ -49,7 +49,7 @@ class ConvDesc(ctypes.Structure):
 EPI_LINEAR, EPI_GEGLU_I8, EPI_HEADS_I8, EPI_HEADS_T_I8 = 0, 1, 2, 3
 
 
-EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_quantize_act", "qd_pack_weights", "qd_pack_weights_t4",
+EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_make_qparams", "qd_quantize_act", "qd_pack_weights", "qd_pack_weights_t4",
            "qd_pack_weights_t8",
            "qd_conv2d_i8", "qd_conv2d_i8_splitk_ws_bytes",
            "qd_conv2d_i8_acc", "qd_groupnorm_ws_bytes", "qd_groupnorm_silu_quant", "qd_layernorm_quant",
@@ -71,6 +71,7 @@ def load():
     lib.qd_groupnorm_ws_bytes.restype = ctypes.c_int64
     lib.qd_groupnorm_ws_bytes.argtypes = [ctypes.c_int64] * 3
     i64, i32, vp, f32 = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_float
+    lib.qd_make_qparams.argtypes = [vp, vp, vp, vp]
     lib.qd_quantize_act.argtypes = [vp, i32, i64, i64, i64, i64, i64, i64, i32, i32, i32, vp, i32, i32, i32, vp, i64, i32, vp]
     lib.qd_pack_weights.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp, vp, vp]
     lib.qd_pack_weights_t4.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]
@@ -144,12 +145,31 @@ def pad32(n):
     return (n + 31) // 32 * 32
 
 
+def make_qparams(delta, zero_point):
+    """{delta, zero_point} (0-dim / 1-element float32 device tensors) -> the float[4] the kernels read
+    ({delta, zero_point, rinv, fast}: include/qdiff_hip.h, qd_make_qparams).  No host synchronisation."""
+    d = delta.detach().reshape(1).float().contiguous()
+    z = zero_point.detach().reshape(1).float().contiguous()
+    out = torch.empty(4, dtype=torch.float32, device=d.device)
+    _check(load().qd_make_qparams(_ptr(d, "delta"), _ptr(z, "zero_point"), _ptr(out), _stream()), "qd_make_qparams")
+    return out
+
+
+def _qp(t):
+    """Kernel-side quantiser parameters: float[4]; a legacy {delta, zero_point} pair is completed on the fly."""
+    if t is None or t.numel() == 4:
+        return t
+    if t.numel() != 2:
+        raise HipEngineError("qparams must be {delta, zero_point} or the float[4] of make_qparams")
+    return make_qparams(t[0], t[1])
+
+
 def quantize_act(x, B, C, S, strides, qparams, grid, out, ldo, c0=0, clen=None, oc0=0):
     """x: any float tensor addressed as logical [B][C][S] by element strides (sb, sc, ss)."""
     clen = C - c0 if clen is None else clen
     sb, sc, ss = strides
     _check(load().qd_quantize_act(_ptr(x, "x"), _dtype(x), B, C, S, sb, sc, ss, c0, clen, pad16(clen),
-                                  _ptr(qparams, "qparams"), grid.qmin, grid.qmax, grid.off, _ptr(out, "out"), ldo, oc0,
+                                  _ptr(_qp(qparams), "qparams"), grid.qmin, grid.qmax, grid.off, _ptr(out, "out"), ldo, oc0,
                                   _stream()), "qd_quantize_act")
 
 
@@ -226,6 +246,7 @@ def _conv_desc(c):
     d.w_tiled = 1 if c.w_tiled else 0
     d.epilogue = c.epilogue or EPI_LINEAR
     if d.epilogue != EPI_LINEAR:
+        c.oq_params = _qp(c.oq_params)              # kept on the call object: the pointer must outlive the launch
         d.oq_params = _ptr(c.oq_params, "oq_params")
         d.oq_min, d.oq_max, d.oq_off = c.oq_grid.qmin, c.oq_grid.qmax, c.oq_grid.off
         d.out_dtype = F32                           # unused: the output is int8
@@ -255,7 +276,7 @@ def groupnorm_silu_quant(x, B, S, C, ldx, groups, eps, gamma, beta, silu, qparam
     """part: optional [B][nchunk][C][2] fp32 first-level statistics written by the producer of x (ConvCall.gn_part)."""
     g = grid or Grid(0, 0, 0)
     _check(load().qd_groupnorm_silu_quant(_ptr(x), _dtype(x), B, S, C, ldx, groups, float(eps), _ptr(gamma), _ptr(beta),
-                                          1 if silu else 0, _ptr(qparams), g.qmin, g.qmax, g.off, _ptr(out), ldo,
+                                          1 if silu else 0, _ptr(_qp(qparams)), g.qmin, g.qmax, g.off, _ptr(out), ldo,
                                           _ptr(yout), ldy, _ptr(ws), _ptr(part), part.shape[1] if part is not None else 0,
                                           _stream()), "qd_groupnorm_silu_quant")
 
@@ -263,6 +284,7 @@ def groupnorm_silu_quant(x, B, S, C, ldx, groups, eps, gamma, beta, silu, qparam
 def layernorm_quant(x, M, C, ldx, eps, gamma, beta, qparams_list, grids, outs, ldo):
     n = len(outs)
     vp, i32 = ctypes.c_void_p, ctypes.c_int
+    qparams_list = [_qp(q) for q in qparams_list]
     qp = (vp * n)(*[q.data_ptr() for q in qparams_list])
     for q in list(qparams_list) + list(outs):
         _ptr(q)
@@ -275,13 +297,13 @@ def layernorm_quant(x, M, C, ldx, eps, gamma, beta, qparams_list, grids, outs, l
 
 
 def geglu_quant(h, M, F, ldh, qparams, grid, out, ldo):
-    _check(load().qd_geglu_quant(_ptr(h), _dtype(h), M, F, ldh, _ptr(qparams), grid.qmin, grid.qmax, grid.off, _ptr(out),
+    _check(load().qd_geglu_quant(_ptr(h), _dtype(h), M, F, ldh, _ptr(_qp(qparams)), grid.qmin, grid.qmax, grid.off, _ptr(out),
                                  ldo, _stream()), "qd_geglu_quant")
 
 
 def quantize_heads(x, B, T, H, d, strides, prescale, qparams, grid, transpose, out, rsum, Tpad, dpad):
     sb, st, sh, sd = strides
-    _check(load().qd_quantize_heads(_ptr(x), _dtype(x), B, T, H, d, sb, st, sh, sd, float(prescale), _ptr(qparams),
+    _check(load().qd_quantize_heads(_ptr(x), _dtype(x), B, T, H, d, sb, st, sh, sd, float(prescale), _ptr(_qp(qparams)),
                                     grid.qmin, grid.qmax, grid.off, 1 if transpose else 0, _ptr(out), _ptr(rsum), Tpad,
                                     dpad, _stream()), "qd_quantize_heads")
 
@@ -293,7 +315,7 @@ def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, 
     g = oq_grid
     _check(load().qd_attn_i8(_ptr(q), _ptr(k), _ptr(vt), None, None, _ptr(vsum), BH, H, T, S, d, Tpad, Spad,
                              dpad, _ptr(prm), wbits, wmin, wmax, 1 if q_asym else 0, _ptr(out), ldo,
-                             _ptr(out8), out8.stride(0) if out8 is not None else 0, _ptr(oq_params),
+                             _ptr(out8), out8.stride(0) if out8 is not None else 0, _ptr(_qp(oq_params)),
                              g.qmin if g else 0, g.qmax if g else 0, g.off if g else 0, _stream()), "qd_attn_i8")
 
 

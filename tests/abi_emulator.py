@@ -19,6 +19,11 @@ def _codes(x, qp, grid):
     return torch.clamp(torch.round(x / d) + z, grid.qmin, grid.qmax)
 
 
+def make_qparams(delta, zero_point):
+    d, z = delta.detach().reshape(()).float(), zero_point.detach().reshape(()).float()
+    return torch.stack([d, z, 1.0 / d, torch.ones(())])
+
+
 def quantize_act(x, B, C, S, strides, qparams, grid, out, ldo, c0=0, clen=None, oc0=0):
     clen = C - c0 if clen is None else clen
     sb, sc, ss = strides
@@ -303,6 +308,6 @@ def splitk_ws_bytes(c):
 def install(monkeypatch):
     """Replace qdiff.hip's device entry points by the emulation (CPU tensors only)."""
     from qdiff import hip
-    for name in ("quantize_act", "pack_weights", "pack_weights_t4", "pack_weights_t8", "conv2d_i8", "groupnorm_ws_bytes", "groupnorm_silu_quant",
+    for name in ("make_qparams", "quantize_act", "pack_weights", "pack_weights_t4", "pack_weights_t8", "conv2d_i8", "groupnorm_ws_bytes", "groupnorm_silu_quant",
                  "layernorm_quant", "geglu_quant", "quantize_heads", "attn_i8", "splitk_ws_bytes", "bmm_qk_i8", "bmm_pv_i8"):
         monkeypatch.setattr(hip, name, globals()[name])

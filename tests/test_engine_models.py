@@ -7,7 +7,12 @@ differ by ~1e-7 relative and occasionally flip a round() tie; a quantised networ
 flips.  The reference is subject to the same effect: evaluating the SAME fake-quant network in fp64
 (oracle tier T2x, QuantCkpt64) moves its output by 2.5e-2 .. 7e-2 of range.  Stated bound for
 (weight+act) quantised UNets:
-    max|engine - ref_fp32| <= 2 * max|ref_fp32 - ref_fp64| + 1e-3 * range   and   cosine >= 0.995 ;
+    max|engine - ref_fp64| <= 1.25 * max|ref_fp32 - ref_fp64| + 1e-3 * range     (the engine is at least as close to
+                                                 exact arithmetic as the reference's own fp32 run; measured 0.8x .. 1.0x)
+    max|engine - ref_fp32| <= 1.5  * max|ref_fp32 - ref_fp64| + 1e-3 * range     (two realisations of a chaotic map can
+                                                 be up to the sum of their distances apart; measured 0.9x .. 1.3x)
+    cosine(engine, ref_fp32) >= 0.995, cosine(engine, ref_fp64) >= cosine(ref_fp32, ref_fp64) - 1e-3
+(round 1 allowed 2x; the discriminating per-block bounds are in tests/test_block_parity.py);
 weights-only and fp states run plain fp32 library convolutions: max|diff| <= 1e-3 * max|ref|.
 """
 import os
@@ -90,8 +95,9 @@ def test_quantised_unet_matches_reference(cuda, name):
     print(f"[{name}] engine vs fp64 oracle: {d64 / mx:.2e} (cos {cos64:.7f}) | reference fp32 vs fp64 oracle: "
           f"{dself / mx:.2e} (cos {cosself:.7f})")
     # bound relative to the reference's own rounding-noise envelope (module docstring)
-    assert d <= 2.0 * dself + 1e-3 * mx, f"{name}: {d / mx:.3e} of range vs envelope {dself / mx:.3e}"
-    assert cos >= 0.995
+    assert d64 <= 1.25 * dself + 1e-3 * mx, f"{name}: engine is {d64 / mx:.3e} of range from the fp64 evaluation, the reference {dself / mx:.3e}"
+    assert d <= 1.5 * dself + 1e-3 * mx, f"{name}: {d / mx:.3e} of range vs envelope {dself / mx:.3e}"
+    assert cos >= 0.995 and cos64 >= cosself - 1e-3
     if name in TINY + ["cifar_full"]:
         qnn.set_quant_state(True, False)
         d, cos, mx = _metrics(_run(qnn, fx, cuda), fx["out_w"])
@@ -160,6 +166,13 @@ def test_packed_checkpoint_round_trip_on_gpu(cuda, name, tmp_path):
     y1 = _run(q2, fx, cuda)
     assert torch.equal(y0, y1)
     assert all(m.weight.numel() == 0 for m in q2.modules() if isinstance(m, qdiff.QuantModule))
+    # ... and that output is the REFERENCE's (golden made by the real reference from the fp32 checkpoint), inside the
+    # envelope of the whole-UNet test: the packed file carries everything the reference-format checkpoint determined
+    ref = fx["out_wa"]
+    d = (y1 - ref).abs().max().item()
+    dself = (ref.double() - _oracle64(fx)).abs().max().item()
+    cos = torch.nn.functional.cosine_similarity(y1.flatten(), ref.flatten(), dim=0).item()
+    assert d <= 1.5 * dself + 1e-3 * ref.abs().max().item() and cos >= 0.995, (d, dself, cos)
 
 
 @pytest.mark.parametrize("name", ["sd_tiny", "ldm_tiny"])
@@ -201,3 +214,25 @@ def test_whole_step_graph_plms_equals_eager_sampler(cuda):
         got = sampling.DevicePLMS(unet, table, x, cond=c, uncond=uc, scale=3.0, use_graph=True).run()
     torch.cuda.synchronize()
     assert torch.isfinite(want).all() and torch.equal(got, want)
+
+
+def test_device_plms_on_gpu_matches_reference_sampler_golden(cuda):
+    """DevicePLMS (device-resident step state, one HIP graph per PLMS step) driving the deterministic stub eps-model ON THE
+    GPU vs the trajectory the real reference's PLMSSampler produced with the same stub (tests/golden/samplers.pt): the
+    sampler arithmetic is identical; tanh / division on the GPU differ from the CPU's in the last ulps, hence 2e-5 of range
+    over 50 steps instead of bit equality (the CPU test test_sampling_sharding.py is bit-exact)."""
+    from qdiff import sampling
+    from test_sampling_sharding import stub_eps
+    fx = load_fixture("samplers.pt")["plms"]
+    calls = []
+
+    def unet(x, t, c=None):
+        calls.append(x.shape[0])
+        return stub_eps(x, t, c)
+    table = sampling.StepTable(sampling.ldm_betas(fx["ls"], fx["le"]), fx["steps"], eta=0.0)
+    with torch.no_grad():
+        got = sampling.DevicePLMS(unet, table, fx["xT"].to(cuda), cond=fx["c"].to(cuda), uncond=fx["uc"].to(cuda),
+                                  scale=fx["scale"], use_graph=True).run()
+    torch.cuda.synchronize()
+    want = fx["out"]
+    assert (got.cpu() - want).abs().max().item() <= 2e-5 * want.abs().max().item()

@@ -57,6 +57,34 @@ def test_quantize_act_bit_exact(cuda, layout, sym, C):
     assert (got[..., 16 + C:] == zp - off).all()              # pad lanes hold "true zero"
 
 
+def test_exact_fast_division_certificate(cuda):
+    """qd_make_qparams: the kernels replace x / delta by y = x*rinv; e = fma(-y, delta, x); q = fma(e, rinv, y) only when
+    the device-side exhaustive check (all 2^23 mantissas) certified bit equality for that delta.  Codes must equal
+    torch.round(x / delta) bit for bit either way; awkward deltas (all-ones mantissa, denormal-adjacent, huge) included."""
+    import struct
+    from qdiff import engine, hip
+    g = torch.Generator().manual_seed(4)
+    ones = struct.unpack("f", struct.pack("I", 0x3dffffff))[0]          # mantissa all ones
+    deltas = [0.037, 0.0151234, 1e-3, 1.0, 3.0000002, ones, 7.3e-7, 123.456, 1e-30] + [float(v) for v in torch.rand(8, generator=g) * 0.1 + 1e-4]
+    x = torch.cat([torch.randn(1 << 16, generator=g) * 3.0, torch.tensor([0.0, -0.0, 0.5 * 0.037, 1.5 * 0.037, 2.5 * 0.037, 1e-20, -1e-20])])
+    M = x.numel()
+    xd = x.to(cuda)
+    grid = engine.act_grid(8, False)
+    fast = 0
+    for d in deltas:
+        dt = torch.tensor(d, dtype=torch.float32)
+        qp = hip.make_qparams(dt.to(cuda), torch.tensor(128.0, device=cuda))
+        vals = qp.cpu()
+        assert vals[0].item() == dt.item() and vals[1].item() == 128.0
+        fast += int(vals[3].item() != 0)
+        out = torch.empty((1, hip.pad16(M)), dtype=torch.int8, device=cuda)
+        hip.quantize_act(xd, 1, M, 1, (0, 1, 0), qp, grid, out, hip.pad16(M))
+        want = torch.clamp(torch.round(x / dt) + 128.0, 0, 255) - 128
+        assert torch.equal(out.cpu()[0, :M].float(), want), d
+    print(f"\n[fastdiv] {fast} of {len(deltas)} deltas certified for the 3-instruction quotient")
+    assert fast >= len(deltas) - 3
+
+
 def test_quantize_act_split_segments(cuda):
     from qdiff import engine, hip
     g = torch.Generator().manual_seed(2)
