@@ -193,6 +193,24 @@ int qd_pack_weights_t8(const float* w, const float* alpha, const float* delta, c
 int qd_conv2d_i8_acc(const qd_conv_desc* d, int32_t* iout, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K6  timestep-embedding MLPs.   Replaces `time_embed` = Linear -> SiLU -> Linear (ldm openaimodel.py:758-759; ddim
+ *     diffusion.py:318-320) and the per-ResBlock `emb_layers` / `temb_proj` = SiLU -> Linear on the shared embedding
+ *     (openaimodel.py:225-232 with qdiff/quant_block.py:98-107; ddim diffusion.py:127), every Linear a QuantModule
+ *     (quant_layer.py:248-279) on M = batch rows: one launch evaluates n_layers Linears that share the input x [B][K]
+ *     (fp32, row stride ldx): out[b][layer.out_off + n] = Linear_layer(act_quant_layer(silu?(x)))[b][n].
+ *     layers: DEVICE array of n_layers records, 64 bytes each:
+ *         { const uint8_t* w (tile-ordered weights, first K-step of the only segment); const float* scale;
+ *           const int32_t* zc; const int32_t* zw; const float* bias; const float* qparams (float[4]);
+ *           const int32_t* zfill; int32_t Cout; int32_t out_off; }          (semantics of qd_conv_seg / qd_conv_desc)
+ *     blocks: DEVICE int32 [n_blocks][2] = {layer index, first output channel}: one workgroup per 64 output channels.
+ *     qmin/qmax/off: the (common) activation grid.  B*K must fit LDS (<= ~44 KB): callers split taller batches.
+ *     Results equal qd_quantize_act + qd_conv2d_i8 on the same SiLU values bit for bit (same integers, same float order).
+ * ------------------------------------------------------------------------------------------ */
+int qd_temb_mlp(const float* x, int64_t ldx, int B, int K, int apply_silu, const void* layers, int n_layers,
+                const int32_t* blocks, int n_blocks, int wbits, int qmin, int qmax, int off, float* out, int64_t ldo,
+                void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * K5  GroupNorm -> SiLU -> quantise.   Replaces nn.GroupNorm(32,C) / GroupNorm32 → x*sigmoid(x)
  *     → act_quantizer of the following QuantModule (ddim/models/diffusion.py:121-123,127-130;
  *     ldm/modules/diffusionmodules/openaimodel.py:201-205,225-232, util.py:214-216;

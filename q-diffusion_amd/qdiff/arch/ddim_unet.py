@@ -209,7 +209,12 @@ class Model(nn.Module):
         assert x.shape[2] == x.shape[3] == self.resolution
         x = x.contiguous(memory_format=torch.channels_last)
         temb = get_timestep_embedding(t, self.ch)
-        temb = self.temb.dense[1](nonlinearity(self.temb.dense[0](temb)))
+        from ..quant_block import time_mlp
+        from ..quant_layer import QuantModule
+        if isinstance(self.temb.dense[0], QuantModule):
+            temb = time_mlp(self.temb.dense[0], self.temb.dense[1], temb, act=nonlinearity)   # two K6 launches on the integer path
+        else:
+            temb = self.temb.dense[1](nonlinearity(self.temb.dense[0](temb)))
 
         skips = [self.conv_in(x)]
         for lvl, stage in enumerate(self.down):

@@ -53,7 +53,7 @@ EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_make_qparams",
            "qd_pack_weights_t8",
            "qd_conv2d_i8", "qd_conv2d_i8_splitk_ws_bytes",
            "qd_conv2d_i8_acc", "qd_groupnorm_ws_bytes", "qd_groupnorm_silu_quant", "qd_layernorm_quant",
-           "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8", "qd_bmm_qk_i8", "qd_bmm_pv_i8"]
+           "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8", "qd_bmm_qk_i8", "qd_bmm_pv_i8", "qd_temb_mlp"]
 
 _lib = None
 
@@ -90,6 +90,7 @@ def load():
                                       vp, vp, i32, i32, vp]
     lib.qd_attn_i8.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp,
                                i64, vp, i64, vp, i32, i32, i32, vp]
+    lib.qd_temb_mlp.argtypes = [vp, i64, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i64, vp]
     lib.qd_bmm_qk_i8.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i64, i64, vp]
     lib.qd_bmm_pv_i8.argtypes = [vp, i64, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i64, i64, vp]
     if lib.qd_abi_version() != 10:
@@ -329,3 +330,54 @@ def bmm_pv_i8(w, v8t, vsum, BH, T, S, d, Spad, dpad, prm, wbits, wmin, wmax, out
     """w [BH][T][S] fp32 probabilities -> quantised (prm[3..6]) -> out [BH][d][T] fp32."""
     _check(load().qd_bmm_pv_i8(_ptr(w), w.stride(1), w.stride(0), _ptr(v8t), _ptr(vsum), BH, T, S, d, Spad, dpad, _ptr(prm),
                                wbits, wmin, wmax, _ptr(out), out.stride(1), out.stride(0), _stream()), "qd_bmm_pv_i8")
+
+
+class _TembLayer(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("zc", ctypes.c_void_p), ("zw", ctypes.c_void_p),
+                ("bias", ctypes.c_void_p), ("qp", ctypes.c_void_p), ("zfill", ctypes.c_void_p),
+                ("Cout", ctypes.c_int32), ("out_off", ctypes.c_int32)]
+
+
+_TEMB_DESC = {}          # tuple(id(plan)) -> (layer records on the device, block table, #blocks, the plans themselves)
+
+
+def _temb_desc(plans, offsets, device):
+    key = tuple(id(p) for p in plans) + tuple(offsets)
+    hit = _TEMB_DESC.get(key)
+    if hit is not None:
+        return hit
+    recs = (_TembLayer * len(plans))()
+    blocks = []
+    for i, (p, off) in enumerate(zip(plans, offsets)):
+        sg = p.segs[0]
+        r = recs[i]
+        r.w = p.pack.wq.data_ptr() + sg["kstep0"] * ((p.Cout + 31) // 32) * (1024 if p.pack.wbits == 4 else 2048)
+        r.scale, r.zc, r.zw = _ptr(sg["scale"]), _ptr(sg.get("zc")), _ptr(sg.get("zw"))
+        r.bias, r.qp, r.zfill = _ptr(p.bias), _ptr(p.qparams[0]), _ptr(sg.get("zfill"))
+        r.Cout, r.out_off = p.Cout, off
+        blocks += [(i, n0) for n0 in range(0, p.Cout, 64)]
+    raw = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8).to(device)
+    tab = torch.tensor(blocks, dtype=torch.int32).to(device).contiguous()
+    if len(_TEMB_DESC) > 64:
+        _TEMB_DESC.clear()
+    hit = _TEMB_DESC[key] = (raw, tab, len(blocks), list(plans))     # the plans (and through them every pointer) stay alive
+    return hit
+
+
+def temb_mlp(x, silu, plans, offsets, out):
+    """x [B][K] fp32 rows; plans: single-segment ConvPlans of Linears that share this input; out[:, off:off+Cout] per plan."""
+    B, K = x.shape
+    p0 = plans[0]
+    if any(len(p.segs) != 1 or p.pack.wbits != p0.pack.wbits or p.pack.Cin != K or p.pack.taps != 1 or
+           (p.grids[0].qmin, p.grids[0].qmax, p.grids[0].off) != (p0.grids[0].qmin, p0.grids[0].qmax, p0.grids[0].off) for p in plans):
+        raise HipEngineError("temb_mlp: the Linears must share input width, weight bits and activation grid (one segment each)")
+    if x.stride(1) != 1 or x.stride(0) % 4 != 0:
+        x = x.contiguous()
+    raw, tab, nblk, _ = _temb_desc(plans, offsets, x.device)
+    g = p0.grids[0]
+    rows = max(1, min(B, (44 * 1024) // K))
+    for b0 in range(0, B, rows):
+        xb, ob = x[b0:b0 + rows], out[b0:b0 + rows]
+        _check(load().qd_temb_mlp(_ptr(xb, "x"), xb.stride(0), xb.shape[0], K, 1 if silu else 0, raw.data_ptr(), len(plans),
+                                  tab.data_ptr(), nblk, p0.pack.wbits, g.qmin, g.qmax, g.off, _ptr(ob, "out"), ob.stride(0),
+                                  _stream()), "qd_temb_mlp")

@@ -11,6 +11,7 @@ Each block has two forwards:
     q/k/softmax/v quantisation + both attention contractions are one fused kernel (K7/K8).
 """
 import logging
+import os
 from types import MethodType
 
 import torch
@@ -107,6 +108,71 @@ def _linear_rows(lin, rows, residual=None, gn_stats=False):
     M, K = rows.shape
     xq = engine.quantize_rows(rows, plan, 1, K, M, (0, rows.stride(1), rows.stride(0)))
     return engine.conv_forward(plan, xq, 1, 1, M, 1, M, residual=residual, gn_stats=gn_stats)
+
+
+# A/B knob for measurements only (tools/r02_ab.sh): "0" evaluates the embedding projections layer by layer
+_TEMB_FUSION = os.environ.get("QDIFF_TEMB_FUSION", "1") != "0"
+
+
+class EmbGroup:
+    """The `SiLU -> Linear` timestep-embedding projections of all residual blocks of one UNet (reference
+    quant_block.py:98-107 `emb_layers`, ddim diffusion.py:127 `temb_proj`): every block receives the SAME embedding
+    tensor, so the first block that asks evaluates all of them with ONE launch (K6, csrc/temb_mlp.hip) and the others
+    pick their slice.  Falls back to the per-block composition (returns None) whenever a projection is not on the
+    integer path, is tracking its range, or still needs its data-dependent initialisation."""
+
+    def __init__(self):
+        self.members = []            # (block, QuantModule)
+        self._emb, self._out, self._offs = None, None, {}
+
+    def register(self, blk, linear):
+        self.members.append((blk, linear))
+        blk.__dict__["_emb_group"] = self
+
+    def get(self, blk, emb):
+        if self._emb is not emb:
+            self._emb, self._out = emb, None
+            self._compute(emb)
+        if self._out is None:
+            return None
+        off, n = self._offs[id(blk)]
+        return self._out[:, off:off + n]
+
+    def _compute(self, emb):
+        lins = [l for _, l in self.members]
+        if not _TEMB_FUSION or not torch.is_tensor(emb) or emb.dim() != 2 or not emb.is_floating_point() or len(lins) < 2:
+            return
+        if not _int_mode(*lins) or any(l.split or l.kind != 'linear' or not l.act_quantizer.inited for l in lins):
+            return
+        plans = [l.conv_plan() for l in lins]
+        p0 = plans[0]
+        g0 = (p0.grids[0].qmin, p0.grids[0].qmax, p0.grids[0].off)
+        if any(len(p.segs) != 1 or p.pack.Cin != emb.shape[1] or p.pack.wbits != p0.pack.wbits
+               or (p.grids[0].qmin, p.grids[0].qmax, p.grids[0].off) != g0 for p in plans):
+            return
+        offs, tot = [], 0
+        for (blk, _), p in zip(self.members, plans):
+            self._offs[id(blk)] = (tot, p.Cout)
+            offs.append(tot)
+            tot += (p.Cout + 63) // 64 * 64
+        out = torch.empty((emb.shape[0], tot), dtype=torch.float32, device=emb.device)
+        engine.hip.temb_mlp(emb.float(), True, plans, offs, out)
+        self._out = out
+
+
+def time_mlp(lin0, lin1, t_emb, act=F.silu):
+    """`Linear -> SiLU -> Linear` on the sinusoid table (reference openaimodel.py:758-759 `time_embed`, ddim
+    diffusion.py:318-320): two K6 launches on the integer path, the plain composition otherwise."""
+    if (_TEMB_FUSION and _int_mode(lin0, lin1) and lin0.kind == 'linear' and lin1.kind == 'linear' and not (lin0.split or lin1.split)
+            and lin0.act_quantizer.inited and lin1.act_quantizer.inited and torch.is_tensor(t_emb) and t_emb.dim() == 2):
+        p0, p1 = lin0.conv_plan(), lin1.conv_plan()
+        if len(p0.segs) == 1 and len(p1.segs) == 1:
+            h = torch.empty((t_emb.shape[0], p0.Cout), dtype=torch.float32, device=t_emb.device)
+            engine.hip.temb_mlp(t_emb.float(), False, [p0], [0], h)
+            out = torch.empty((t_emb.shape[0], p1.Cout), dtype=torch.float32, device=t_emb.device)
+            engine.hip.temb_mlp(h, True, [p1], [0], out)
+            return out
+    return lin1(act(lin0(t_emb)))
 
 
 class _AttnQuant:
@@ -225,8 +291,11 @@ class QuantResBlock(BaseQuantBlock, ldm_unet.TimestepBlock):
         S = H * W
         rows = _nhwc_rows(x)
         xq = _gn_silu_to(conv1, rows, B, S, C, self.in_layers[0])
-        e = self.emb_layers(emb)                                      # SiLU + integer linear -> [B, Cout]
-        h = conv1.forward_codes(xq, B, H, W, rowbias=e.float().contiguous(), gn_stats=True)
+        grp = self.__dict__.get("_emb_group")
+        e = grp.get(self, emb) if grp is not None else None           # all blocks' projections in one launch (K6)
+        if e is None:
+            e = self.emb_layers(emb).float().contiguous()             # SiLU + integer linear -> [B, Cout]
+        h = conv1.forward_codes(xq, B, H, W, rowbias=e, gn_stats=True)
         hq = _gn_silu_to(conv2, h, B, S, self.out_channels, self.out_layers[0])
         if isinstance(self.skip_connection, nn.Identity):
             res = rows
@@ -533,8 +602,11 @@ class QuantResnetBlock(BaseQuantBlock):
         S = H * W
         rows = _nhwc_rows(x)
         xq = _gn_silu_to(self.conv1, rows, B, S, C, self.norm1)
-        e = self.temb_proj(ddim_unet.nonlinearity(temb))
-        h = self.conv1.forward_codes(xq, B, H, W, rowbias=e.float().contiguous())
+        grp = self.__dict__.get("_emb_group")
+        e = grp.get(self, temb) if grp is not None else None
+        if e is None:
+            e = self.temb_proj(ddim_unet.nonlinearity(temb)).float().contiguous()
+        h = self.conv1.forward_codes(xq, B, H, W, rowbias=e)
         hq = _gn_silu_to(self.conv2, h, B, S, self.out_channels, self.norm2)
         if self.in_channels != self.out_channels:
             sk = self.conv_shortcut(x) if self.use_conv_shortcut else self.nin_shortcut(x, split=split)

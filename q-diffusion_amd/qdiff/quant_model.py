@@ -13,8 +13,9 @@ import torch.nn as nn
 
 from types import MethodType
 
-from .quant_block import (BaseQuantBlock, QuantAttentionBlock, QuantAttnBlock, QuantBasicTransformerBlock,
-                          QuantQKMatMul, QuantResBlock, QuantSMVMatMul, get_specials, reference_classes)
+from .quant_block import (BaseQuantBlock, EmbGroup, QuantAttentionBlock, QuantAttnBlock, QuantBasicTransformerBlock,
+                          QuantQKMatMul, QuantResBlock, QuantResnetBlock, QuantSMVMatMul, get_specials, reference_classes,
+                          time_mlp)
 from .quant_layer import QuantModule, StraightThrough
 from .arch import ldm_unet
 
@@ -35,6 +36,7 @@ class QuantModel(nn.Module):
         self.quant_module_refactor(self.model, weight_quant_params, act_quant_params)
         self.quant_block_refactor(self.model, weight_quant_params, act_quant_params)
         self._adopt_reference_modules()
+        self._fuse_time_embedding()
         self._graphs = None
         self._quant_state = (False, False)
 
@@ -64,6 +66,20 @@ class QuantModel(nn.Module):
                 setattr(module, name, target(child, act_quant_params, sm_abit=self.sm_abit, quant_matmuls=self.quant_act))
             else:
                 setattr(module, name, target(child, act_quant_params))
+
+    def _fuse_time_embedding(self):
+        """K6: one launch for the `SiLU -> Linear` embedding projections of all residual blocks (they all receive the same
+        embedding tensor), two for the `time_embed` MLP of the LDM / SD UNet (this repo's class or the reference's)."""
+        group = EmbGroup()
+        for m in self.model.modules():
+            if isinstance(m, QuantResBlock) and not m.use_scale_shift_norm and isinstance(m.emb_layers[-1], QuantModule):
+                group.register(m, m.emb_layers[-1])
+            elif isinstance(m, QuantResnetBlock) and isinstance(m.temb_proj, QuantModule):
+                group.register(m, m.temb_proj)
+        te = getattr(self.model, "time_embed", None)
+        if (isinstance(te, nn.Sequential) and len(te) == 3 and isinstance(te[0], QuantModule) and isinstance(te[2], QuantModule)
+                and isinstance(te[1], nn.SiLU)):
+            te.forward = MethodType(lambda seq, t_emb: time_mlp(seq[0], seq[2], t_emb), te)
 
     def _adopt_reference_modules(self):
         """Drop-in use on the REFERENCE's own UNet classes (scripts/txt2img.py:381-383 builds its LatentDiffusion UNet, then

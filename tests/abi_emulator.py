@@ -300,6 +300,16 @@ def bmm_pv_i8(w, v8t, vsum, BH, T, S, d, Spad, dpad, prm, wbits, wmin, wmax, out
     out.copy_(torch.einsum("bts,bcs->bct", u.double(), vi.double()).float() * osc)
 
 
+def temb_mlp(x, silu, plans, offsets, out):
+    """qd_temb_mlp: SiLU -> each Linear's own activation quantiser -> exact integer contraction -> generic epilogue."""
+    from qdiff import engine
+    y = F.silu(x.float()) if silu else x.float()
+    B, K = y.shape
+    for plan, off in zip(plans, offsets):
+        xq = engine.quantize_rows(y, plan, 1, K, B, (0, 1, y.stride(0)))
+        out[:, off:off + plan.Cout] = engine.conv_forward(plan, xq, 1, 1, B, 1, B, splitk=False)
+
+
 def splitk_ws_bytes(c):
     """The emulation never splits K (the schedule does not change results)."""
     return 0
@@ -309,5 +319,5 @@ def install(monkeypatch):
     """Replace qdiff.hip's device entry points by the emulation (CPU tensors only)."""
     from qdiff import hip
     for name in ("make_qparams", "quantize_act", "pack_weights", "pack_weights_t4", "pack_weights_t8", "conv2d_i8", "groupnorm_ws_bytes", "groupnorm_silu_quant",
-                 "layernorm_quant", "geglu_quant", "quantize_heads", "attn_i8", "splitk_ws_bytes", "bmm_qk_i8", "bmm_pv_i8"):
+                 "layernorm_quant", "geglu_quant", "quantize_heads", "attn_i8", "splitk_ws_bytes", "bmm_qk_i8", "bmm_pv_i8", "temb_mlp"):
         monkeypatch.setattr(hip, name, globals()[name])

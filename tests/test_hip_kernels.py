@@ -655,3 +655,42 @@ def test_standalone_bmm_kernels_asymmetric_ragged(cuda, smb):
     want_a = torch.einsum("bts,bcs->bct", fq(p, aq_w), fq(v, aq_v))
     got_a = engine.smv_matmul_int(aq_w, aq_v, p.to(cuda), v.to(cuda)).cpu()
     assert (got_a.double() - want_a).abs().max() <= 2e-6 * want_a.abs().max()
+
+
+@pytest.mark.parametrize("w_bits,B,K,widths", [(4, 16, 1280, (320, 640, 1280, 320)), (4, 5, 224, (224, 448)), (8, 64, 512, (128, 256, 256)),
+                                                (4, 40, 1280, (1280,))])
+def test_temb_mlp_equals_generic_path(cuda, w_bits, B, K, widths):
+    """K6 (qd_temb_mlp): L Linears sharing one input, each with its own activation quantiser, in one launch — equal BIT FOR
+    BIT to qd_quantize_act + qd_conv2d_i8 per layer (same codes, same integers, same float order); with the SiLU folded in,
+    equal to the generic path on torch's SiLU up to the last ulp of exp() (codes may flip on exact ties only)."""
+    from qdiff import engine, hip
+    g = torch.Generator().manual_seed(81)
+    x = torch.randn(B, K, generator=g) * 1.5
+    plans = []
+    for i, n in enumerate(widths):
+        w = torch.randn(n, K, generator=g) * 0.05
+        q = _weight_quantizer(w, w_bits, True, g)
+        for silu_in in (x, F.silu(x)):
+            pass
+        d, z = R.uaq_init_scale(F.silu(x) * (1.0 + 0.1 * i), 8, False, False, "max")
+        plans.append(engine.build_conv_plan(engine.pack_module_weights(w.to(cuda), [q], 0), [_aq(d, z)], 1, 1, 1, 0,
+                                            (torch.randn(n, generator=g) * 0.1).to(cuda)))
+    offs, tot = [], 0
+    for n in widths:
+        offs.append(tot)
+        tot += (n + 63) // 64 * 64
+    xd = x.to(cuda)
+    for silu in (False, True):
+        out = torch.full((B, tot), float("nan"), device=cuda)
+        hip.temb_mlp(xd, silu, plans, offs, out)
+        y = F.silu(xd) if silu else xd
+        torch.cuda.synchronize()
+        for p, off in zip(plans, offs):
+            xq = engine.quantize_rows(y, p, 1, K, B, (0, 1, K))
+            want = engine.conv_forward(p, xq, 1, 1, B, 1, B, splitk=False)
+            got = out[:, off:off + p.Cout]
+            if not silu:
+                assert torch.equal(got, want)
+            else:
+                bad = (got != want).float().mean().item()
+                assert bad <= 2e-2 and (got - want).abs().max().item() <= 2e-3 * want.abs().max().item(), (bad,)
