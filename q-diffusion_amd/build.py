@@ -46,6 +46,26 @@ def _compile(src):
     return obj
 
 
+def build_variant(name, defines):
+    """A second library with extra -D flags (A/B measurements: QDIFF_HIP_LIB=<path> selects it in qdiff/hip.py)."""
+    objdir = os.path.join(HERE, "build", name)
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        path = os.path.join(CSRC, src)
+        if _stale(obj, [path] + HEADERS):
+            r = subprocess.run([_hipcc()] + CFLAGS + [f"-D{d}" for d in defines] + ["-x", "hip", "-c", path, "-o", obj], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+        objs.append(obj)
+    lib = os.path.join(LIBDIR, f"libqdiff_hip_{name}.so")
+    r = subprocess.run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    return lib
+
+
 def build(force=False):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
@@ -63,4 +83,8 @@ def build(force=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--variant" in sys.argv:                  # python build.py --variant occ3 QD_MT1_OCC=3
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        print(build(force="--force" in sys.argv))

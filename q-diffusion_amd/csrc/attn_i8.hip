@@ -265,6 +265,8 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_k
     const int b = bh / p.H, hh = bh % p.H;
     const QP oqp = p.out8 ? qd_load_qp(p.oq) : QP{1.f, 0.f, 1.f, false};
     const long kconst = (P16 ? 256L * 128L : 0L) + 128L + (long)p.iwmin - (long)izpw;  // multiplies vsum
+    auto epi = [&](auto ft) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(ft)::value;
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
         const int dd = t * 32 + frow;
@@ -278,10 +280,12 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_k
             long I = (long)ol[t][r] + kconst * vs - (long)zv * us + (long)p.S * izpw * zv;
             if (P16) I += 256L * (long)oh[P16 ? t : 0][r];
             const float o = (float)I * oscale;
-            if (p.out8) p.out8[((long)b * p.T + i) * p.ldo8 + hh * p.d + dd] = (int8_t)(qd_code(o, oqp, p.oqmin, p.oqmax) - p.oqoff);
+            if (p.out8) p.out8[((long)b * p.T + i) * p.ldo8 + hh * p.d + dd] = (int8_t)(qd_code_t<FAST>(o, oqp, p.oqmin, p.oqmax) - p.oqoff);
             else p.out[((long)b * p.T + i) * p.ldo + hh * p.d + dd] = o;
         }
     }
+    };
+    QD_FAST_DISPATCH(oqp.fast, epi);
 }
 
 template <int DT>

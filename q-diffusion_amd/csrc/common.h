@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/qdiff_hip.h"
 
 typedef int   v4i  __attribute__((ext_vector_type(4)));
@@ -107,6 +108,28 @@ __device__ __forceinline__ int qd_code(float x, const QP& q, float qmin, float q
     r = fminf(fmaxf(r, qmin), qmax);
     return (int)r;
 }
+// The same with the fast / exact choice as a COMPILE-TIME flag.  The run-time form above puts a (uniform) branch around
+// the division of every element, which splits an unrolled epilogue into one basic block per element and serialises its
+// dependency chains (seen in the ISA of the GEGLU epilogue: 167 us of a 234 us launch); kernels therefore test q.fast once
+// and run a branch-free body:  QD_FAST_DISPATCH(q.fast, body)  with  body = [&](auto fast_tag) { ... qd_code_t<FAST>(...) }.
+template <bool FAST>
+__device__ __forceinline__ int qd_code_t(float x, const QP& q, float qmin, float qmax) {
+    float d;
+    if constexpr (FAST) {
+        const float y = x * q.rinv;
+        d = __builtin_fmaf(__builtin_fmaf(-y, q.delta, x), q.rinv, y);
+    } else {
+        d = x / q.delta;
+    }
+    float r = rintf(d) + q.zp;
+    r = fminf(fmaxf(r, qmin), qmax);
+    return (int)r;
+}
+#define QD_FAST_DISPATCH(flag, body)                     \
+    do {                                                 \
+        if (flag) body(std::true_type{});                \
+        else body(std::false_type{});                    \
+    } while (0)
 
 // quantise one value to its stored byte: clamp(rint(x/delta)+zp, qmin, qmax) - off
 // (true IEEE division + round-half-even, as torch.round(x / delta): quant_layer.py:82)

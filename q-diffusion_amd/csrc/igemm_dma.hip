@@ -118,8 +118,11 @@ __device__ __forceinline__ constexpr int crow(int r) { return (r & 3) + 8 * (r >
 
 // WB = weight bits of the tile-ordered operand: 4 (raw nibbles, 1 KB per K-step x 32 channels) or 8 (s8 bytes W-128,
 // 2 KB); everything but the B tile size and the fragment read is shared.
+#ifndef QD_MT1_OCC
+#define QD_MT1_OCC 2      // waves per SIMD the 128-row tiles are compiled for (3 fits without spills; A/B knob of build.py)
+#endif
 template <int MT, int NT, int WM, int WN, bool SPLIT, int OUT, int WB>
-__global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : 2) void igemm_kernel(const ConvD p) {
+__global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <= 5 ? QD_MT1_OCC : 2)) void igemm_kernel(const ConvD p) {
     static_assert(WB == 4 || WB == 8, "weight bits");
     static_assert(WM * WN == 4, "four waves per block");
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, NTB = NT * WN;
@@ -455,6 +458,8 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : 2) void igemm_ke
         const int Fout = p.Cout >> 1;
         const int f0 = (wcol0 >> 1);                   // first output feature of this wave
         int8_t* o8 = reinterpret_cast<int8_t*>(p.out) + f0;
+        auto epi = [&](auto ft) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(ft)::value;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int rbase = wrow0 + i * 32;
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : 2) void igemm_ke
                     const float val = (float)(acc[i][2 * jp][r] - zcv - __mul24(zwv, as)) * sv + bv;
                     const float gate = (float)(acc[i][2 * jp + 1][r] - zcg - __mul24(zwg, as)) * sgt + bg;
                     const float y = val * (0.5f * gate * (1.0f + qd_erff(gate * 0.70710678118654752440f)));
-                    tb8[rl * ROWB + jp * 32 + frow] = (int8_t)(qd_code(y, oqp, p.oqmin, p.oqmax) - p.oqoff);
+                    tb8[rl * ROWB + jp * 32 + frow] = (int8_t)(qd_code_t<FAST>(y, oqp, p.oqmin, p.oqmax) - p.oqoff);
                 }
             }
 #pragma unroll
@@ -483,6 +488,8 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : 2) void igemm_ke
                 if (m < p.M && f0 + cb < Fout) *reinterpret_cast<v4i*>(o8 + m * p.ldo + cb) = v;
             }
         }
+        };
+        QD_FAST_DISPATCH(oqp.fast, epi);
         return;
     }
     if constexpr (OUT == O_HROWS) {
@@ -496,6 +503,8 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : 2) void igemm_ke
         const int bidx = m0 / p.hdT, t0 = m0 - bidx * p.hdT;
         const bool hres = p.residual != nullptr;
         const float* rf = reinterpret_cast<const float*>(p.residual);
+        auto epi = [&](auto ft) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(ft)::value;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int cl = wn * WCOLS + j * 32 + frow;
@@ -530,11 +539,13 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : 2) void igemm_ke
                     unsigned w = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        w |= (unsigned)((qd_code(v[e] * p.oqpre, oqp, p.oqmin, p.oqmax) - p.oqoff) & 0xff) << (8 * e);
+                        w |= (unsigned)((qd_code_t<FAST>(v[e] * p.oqpre, oqp, p.oqmin, p.oqmax) - p.oqoff) & 0xff) << (8 * e);
                     if (nok) *reinterpret_cast<unsigned*>(ob + (long)(rbase + rl) * p.hddpad) = w;
                 }
             }
         }
+        };
+        QD_FAST_DISPATCH(oqp.fast, epi);
         return;
     }
     if constexpr (OUT == O_HTR) {
@@ -542,6 +553,8 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : 2) void igemm_ke
         int8_t* o8 = reinterpret_cast<int8_t*>(p.out);
         const int bidx = m0 / p.hdT, t0 = m0 - bidx * p.hdT;
         int* sPart = reinterpret_cast<int*>(smem);            // [4][WCOLS] column-sum partials (the ring is dead by now)
+        auto epi = [&](auto ft) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(ft)::value;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int cl = wn * WCOLS + j * 32 + frow;
@@ -566,7 +579,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : 2) void igemm_ke
                         const int rowl = tile0 + 4 * fhalf + crow(r);
                         const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rowl] - kz);
                         const float v = (float)I * sc + bias_n;
-                        const int code = qd_code(v * p.oqpre, oqp, p.oqmin, p.oqmax) - p.oqoff;
+                        const int code = qd_code_t<FAST>(v * p.oqpre, oqp, p.oqmin, p.oqmax) - p.oqoff;
                         csum += code;
                         w |= (unsigned)(code & 0xff) << (8 * e);
                     }
@@ -579,6 +592,8 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : 2) void igemm_ke
             csum += __shfl_xor(csum, 32);
             if (fhalf == 0) sPart[wave * WCOLS + j * 32 + frow] = nok ? csum : 0;
         }
+        };
+        QD_FAST_DISPATCH(oqp.fast, epi);
         __syncthreads();
         const int c = threadIdx.x;
         if (c < BN && n0 + c < p.Cout) {

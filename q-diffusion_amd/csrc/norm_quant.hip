@@ -96,13 +96,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     QP q{1.f, 0.f, 1.f, false};
     if (out) q = qd_load_qp(qp);
     unsigned u = 0;
+    auto body = [&](auto ft) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float y = v[j] * a4[j] + s4[j];
-        if (apply_silu) y = y * (1.0f / (1.0f + expf(-y)));
-        if (yout) yout[row * ldy + c + j] = y;
-        if (out) u |= (unsigned)((qd_code(y, q, qmin, qmax) - off) & 0xff) << (8 * j);
-    }
+        for (int j = 0; j < 4; ++j) {
+            float y = v[j] * a4[j] + s4[j];
+            if (apply_silu) y = y * (1.0f / (1.0f + expf(-y)));
+            if (yout) yout[row * ldy + c + j] = y;
+            if (out) u |= (unsigned)((qd_code_t<decltype(ft)::value>(y, q, qmin, qmax) - off) & 0xff) << (8 * j);
+        }
+    };
+    QD_FAST_DISPATCH(q.fast, body);
     if (out) *reinterpret_cast<unsigned*>(out + row * ldo + c) = u;
 }
 
@@ -176,6 +179,8 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(const T* __restrict__ x, 
     const QP qa = qd_load_qp(qp0);
     const QP qb = nout > 1 ? qd_load_qp(qp1) : QP{1.f, 0.f, 1.f, false};
     const QP qc = nout > 2 ? qd_load_qp(qp2) : QP{1.f, 0.f, 1.f, false};
+    auto lnbody = [&](auto ft) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(ft)::value;
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         rstd[r] = 1.0f / sqrtf(q[r] / (float)C + eps);
@@ -189,9 +194,9 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(const T* __restrict__ x, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float y = (v[r][k][j] - mean[r]) * rstd[r] * g[k][j] + bt[k][j];
-                    u0 |= (unsigned)((qd_code(y, qa, qmin.x, qmax.x) - off.x) & 0xff) << (8 * j);
-                    if (nout > 1) u1 |= (unsigned)((qd_code(y, qb, qmin.y, qmax.y) - off.y) & 0xff) << (8 * j);
-                    if (nout > 2) u2 |= (unsigned)((qd_code(y, qc, qmin.z, qmax.z) - off.z) & 0xff) << (8 * j);
+                    u0 |= (unsigned)((qd_code_t<FAST>(y, qa, qmin.x, qmax.x) - off.x) & 0xff) << (8 * j);
+                    if (nout > 1) u1 |= (unsigned)((qd_code_t<FAST>(y, qb, qmin.y, qmax.y) - off.y) & 0xff) << (8 * j);
+                    if (nout > 2) u2 |= (unsigned)((qd_code_t<FAST>(y, qc, qmin.z, qmax.z) - off.z) & 0xff) << (8 * j);
                 }
                 *reinterpret_cast<unsigned*>(o0 + row * ldo + idx * 4) = u0;
                 if (nout > 1) *reinterpret_cast<unsigned*>(o1 + row * ldo + idx * 4) = u1;
@@ -199,6 +204,8 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(const T* __restrict__ x, 
             }
         }
     }
+    };
+    QD_FAST_DISPATCH(qa.fast && (nout < 2 || qb.fast) && (nout < 3 || qc.fast), lnbody);
 }
 
 template <typename T, int NV>

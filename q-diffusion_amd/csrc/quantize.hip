@@ -31,8 +31,11 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const T* __restrict__ x
         float v[4];
         qd_ld4(x + b * sb + s * row_stride + c0 + c, vec != 0, v);
         u = 0;
+        auto body = [&](auto ft) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) u |= (unsigned)((qd_code(v[j], q, qmin, qmax) - off) & 0xff) << (8 * j);
+            for (int j = 0; j < 4; ++j) u |= (unsigned)((qd_code_t<decltype(ft)::value>(v[j], q, qmin, qmax) - off) & 0xff) << (8 * j);
+        };
+        QD_FAST_DISPATCH(q.fast, body);
     } else {
         u = 0;
 #pragma unroll
@@ -172,18 +175,21 @@ __global__ __launch_bounds__(256) void geglu_quant_kernel(const T* __restrict__ 
     const T* xa = h + row * ldh + ch * 16;
     const T* xg = xa + F;
     v4i v;
+    auto body = [&](auto ft) __attribute__((always_inline)) {
 #pragma unroll
-    for (int wd = 0; wd < 4; ++wd) {
-        unsigned u = 0;
+        for (int wd = 0; wd < 4; ++wd) {
+            unsigned u = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float a = qd_ld(xa + wd * 4 + j), g = qd_ld(xg + wd * 4 + j);
-            float gl = 0.5f * g * (1.0f + qd_erff(g * 0.70710678118654752440f));
-            int code = qd_code(a * gl, q, qmin, qmax) - off;
-            u |= (unsigned)(code & 0xff) << (8 * j);
+            for (int j = 0; j < 4; ++j) {
+                float a = qd_ld(xa + wd * 4 + j), g = qd_ld(xg + wd * 4 + j);
+                float gl = 0.5f * g * (1.0f + qd_erff(g * 0.70710678118654752440f));
+                int code = qd_code_t<decltype(ft)::value>(a * gl, q, qmin, qmax) - off;
+                u |= (unsigned)(code & 0xff) << (8 * j);
+            }
+            v[wd] = (int)u;
         }
-        v[wd] = (int)u;
-    }
+    };
+    QD_FAST_DISPATCH(q.fast, body);
     *reinterpret_cast<v4i*>(out + row * ldo + ch * 16) = v;
 }
 

@@ -47,6 +47,8 @@ __global__ __launch_bounds__(256) void temb_kernel(const float* __restrict__ x, 
     if (tid < B) sAsum[tid] = 0;
     __syncthreads();
     const int k4n = K >> 2;
+    auto quant = [&](auto ft) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(ft)::value;
     for (int idx = tid; idx < B * k4n; idx += 256) {
         const int b = idx / k4n, k4 = idx - b * k4n;
         const float4 v = *reinterpret_cast<const float4*>(x + (long)b * ldx + k4 * 4);
@@ -57,13 +59,15 @@ __global__ __launch_bounds__(256) void temb_kernel(const float* __restrict__ x, 
         for (int j = 0; j < 4; ++j) {
             float y = e[j];
             if (silu) y = y / (1.0f + expf(-y));                   // torch's silu: x / (1 + exp(-x))
-            const int c = qd_code(y, q, qmin, qmax) - off;
+            const int c = qd_code_t<FAST>(y, q, qmin, qmax) - off;
             s += c;
             u |= (unsigned)(c & 0xff) << (8 * j);
         }
         *reinterpret_cast<unsigned*>(codes + (long)b * K + k4 * 4) = u;
         atomicAdd(&sAsum[b], s);
     }
+    };
+    QD_FAST_DISPATCH(q.fast, quant);
     __syncthreads();
 
     // ---- 2. contraction: lane = output channel, wave = every 4th 16-wide K chunk ---------------------------------------

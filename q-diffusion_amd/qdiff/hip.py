@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libqdiff_hip.so")
+# QDIFF_HIP_LIB: an alternative build of the same library (q-diffusion_amd/build.py --variant ...), for A/B measurements
+LIB_PATH = os.environ.get("QDIFF_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libqdiff_hip.so")
 
 F32, F16 = 0, 1
 _DT = {torch.float32: F32, torch.float16: F16}
