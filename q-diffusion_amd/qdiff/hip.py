@@ -204,13 +204,14 @@ class ConvCall:
             setattr(self, k, kw.get(k))
 
 
-_SPLITK_WS = {}          # device -> list of scratch buffers, newest last; old ones stay alive for captured graphs
+_SPLITK_WS = {}          # (device, stream) -> list of scratch buffers, newest last; old ones stay alive for captured graphs
 
 
 def _splitk_scratch(device, nbytes):
-    """Stream-ordered scratch shared by every split-K launch on `device` (grows, never shrinks or moves:
-    a HIP graph captured earlier keeps pointing at the buffer it was captured with)."""
-    bufs = _SPLITK_WS.setdefault(device, [])
+    """Stream-ordered scratch shared by every split-K launch on one stream of `device` (grows, never shrinks or moves: a
+    HIP graph captured earlier keeps pointing at the buffer it was captured with; launches on another stream — the
+    context K/V branch of qdiff.quant_block.ContextKV — get their own)."""
+    bufs = _SPLITK_WS.setdefault((device, _stream()), [])
     if not bufs or bufs[-1].numel() < nbytes:
         bufs.append(torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device))
     return bufs[-1]

@@ -129,6 +129,11 @@ class EmbGroup:
         self.members.append((blk, linear))
         blk.__dict__["_emb_group"] = self
 
+    def reset(self):
+        """Start of a UNet evaluation (forward pre-hook of the wrapped model): nothing carries over between evaluations —
+        the same tensor object may hold new values (static inputs of a captured graph, in-place updates)."""
+        self._emb, self._out = None, None
+
     def get(self, blk, emb):
         if self._emb is not emb:
             self._emb, self._out = emb, None
@@ -158,6 +163,94 @@ class EmbGroup:
         out = torch.empty((emb.shape[0], tot), dtype=torch.float32, device=emb.device)
         engine.hip.temb_mlp(emb.float(), True, plans, offs, out)
         self._out = out
+
+
+_CTX_BRANCH = os.environ.get("QDIFF_CTX_BRANCH", "1") != "0"     # A/B knob for measurements only
+
+
+class ContextKV:
+    """Cross-attention keys / values of ALL transformer blocks of one UNet, evaluated on a SIDE STREAM.
+    to_k / to_v of attn2 (reference quant_block.py:190-221, ldm attention.py:152-198) see only the conditioning `context`
+    — [B, 77, 768] for SD — never the latent: 16 blocks x (row quantiser + two skinny GEMMs on B*77 rows + head-layout
+    quantisers) = ~130 tiny dependent launches per evaluation that no single one of can fill the chip (~1.3 ms of an SD
+    evaluation when serialised into the main stream).  The first block that meets a new context tensor forks a branch
+    that prepares the int8 attention operands of every block while the main stream runs the stem / first residual
+    blocks / self-attention; the first cross-attention joins it.  Under HIP-graph capture the fork / join become
+    parallel branches of the graph.  Results are those of the in-line path bit for bit (same kernels, same inputs)."""
+
+    def __init__(self):
+        self.members = []
+        self._ctx, self._out, self._side, self._joined = None, None, None, True
+
+    def register(self, blk):
+        self.members.append(blk)
+        blk.__dict__["_ctx_group"] = self
+
+    def reset(self):
+        """Start of a UNet evaluation: see EmbGroup.reset.  A branch that nobody joined (no cross-attention ran) is joined
+        here so that no work is left dangling on the side stream."""
+        if not self._joined and self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._ctx, self._out, self._joined = None, None, True
+
+    def get(self, blk, context):
+        """(k8, v8, vsum) of blk.attn2 for this context, or None (in-line path)."""
+        if self._ctx is not context:
+            self._ctx, self._out = context, None
+            self._prepare(context)
+        if self._out is None:
+            return None
+        if not self._joined:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._joined = True
+        return self._out[id(blk)]
+
+    def _prepare(self, context):
+        if not _CTX_BRANCH or not torch.is_tensor(context) or context.dim() != 3 or len(self.members) < 2:
+            return
+        mods = [m for blk in self.members for m in (blk.attn2.to_k, blk.attn2.to_v)]
+        if not _int_mode(*mods) or any(m.split or not m.act_quantizer.inited for m in mods):
+            return
+        if not all(blk.attn2.use_act_quant and blk._attn_inited(blk.attn2) for blk in self.members):
+            return
+        B, S, Cc = context.shape
+        ctx = context.reshape(B * S, Cc).float()
+        if ctx.stride(1) != 1:
+            ctx = ctx.contiguous()
+        bufs = self.__dict__.setdefault("_bufs", {})
+        dev = context.device
+
+        def work():
+            out = {}
+            for blk in self.members:
+                att = blk.attn2
+                h = att.heads
+                inner = att.to_k.conv_plan().Cout
+                d = inner // h
+                ap = blk._attn_plan(att, float(att.scale), 1.0, dev)
+                key = (id(blk), B, S, h, d)
+                if key not in bufs:
+                    Sp, dp = engine.pad32(S), engine.pad32(d)
+                    bufs[key] = (torch.zeros((B * h, Sp, dp), dtype=torch.int8, device=dev),
+                                 torch.zeros((B * h, dp, Sp), dtype=torch.int8, device=dev),
+                                 torch.zeros((B * h, dp), dtype=torch.int32, device=dev))
+                k8, v8, vsum = bufs[key]
+                for mod, which, buf in ((att.to_k, 1, k8), (att.to_v, 2, v8)):
+                    y = _linear_rows(mod, ctx)
+                    engine.heads_from_float(ap, which, y, B, S, h, d, (S * inner, inner, d, 1), buf, vsum)
+                out[id(blk)] = (k8, v8, vsum)
+            return out
+
+        if dev.type != "cuda":
+            self._out, self._joined = work(), True
+            return
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        self._side.wait_stream(main)                  # after everything queued so far (incl. the previous evaluation's readers)
+        with torch.cuda.stream(self._side):
+            self._out = work()
+        self._joined = False
 
 
 def time_mlp(lin0, lin1, t_emb, act=F.silu):
@@ -502,8 +595,9 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
         x = self.attn2(self.norm2(x), context=context) + x
         return self.ff(self.norm3(x)) + x
 
-    def _attn_int(self, att, rows, B, T, C, ln, ctx_rows, S):
-        """norm -> q/k/v projections -> fused quantised attention -> to_out (+ residual rows)."""
+    def _attn_int(self, att, rows, B, T, C, ln, ctx_rows, S, kv=None):
+        """norm -> q/k/v projections -> fused quantised attention -> to_out (+ residual rows).
+        kv: (k8, v8, vsum) prepared ahead of time for this block's context (ContextKV), else they are computed here."""
         h = att.heads
         ap = self._attn_plan(att, float(att.scale), 1.0, rows.device)
         if ctx_rows is None:
@@ -515,6 +609,8 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
         inner = att.to_q.conv_plan().Cout
         d = inner // h
         q8, k8, v8, vsum = engine.head_buffers(rows.device, B * h, T, S, d)
+        if kv is not None:
+            k8, v8, vsum = kv
 
         def operand(mod, codes, which, n_tok, buf):
             # projection -> attention operand bytes: inside the GEMM epilogue when the shape allows it, else
@@ -526,8 +622,9 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
             engine.heads_from_float(ap, which, y, B, n_tok, h, d, (n_tok * inner, inner, d, 1), buf, vsum)
 
         operand(att.to_q, xq, 0, T, q8)
-        operand(att.to_k, xk, 1, S, k8)
-        operand(att.to_v, xv, 2, S, v8)
+        if kv is None:
+            operand(att.to_k, xk, 1, S, k8)
+            operand(att.to_v, xv, 2, S, v8)
         out_lin = att.to_out[0]
         if out_lin.act_quantizer.inited and out_lin.conv_plan().ldx == inner and len(out_lin.conv_plan().segs) == 1:
             # the attention epilogue quantises its output for to_out[0]: no fp32 round trip
@@ -546,10 +643,14 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
             rows = self._attn_int(self.attn2, rows, B, T, C, self.norm2, None, T)
         else:
             S = context.shape[1]
-            ctx = context.reshape(B * S, context.shape[2]).float()
-            if ctx.stride(1) != 1:
-                ctx = ctx.contiguous()
-            rows = self._attn_int(self.attn2, rows, B, T, C, self.norm2, ctx, S)
+            grp = self.__dict__.get("_ctx_group")
+            kv = grp.get(self, context) if grp is not None else None
+            ctx = None
+            if kv is None:
+                ctx = context.reshape(B * S, context.shape[2]).float()
+                if ctx.stride(1) != 1:
+                    ctx = ctx.contiguous()
+            rows = self._attn_int(self.attn2, rows, B, T, C, self.norm2, ctx if kv is None else rows, S, kv=kv)
         proj, ff_out = self.ff.net[0].proj, self.ff.net[-1]
         (h8,) = _ln_to([proj], rows, B * T, C, self.norm3)
         gplan = proj.geglu_plan() if ff_out.act_quantizer.inited else None

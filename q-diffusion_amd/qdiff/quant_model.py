@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from types import MethodType
 
-from .quant_block import (BaseQuantBlock, EmbGroup, QuantAttentionBlock, QuantAttnBlock, QuantBasicTransformerBlock,
+from .quant_block import (BaseQuantBlock, ContextKV, EmbGroup, QuantAttentionBlock, QuantAttnBlock, QuantBasicTransformerBlock,
                           QuantQKMatMul, QuantResBlock, QuantResnetBlock, QuantSMVMatMul, get_specials, reference_classes,
                           time_mlp)
 from .quant_layer import QuantModule, StraightThrough
@@ -76,6 +76,11 @@ class QuantModel(nn.Module):
                 group.register(m, m.emb_layers[-1])
             elif isinstance(m, QuantResnetBlock) and isinstance(m.temb_proj, QuantModule):
                 group.register(m, m.temb_proj)
+        ctx = ContextKV()                # cross-attention keys / values of every transformer block: one side-stream branch
+        for m in self.model.modules():
+            if isinstance(m, QuantBasicTransformerBlock):
+                ctx.register(m)
+        self.model.register_forward_pre_hook(lambda _m, _a: (group.reset(), ctx.reset()) and None)
         te = getattr(self.model, "time_embed", None)
         if (isinstance(te, nn.Sequential) and len(te) == 3 and isinstance(te[0], QuantModule) and isinstance(te[2], QuantModule)
                 and isinstance(te[1], nn.SiLU)):

@@ -1,0 +1,5 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/p12; mkdir -p $out
+timeout 900 python -m pytest tests/test_engine_models.py -m gpu -q -x -k "sd_tiny or sd_full or graph or plms" > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $out/pytest.log
+bash tools/r02_ab.sh "QDIFF_CTX_BRANCH=1" "QDIFF_CTX_BRANCH=0" "QDIFF_CTX_BRANCH=1" "QDIFF_CTX_BRANCH=0"
