@@ -15,11 +15,11 @@
 // 16-bit probabilities are split into hi/lo bytes: two exact int32 accumulators, combined in int64.
 #include "common.h"
 #include <climits>
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
 
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct AttnK {
     const int8_t* q;
@@ -296,6 +296,281 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_k
     QD_FAST_DISPATCH(oqp.fast, epi);
 }
 
+// ---- lean variant (head dims that are NOT a multiple of 32 and < 64: Stable Diffusion's 4096-token, d = 40 level) -----
+// Same mathematics, ~25 % fewer VALU instructions per score.  The 32x32 score tile costs VALU time, not matrix time, so:
+//   * no int->float converts: the MFMA accumulator starts at 0x4B400000 - rowmax (the bit pattern of 1.5*2^23, minus the
+//     integer row maximum), so its bits ARE the float 1.5*2^23 + (s - max), exactly, as long as |s - max| < 2^22 — the
+//     launcher guarantees that from d and the operand ranges (d * 128 * 256 * 2 < 2^22 <=> d < 64).  One packed FMA maps
+//     it to the log2 domain: fma(F, cs2, -fl(1.5*2^23*cs2)) = cs2*(s - max) + eps with ONE rounding; eps (the rounding of
+//     the constant) is the same for every score of both sweeps, i.e. a common factor 2^eps that cancels in e / sum(e);
+//   * sweep 1 does not maintain a running maximum in the float domain (16 accumulator re-initialisations, a rescale and
+//     an extra exp2 per tile): it accumulates sum(exp2(cs2*(s - m0))) against the maximum m0 of the FIRST tile and tracks
+//     the integer maximum with v_max3_i32 only.  fp32 has the exponent range for that (the relative precision of a
+//     floating-point sum does not depend on the common scale) unless the maximum rises by more than 64 octaves, which
+//     is detected (wave-uniform) and answered by one more pass against the true maximum;
+//   * rounding to the probability grid is folded into the normalising FMA: fma(e, inv, ubias + 1.5*2^23);
+//   * the sums of the probability codes (needed for the v zero point) come out of the P.V MFMA itself: the lane that
+//     holds V^T row `d` (a padding row: d is not a multiple of 32) reads a constant row of ones instead, so column d
+//     of the output tile is sum_j code_j — no v_dot4 in the loop.
+__device__ __attribute__((aligned(16))) int qd_ones16[4] = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
+
+template <int DT, bool P16, bool ASYM>
+#ifndef QD_ATTN_LEAN_OCC
+#define QD_ATTN_LEAN_OCC 3
+#endif
+__global__ __launch_bounds__(256, QD_ATTN_LEAN_OCC) void attn_lean_kernel(const AttnK p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    if (q0 >= p.T) return;
+
+    const float cs2 = p.prm[0] * 1.4426950408889634f;
+    const int nzq = -(int)p.prm[1];
+    const float dw = p.prm[3], zpw = p.prm[4], oscale = p.prm[5];
+    const int zv = (int)p.prm[6];
+    const int izpw = (int)zpw;
+    const float urange = p.wmax - p.wmin;
+    const float ubias = zpw - p.wmin;
+    constexpr float MAGIC = 12582912.f;
+    constexpr int   MAGICI = 0x4B400000;
+    constexpr int   MASKED = -(1 << 30);
+    const float nc0 = -(MAGIC * cs2);                             // the (rounded) constant both sweeps subtract
+
+    v4i qf[DT];
+    const int8_t* qrow = p.q + ((long)bh * p.Tpad + q0 + frow) * p.dpad + half * 16;
+#pragma unroll
+    for (int kk = 0; kk < DT; ++kk) qf[kk] = *reinterpret_cast<const v4i*>(qrow + kk * 32);
+    const int8_t* kbase = p.k + (long)bh * p.Spad * p.dpad + (long)frow * p.dpad + half * 16;
+    const int c1 = nzq > 127 ? 64 : nzq, c2 = nzq - c1;
+    const int c1w = (c1 & 0xff) * 0x01010101, c2w = (c2 & 0xff) * 0x01010101;
+    const v4i c1v = {c1w, c1w, c1w, c1w}, c2v = {c2w, c2w, c2w, c2w};
+    const int ntile = p.Spad >> 5;
+    const int tail_tile = (p.S & 31) ? ntile - 1 : ntile;
+
+    auto load_k = [&](int jt, v4i (&kf)[DT]) __attribute__((always_inline)) {
+        const int8_t* kp = kbase + (long)jt * 32 * p.dpad;
+#pragma unroll
+        for (int kk = 0; kk < DT; ++kk) kf[kk] = *reinterpret_cast<const v4i*>(kp + kk * 32);
+    };
+    // acc[4g+e] = init + score of key jt*32 + e + 8g + 4*half (per-query constants dropped)
+    auto scores = [&](const v4i (&kf)[DT], int init, v16i& acc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = init;
+#pragma unroll
+        for (int kk = 0; kk < DT; ++kk) {
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], qf[kk], acc, 0, 0, 0);
+            if (ASYM) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], c1v, acc, 0, 0, 0);
+        }
+        if (ASYM && c2 != 0) {
+#pragma unroll
+            for (int kk = 0; kk < DT; ++kk) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], c2v, acc, 0, 0, 0);
+        }
+    };
+    auto key_ok = [&](int jt, int r) __attribute__((always_inline)) { return jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half < p.S; };
+    const v2f cs2v = {cs2, cs2}, nc0v = {nc0, nc0};
+
+    // ---- sweep 1 ----------------------------------------------------------------------------------------------------
+    int m0, mx = 0;
+    float l = 0.f;
+    {
+        v4i kf[DT], kfn[DT];
+        load_k(0, kf);
+        {
+            v16i acc;
+            scores(kf, 0, acc);
+            if (tail_tile == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (!key_ok(0, r)) acc[r] = MASKED;
+            }
+            m0 = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m0 = max(m0, acc[r]);
+        }
+        for (int pass = 0; pass < 2; ++pass) {
+            const int init = MAGICI - m0;
+            int mxa = 0;                                          // max of the raw accumulators (all > 0: 0 is "masked")
+            v2f a2 = {0.f, 0.f};
+            auto s1_tile = [&](int jt, auto tail_tag) __attribute__((always_inline)) {
+                constexpr bool tail = decltype(tail_tag)::value;
+                if (jt + 1 < ntile) load_k(jt + 1, kfn);
+                v16i acc;
+                scores(kf, init, acc);
+                if (tail) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) if (!key_ok(jt, r)) acc[r] = 0;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    mxa = max(max(mxa, acc[r]), acc[r + 1]);              // v_max3_i32
+                    const v2f F = {__int_as_float(acc[r]), __int_as_float(acc[r + 1])};
+                    const v2f x = __builtin_elementwise_fma(F, cs2v, nc0v);
+                    v2f e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                    if (tail) {
+                        if (acc[r] == 0) e.x = 0.f;
+                        if (acc[r + 1] == 0) e.y = 0.f;
+                    }
+                    a2 += e;
+                }
+                if (jt + 1 < ntile) {
+#pragma unroll
+                    for (int kk = 0; kk < DT; ++kk) kf[kk] = kfn[kk];
+                }
+            };
+            for (int jt = 0; jt < tail_tile; ++jt) s1_tile(jt, std::false_type{});
+            if (tail_tile < ntile) s1_tile(tail_tile, std::true_type{});
+            l = a2.x + a2.y;
+            mx = mxa ? mxa - MAGICI : 0;                          // how far the row maximum lies above m0 (>= 0: tile 0 is in the
+                                                                  // loop); a lane without any valid key keeps m0 = MASKED, l = 0
+            if (!__any((float)mx * cs2 > 64.f)) break;
+            m0 += mx;                                             // (rare) start again against the true maximum
+            load_k(0, kf);
+        }
+    }
+    int mi = m0 + mx;
+    l *= __builtin_amdgcn_exp2f(-(float)mx * cs2);                // normaliser relative to this half's maximum
+    {
+        const int mo = __shfl_xor(mi, 32);
+        const float lo = __shfl_xor(l, 32);
+        const int mf = max(mi, mo);
+        l = l * __builtin_amdgcn_exp2f((float)(mi - mf) * cs2) + lo * __builtin_amdgcn_exp2f((float)(mo - mf) * cs2);
+        mi = mf;
+    }
+    const float inv = 1.0f / (l * dw);
+    const float emax = __builtin_amdgcn_exp2f(__builtin_fmaf(MAGIC, cs2, nc0));   // e of the row maximum (2^eps)
+
+    // ---- sweep 2 ----------------------------------------------------------------------------------------------------
+    v16i ol[DT], oh[P16 ? DT : 1];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            ol[t][r] = 0;
+            if (P16) oh[P16 ? t : 0][r] = 0;
+        }
+    const int t1 = p.d >> 5, frow1 = p.d & 31;                     // where the row of ones sits
+    const int8_t* vp[DT];
+    int vstep[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+        const bool ones = (t == t1) && (frow == frow1);
+        vp[t] = ones ? reinterpret_cast<const int8_t*>(qd_ones16) : p.vt + ((long)bh * p.dpad + t * 32 + frow) * p.Spad + half * 16;
+        vstep[t] = ones ? 0 : 32;
+    }
+    {
+        v4i kf[DT], kfn[DT];
+        load_k(0, kf);
+        const int init = MAGICI - mi;
+        const v2f invv = {inv, inv}, ubv = {ubias, ubias}, magic = {MAGIC, MAGIC}, ubm = {ubias + MAGIC, ubias + MAGIC};
+        auto s2_tile = [&](int jt, auto tail_tag, auto clamp_tag) __attribute__((always_inline)) {
+            constexpr bool tail = decltype(tail_tag)::value, CLAMP = decltype(clamp_tag)::value;
+            v4i vf[DT];
+#pragma unroll
+            for (int t = 0; t < DT; ++t) vf[t] = *reinterpret_cast<const v4i*>(vp[t] + (long)jt * vstep[t]);
+            if (jt + 1 < ntile) load_k(jt + 1, kfn);
+            v16i acc;
+            scores(kf, init, acc);
+            unsigned ub[16];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const v2f F = {__int_as_float(acc[r]), __int_as_float(acc[r + 1])};
+                const v2f x = __builtin_elementwise_fma(F, cs2v, nc0v);
+                const v2f e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                v2f t;
+                if (CLAMP) {
+                    t = __builtin_elementwise_fma(e, invv, ubv);
+                    t.x = fminf(t.x, urange);
+                    t.y = fminf(t.y, urange);
+                    t += magic;
+                } else {
+                    t = __builtin_elementwise_fma(e, invv, ubm);  // one rounding: half-even on the exact e*inv
+                }
+                ub[r] = __float_as_uint(t.x);
+                ub[r + 1] = __float_as_uint(t.y);
+            }
+            if (tail) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (!key_ok(jt, r)) ub[r] = 0x8080u;
+            }
+            v4i plo, phi;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned a01 = __builtin_amdgcn_perm(ub[4 * g + 1], ub[4 * g], 0x05010400u);
+                const unsigned a23 = __builtin_amdgcn_perm(ub[4 * g + 3], ub[4 * g + 2], 0x05010400u);
+                plo[g] = (int)(__builtin_amdgcn_perm(a23, a01, 0x05040100u) ^ 0x80808080u);
+                phi[g] = P16 ? (int)(__builtin_amdgcn_perm(a23, a01, 0x07060302u) ^ 0x80808080u) : 0;
+            }
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                ol[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(plo, vf[t], ol[t], 0, 0, 0);
+                if (P16) oh[P16 ? t : 0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(phi, vf[t], oh[P16 ? t : 0], 0, 0, 0);
+            }
+            if (jt + 1 < ntile) {
+#pragma unroll
+                for (int kk = 0; kk < DT; ++kk) kf[kk] = kfn[kk];
+            }
+        };
+        // (an odd ubias would send exact ties of e*inv to the even SUM: keep the two-step rounding of the clamp path then)
+        if (__any(!(emax * inv * 1.0001f + ubias + 0.5f <= urange)) || (((int)ubias) & 1)) {
+            for (int jt = 0; jt < tail_tile; ++jt) s2_tile(jt, std::false_type{}, std::true_type{});
+        } else {
+            for (int jt = 0; jt < tail_tile; ++jt) s2_tile(jt, std::false_type{}, std::false_type{});
+        }
+        if (tail_tile < ntile) s2_tile(tail_tile, std::true_type{}, std::true_type{});
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    const int b = bh / p.H, hh = bh % p.H;
+    const QP oqp = p.out8 ? qd_load_qp(p.oq) : QP{1.f, 0.f, 1.f, false};
+    const long kconst = (P16 ? 256L * 128L : 0L) + 128L + (long)p.iwmin - (long)izpw;
+    // code sums of query il(r, half): column d of the output tile, i.e. register r of lane frow1 + 32*half
+    int us[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int sl = 0, sh = 0;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+            if (t == t1) {
+                sl = ol[t][r];
+                if (P16) sh = oh[P16 ? t : 0][r];
+            }
+        sl = __shfl(sl, frow1 + 32 * half);
+        if (P16) sh = __shfl(sh, frow1 + 32 * half);
+        // sum over the valid keys of uu = 256*hi + lo from the signed operand bytes, then of u = uu + wmin
+        us[r] = sl + 128 * p.S + (P16 ? 256 * (sh + 128 * p.S) : 0) + p.S * p.iwmin;
+    }
+    auto epi = [&](auto ft) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(ft)::value;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+        const int dd = t * 32 + frow;
+        const long vs = (dd < p.d) ? p.vsum[(long)bh * p.dpad + dd] : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int il = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int i = q0 + il;
+            if (dd >= p.d || i >= p.T) continue;
+            long I = (long)ol[t][r] + kconst * vs - (long)zv * us[r] + (long)p.S * izpw * zv;
+            if (P16) I += 256L * (long)oh[P16 ? t : 0][r];
+            const float o = (float)I * oscale;
+            if (p.out8) p.out8[((long)b * p.T + i) * p.ldo8 + hh * p.d + dd] = (int8_t)(qd_code_t<FAST>(o, oqp, p.oqmin, p.oqmax) - p.oqoff);
+            else p.out[((long)b * p.T + i) * p.ldo + hh * p.d + dd] = o;
+        }
+    }
+    };
+    QD_FAST_DISPATCH(oqp.fast, epi);
+}
+
+template <int DT>
+int launch_lean(const AttnK& k, bool p16, bool asym, hipStream_t st) {
+    dim3 grid((unsigned)((k.T + 127) / 128), (unsigned)k.BH);
+    if (p16 && asym) hipLaunchKernelGGL((attn_lean_kernel<DT, true, true>), grid, dim3(256), 0, st, k);
+    else if (p16) hipLaunchKernelGGL((attn_lean_kernel<DT, true, false>), grid, dim3(256), 0, st, k);
+    else if (asym) hipLaunchKernelGGL((attn_lean_kernel<DT, false, true>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((attn_lean_kernel<DT, false, false>), grid, dim3(256), 0, st, k);
+    return 0;
+}
+
 template <int DT>
 int launch_dt(const AttnK& k, bool p16, bool asym, hipStream_t st) {
     dim3 grid((unsigned)((k.T + 127) / 128), (unsigned)k.BH);
@@ -328,6 +603,14 @@ extern "C" int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt, co
             out8, (long)ldo8, oq_params, (float)oq_min, (float)oq_max, oq_off};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool p16 = wbits == 16;
+    // lean variant: needs a padding row of V^T (d not a multiple of 32) and |score differences| < 2^22 (d < 64)
+    static const bool lean_ok = !(getenv("QD_ATTN_LEAN") && atoi(getenv("QD_ATTN_LEAN")) == 0);
+    if (lean_ok && d < 64 && (d & 31) != 0) {
+        if (dpad == 32) launch_lean<1>(a, p16, asym, st);
+        else launch_lean<2>(a, p16, asym, st);
+        QD_LAUNCH_CHECK("qd_attn_i8");
+        return 0;
+    }
     switch (dpad / 32) {
         case 1: launch_dt<1>(a, p16, asym, st); break;
         case 2: launch_dt<2>(a, p16, asym, st); break;

@@ -125,6 +125,61 @@ __device__ __forceinline__ int qd_code_t(float x, const QP& q, float qmin, float
     r = fminf(fmaxf(r, qmin), qmax);
     return (int)r;
 }
+// ---- packed forms for the VALU-bound epilogues (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two fp32 lanes per issue) ----
+// Same IEEE operations in the same order as the scalar forms above, so the codes are those of qd_code_t bit for bit.
+// The byte itself comes from one float add instead of rint + add + min + max + cvt + sub: clamping BEFORE rounding is the
+// same function when the bounds are integers (qmin - zp, qmax - zp; zero points are integers, checked by the host), and
+// adding 1.5*2^23 rounds half-to-even into the low mantissa bits; (zp - off) is then added as an INTEGER (folding it into
+// the float constant would send ties to the even SUM, i.e. to the odd code whenever zp - off is odd), which leaves the
+// two's complement of (code - off) in the low byte.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f qd_splat2(float a) { return v2f{a, a}; }
+__device__ __forceinline__ v2f qd_fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+struct QB { float lo, hi; int n; };
+__device__ __forceinline__ QB qd_bytes_setup(const QP& q, float qmin, float qmax, int off) {
+    return QB{qmin - q.zp, qmax - q.zp, (int)q.zp - off};
+}
+template <bool FAST>
+__device__ __forceinline__ v2f qd_quot2_t(v2f x, const QP& q) {
+    if constexpr (FAST) {
+        const v2f r = qd_splat2(q.rinv), dl = qd_splat2(q.delta);
+        const v2f y = x * r;
+        return qd_fma2(qd_fma2(-y, dl, x), r, y);
+    } else {
+        return v2f{x.x / q.delta, x.y / q.delta};
+    }
+}
+// two values -> two ints whose LOW BYTES are the stored codes clamp(rint(x / delta) + zp, qmin, qmax) - off
+template <bool FAST>
+__device__ __forceinline__ void qd_bytes2_t(v2f x, const QP& q, const QB& b, int& b0, int& b1) {
+    const v2f d = qd_quot2_t<FAST>(x, q);
+    v2f c = {__builtin_amdgcn_fmed3f(d.x, b.lo, b.hi), __builtin_amdgcn_fmed3f(d.y, b.lo, b.hi)};
+    c += qd_splat2(12582912.f);
+    b0 = __float_as_int(c.x) + b.n;
+    b1 = __float_as_int(c.y) + b.n;
+}
+__device__ __forceinline__ v2f qd_erff2(v2f a) {             // qd_erff on two values (same operations, packed)
+    const v2f t = {__builtin_fabsf(a.x), __builtin_fabsf(a.y)}, s = a * a;
+    v2f r = qd_fma2(qd_splat2(-1.72853470e-5f), t, qd_splat2(3.83197126e-4f));
+    const v2f u = qd_fma2(qd_splat2(-3.88396438e-3f), t, qd_splat2(2.42546219e-2f));
+    r = qd_fma2(r, s, u);
+    r = qd_fma2(r, t, qd_splat2(-1.06777877e-1f));
+    r = qd_fma2(r, t, qd_splat2(-6.34846687e-1f));
+    r = qd_fma2(r, t, qd_splat2(-1.28717512e-1f));
+    r = qd_fma2(r, t, -t);
+    const v2f rl = r * qd_splat2(1.4426950408889634f);
+    const v2f om = qd_splat2(1.0f) - v2f{__builtin_amdgcn_exp2f(rl.x), __builtin_amdgcn_exp2f(rl.y)};
+    const v2f big = {__builtin_copysignf(om.x, a.x), __builtin_copysignf(om.y, a.y)};
+    v2f q = qd_splat2(-5.96761703e-4f);
+    q = qd_fma2(q, s, qd_splat2(4.99119423e-3f));
+    q = qd_fma2(q, s, qd_splat2(-2.67681349e-2f));
+    q = qd_fma2(q, s, qd_splat2(1.12819925e-1f));
+    q = qd_fma2(q, s, qd_splat2(-3.76125336e-1f));
+    q = qd_fma2(q, s, qd_splat2(1.28379166e-1f));
+    const v2f small = qd_fma2(q, a, a);
+    return v2f{t.x > 0.927734375f ? big.x : small.x, t.y > 0.927734375f ? big.y : small.y};
+}
+
 #define QD_FAST_DISPATCH(flag, body)                     \
     do {                                                 \
         if (flag) body(std::true_type{});                \

@@ -454,6 +454,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
         constexpr int LPR = ROWB / 16;                 // lanes per row in phase 2
         constexpr int RPP = 64 / LPR;                  // rows per pass
         const QP oqp = qd_load_qp(p.oq);
+        const QB oqb = qd_bytes_setup(oqp, p.oqmin, p.oqmax, p.oqoff);
         int8_t* tb8 = reinterpret_cast<int8_t*>(tb);   // [32 rows][ROWB]  (<= 4 KB for NT <= 8)
         const int Fout = p.Cout >> 1;
         const int f0 = (wcol0 >> 1);                   // first output feature of this wave
@@ -471,13 +472,17 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
                 const int zwv = sZw[lv], zwg = sZw[lg];
                 const float bv = sBias[lv], bg = sBias[lg];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rl = crow(r) + 4 * fhalf;
-                    const int as = sAsum[rbase + rl] - kz;
-                    const float val = (float)(acc[i][2 * jp][r] - zcv - __mul24(zwv, as)) * sv + bv;
-                    const float gate = (float)(acc[i][2 * jp + 1][r] - zcg - __mul24(zwg, as)) * sgt + bg;
-                    const float y = val * (0.5f * gate * (1.0f + qd_erff(gate * 0.70710678118654752440f)));
-                    tb8[rl * ROWB + jp * 32 + frow] = (int8_t)(qd_code_t<FAST>(y, oqp, p.oqmin, p.oqmax) - p.oqoff);
+                for (int r = 0; r < 16; r += 2) {      // two rows per step: the float math runs packed (v_pk_*_f32)
+                    const int rl0 = crow(r) + 4 * fhalf, rl1 = crow(r + 1) + 4 * fhalf;
+                    const int as0 = sAsum[rbase + rl0] - kz, as1 = sAsum[rbase + rl1] - kz;
+                    const v2f vi = {(float)(acc[i][2 * jp][r] - zcv - __mul24(zwv, as0)), (float)(acc[i][2 * jp][r + 1] - zcv - __mul24(zwv, as1))};
+                    const v2f gi = {(float)(acc[i][2 * jp + 1][r] - zcg - __mul24(zwg, as0)), (float)(acc[i][2 * jp + 1][r + 1] - zcg - __mul24(zwg, as1))};
+                    const v2f val = qd_fma2(vi, qd_splat2(sv), qd_splat2(bv)), gate = qd_fma2(gi, qd_splat2(sgt), qd_splat2(bg));
+                    const v2f y = val * (qd_splat2(0.5f) * gate * (qd_splat2(1.0f) + qd_erff2(gate * qd_splat2(0.70710678118654752440f))));
+                    int b0, b1;
+                    qd_bytes2_t<FAST>(y, oqp, oqb, b0, b1);
+                    tb8[rl0 * ROWB + jp * 32 + frow] = (int8_t)b0;
+                    tb8[rl1 * ROWB + jp * 32 + frow] = (int8_t)b1;
                 }
             }
 #pragma unroll
@@ -499,6 +504,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
         // (H = 1, d = Cout turns this epilogue into "Linear + residual -> the next Linear's int8 rows": the FF output of
         // a transformer block feeding SpatialTransformer.proj_out), quantises and stores 4 codes per lane.
         const QP oqp = qd_load_qp(p.oq);
+        const QB oqb = qd_bytes_setup(oqp, p.oqmin, p.oqmax, p.oqoff);
         int8_t* o8 = reinterpret_cast<int8_t*>(p.out);
         const int bidx = m0 / p.hdT, t0 = m0 - bidx * p.hdT;
         const bool hres = p.residual != nullptr;
@@ -536,10 +542,11 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
                     const int rl = ps * 8 + rr0;
                     v4f v = *reinterpret_cast<const v4f*>(tb + rl * 32 + c4);
                     if (hres) v += rs[ps];
-                    unsigned w = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        w |= (unsigned)((qd_code_t<FAST>(v[e] * p.oqpre, oqp, p.oqmin, p.oqmax) - p.oqoff) & 0xff) << (8 * e);
+                    int b0, b1, b2, b3;
+                    qd_bytes2_t<FAST>(v2f{v[0], v[1]} * qd_splat2(p.oqpre), oqp, oqb, b0, b1);
+                    qd_bytes2_t<FAST>(v2f{v[2], v[3]} * qd_splat2(p.oqpre), oqp, oqb, b2, b3);
+                    const unsigned w = __builtin_amdgcn_perm(__builtin_amdgcn_perm((unsigned)b3, (unsigned)b2, 0x0c0c0400u),
+                                                             __builtin_amdgcn_perm((unsigned)b1, (unsigned)b0, 0x0c0c0400u), 0x05040100u);
                     if (nok) *reinterpret_cast<unsigned*>(ob + (long)(rbase + rl) * p.hddpad) = w;
                 }
             }

@@ -49,7 +49,7 @@ def short(name):
 def klass(name):
     if "igemm" in name or "splitk_finalize" in name:
         return "igemm"
-    if "attn_kernel" in name or "bmm_" in name:
+    if "attn_" in name or "bmm_" in name:
         return "attention"
     if any(s in name for s in ("gn_", "ln_quant", "quant_rows", "quant_strided", "quant_heads", "geglu_quant", "temb_", "qparams")):
         return "producers"
@@ -84,7 +84,36 @@ def join(db_path, evals):
         print(f"| {ms / evals:7.3f} | {n / evals:6.1f} | {1000 * ms / n:8.2f} | {k} |")
 
 
+def timeline(db_path, evals, out_path):
+    """Per-dispatch timeline of the LAST evaluation between the markers: start, duration, gap to the previous kernel's
+    end, grid, kernel.  (The table's grid columns are discovered: rocpd schemas differ between ROCm releases.)"""
+    db = sqlite3.connect(db_path)
+    cols = [r[1] for r in db.execute("pragma table_info(rocpd_kernel_dispatch)").fetchall()]
+    gcols = [c for c in cols if "grid" in c.lower()] + [c for c in cols if "workgroup" in c.lower()]
+    sel = ", ".join("d." + c for c in gcols)
+    rows = db.execute(
+        f"select s.kernel_name, d.start, d.end{', ' + sel if sel else ''} from rocpd_kernel_dispatch d join "
+        "rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start").fetchall()
+    spins = [i for i, r in enumerate(rows) if "spin_kernel" in r[0]]
+    a, b = spins[-2], spins[-1]
+    seg = rows[a + 1:b]
+    per = len(seg) // evals
+    last = seg[len(seg) - per:]
+    t0 = last[0][1]
+    prev_end = None
+    with open(out_path, "w") as f:
+        f.write("# idx\tstart_us\tdur_us\tgap_us\t" + "/".join(gcols) + "\tkernel\n")
+        for i, r in enumerate(last):
+            gap = 0.0 if prev_end is None else (r[1] - prev_end) / 1e3
+            prev_end = max(prev_end or 0, r[2])
+            f.write(f"{i}\t{(r[1] - t0) / 1e3:.2f}\t{(r[2] - r[1]) / 1e3:.2f}\t{gap:.2f}\t{'/'.join(str(x) for x in r[3:])}\t{short(r[0])[:100]}\n")
+    print(f"{per} dispatches -> {out_path}")
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "timeline":
+        timeline(sys.argv[2], int(sys.argv[3]), sys.argv[4])
+        sys.exit(0)
     if sys.argv[1] == "run":
         run(sys.argv[2] if len(sys.argv) > 2 else "sd", int(sys.argv[3]) if len(sys.argv) > 3 else 8,
             int(sys.argv[4]) if len(sys.argv) > 4 else 3, graph="graph" in sys.argv)
