@@ -94,6 +94,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // (wait_vmcnt<N> + s_barrier).  LDS destination = lds_base (wave-uniform, bytes) + lane*16; M0 is written in the
 // same statement that reads it (cdna_hip_programming.md §5.7).
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
+#ifdef QD_ABL_NODMA            // measurement-only build (wrong results): the K-loop without its global -> LDS traffic
+    asm volatile("" ::"v"(gsrc), "s"(lds_base) : "memory");
+    return;
+#endif
     asm volatile(
         "s_mov_b32 m0, %1\n\t"
         "s_nop 0\n\t"
@@ -231,7 +235,11 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
             for (int i = 0; i < NA; ++i)
                 if (i == d) {
                     // K tail: the last 64-wide step of a tap may run past the segment's channels
+#ifdef QD_ABL_ZERODMA      // measurement-only build (wrong results): every DMA reads the same 16 bytes (issue cost without traffic)
+                    const int8_t* src = zero16;
+#else
                     const int8_t* src = a_chunk < krem ? a_cur[i] : zero16;
+#endif
                     glds16(src, lds0 + stage + (wave + 4 * i) * 1024);
                     a_cur[i] += a_inc[i];
                 }
@@ -239,7 +247,11 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
 #pragma unroll
             for (int r = 0; r < NBW; ++r)
                 if (r == d - NA) {
+#ifdef QD_ABL_ZERODMA
+                    glds16(zero16, lds0 + stage + b_dst[r]);
+#else
                     glds16(b_cur[r], lds0 + stage + b_dst[r]);
+#endif
                     b_cur[r] += b_inc[r];
                 }
         }
@@ -402,19 +414,34 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
             __builtin_amdgcn_sched_barrier(0);
             v4i bf;
             if constexpr (WB == 4) {
+#ifdef QD_ABL_NOUNPACK     // measurement-only build (wrong results): how much of a K-step is the nibble unpack?
+                bf = v4i{(int)raw[s].x, (int)raw[s].x, (int)raw[s].y, (int)raw[s].y};
+#else
                 bf = v4i{(int)(raw[s].x & 0x0F0F0F0Fu), (int)((raw[s].x >> 4) & 0x0F0F0F0Fu),
                          (int)(raw[s].y & 0x0F0F0F0Fu), (int)((raw[s].y >> 4) & 0x0F0F0F0Fu)};
+#endif
             } else {
                 bf = raw[s];
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
+#ifdef QD_ABL_NOMFMA       // measurement-only build (wrong results): the K-step without its matrix instructions
+                acc[i][j][0] += af[ks][i].x ^ bf.x ^ af[ks][i].w ^ bf.w;
+#else
                 acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks][i], bf, acc[i][j], 0, 0, 0);
+#endif
             if (j == 0) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) asum[i] += bytesum16(af[ks][i]);
             }
+#ifndef QD_DMA_FRONT
             if (s < PER) issue_one(nxt, s);
+#else                      // A/B knob: all DMAs of the step right behind the first MFMA group
+            if (s == 0) {
+#pragma unroll
+                for (int d = 0; d < PER && d < S; ++d) issue_one(nxt, d);
+            }
+#endif
         }
 #pragma unroll
         for (int d = S; d < PER; ++d) issue_one(nxt, d);
