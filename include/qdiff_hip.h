@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 10
+#define QD_ABI_VERSION 11
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -160,8 +160,13 @@ typedef struct {
     int32_t*       hd_sum;
     /* optional (w_tiled, QD_EPI_LINEAR, fp32 out, Ho*Wo % 128 == 0): the kernel also writes the first level of the
      * GroupNorm statistics of its output, gn_part[b][Ho*Wo/128][Cout][2] = {sum, sum of squares} over each 128-row
-     * chunk, which qd_groupnorm_silu_quant accepts as part_in (one pass over the tensor less).  Disables split-K. */
+     * chunk, which qd_groupnorm_silu_quant accepts as part_in (one pass over the tensor less).  Disables split-K.
+     * gn_ld: channels per chunk row of the statistics buffer (0 = Cout).  A value > Cout lets two producers write the
+     * statistics of the two halves of a skip concatenation (openaimodel.py:776) into column ranges of one buffer, the
+     * same way `out` + `ldo` place their fp32 rows into column ranges of one activation buffer: the concatenation
+     * then costs no copy at all. */
     float*         gn_part;
+    int64_t        gn_ld;
 } qd_conv_desc;
 
 int qd_conv2d_i8(const qd_conv_desc* d, void* stream);
@@ -220,16 +225,36 @@ int qd_temb_mlp(const float* x, int64_t ldx, int B, int K, int apply_silu, const
  *     Two-quantizer outputs are not needed here (split only affects 1x1 skips).
  *     If yout != NULL the fp32 normalised (+SiLU) tensor is also written ([B*S][ldy]).
  *     part_in != NULL: the first statistics level was already produced by the kernel that wrote x
- *     (qd_conv_desc.gn_part: [B][nchunk_in][C][2] sums / sums of squares per row chunk); the statistics
- *     pass over x is skipped.
+ *     (qd_conv_desc.gn_part: [B][nchunk_in][part_ld >= C][2] sums / sums of squares per row chunk; part_ld = 0
+ *     means C); the statistics pass over x is skipped.
+ *     raw != NULL (and raw->out != NULL): see qd_raw_quant above.
  * ------------------------------------------------------------------------------------------ */
+/* Optional second output of qd_groupnorm_silu_quant: the RAW (un-normalised) input quantised for another consumer of
+ * the same tensor, i.e. the 1x1 skip connection of a residual block, which reads the very tensor `in_layers` normalises
+ * (qdiff/quant_block.py:108-111; openaimodel.py:266-278), with up to two channel segments that carry their own
+ * activation quantisers (the split shortcut, quant_layer.py:257-269).  Codes are those of qd_quantize_act, written to
+ * out[row][oc0 + (c - c0)] for c in [c0, c0 + clen); c0 / clen / oc0 are multiples of 16.                               */
+typedef struct {
+    int32_t      c0, clen, oc0;
+    int32_t      qmin, qmax, off;
+    const float* qparams;
+} qd_raw_seg;
+typedef struct {
+    int8_t*    out;       /* [B*S][ldo] int8 rows of the consumer (NULL: no raw output) */
+    int64_t    ldo;
+    int32_t    nseg;      /* 1 or 2 */
+    int32_t    _pad;
+    qd_raw_seg seg[2];
+} qd_raw_quant;
+
 int64_t qd_groupnorm_ws_bytes(int64_t B, int64_t C, int64_t S);
 int qd_groupnorm_silu_quant(const void* x, int x_dtype, int64_t B, int64_t S, int C, int64_t ldx,
                             int groups, float eps, const float* gamma, const float* beta,
                             int apply_silu,
                             const float* qparams, int qmin, int qmax, int off,
                             int8_t* out, int64_t ldo, float* yout, int64_t ldy,
-                            void* ws, const float* part_in, int nchunk_in, void* stream);
+                            void* ws, const float* part_in, int nchunk_in, int64_t part_ld, const qd_raw_quant* raw,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K9a LayerNorm -> quantise (up to 3 consumers).  Replaces nn.LayerNorm (attention.py:229-231)

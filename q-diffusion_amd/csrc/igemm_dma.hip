@@ -72,6 +72,7 @@ struct ConvD {
     int32_t* hdsum;           // O_HTR: [(b*H+h)][dpad] column sums of the stored bytes (atomically accumulated)
     float* gnpart;            // O_F32, optional: per-(sample, 128-row chunk, channel) {sum, sum of squares} of the output,
     int    gn_nchunk;         //   i.e. the first level of GroupNorm's statistics (layout of gn_partial_kernel); S/128
+    long   gn_ld;             //   channels per chunk row of gnpart (>= Cout: column range of a wider statistics buffer)
 };
 
 // O_PART: split-K partial.  The block contracts K-steps [y*it_per, (y+1)*it_per) only and stores
@@ -794,7 +795,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
                     tq += sGn[(wv * WCOLS + cw) * 2 + 1];
                 }
                 const int b = mrow / HoWo, chunk = (mrow - b * HoWo) >> 7;
-                float* dst = p.gnpart + (((long)b * p.gn_nchunk + chunk) * p.Cout + n0 + c) * 2;
+                float* dst = p.gnpart + (((long)b * p.gn_nchunk + chunk) * p.gn_ld + n0 + c) * 2;
                 dst[0] = ts;
                 dst[1] = tq;
             }
@@ -1033,6 +1034,8 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
         QD_REQUIRE((d->Ho * d->Wo) % 128 == 0, "qd_conv2d_i8: gn_part needs Ho*Wo %% 128 == 0 (a 128-row chunk stays inside one sample)");
         k.gnpart = d->gn_part;
         k.gn_nchunk = d->Ho * d->Wo / 128;
+        QD_REQUIRE(d->gn_ld == 0 || d->gn_ld >= d->Cout, "qd_conv2d_i8: gn_ld must be 0 or >= Cout");
+        k.gn_ld = d->gn_ld ? (long)d->gn_ld : (long)d->Cout;
     }
     const bool mt2_ok = !heads || d->hd_T % 256 == 0;            // a block must stay inside one sample
     if (geglu) {

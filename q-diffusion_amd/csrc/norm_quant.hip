@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 }
 
 // finalize: grid (groups, B), 64 threads.  Writes per-(b,c) affine a = rstd*gamma, sh = beta - mean*a.
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, int nchunk, long S, int C,
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, int nchunk, long ldp, long S, int C,
                                                          int groups, float eps, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ ab) {
     const int g = blockIdx.x;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     const int items = nchunk * cpg;
     for (int i = threadIdx.x; i < items; i += 64) {
         int chunk = i / cpg, c = g * cpg + i % cpg;
-        const float* p = part + (((b * nchunk + chunk) * (long)C) + c) * 2;
+        const float* p = part + (((b * nchunk + chunk) * ldp) + c) * 2;
         s += (double)p[0];
         q += (double)p[1];
     }
@@ -75,13 +75,26 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     }
 }
 
+// second, optional output of the apply pass: the RAW input quantised for another consumer of the same tensor — the 1x1
+// skip connection of a residual block (reference quant_block.py:108-111: `skip_connection(x, split)` reads the very
+// tensor `in_layers` normalises; up to two channel segments with their own activation quantisers, quant_layer.py:257-269).
+// One read of x feeds both consumers instead of a second pass (qd_quantize_act) over the largest tensors of the UNet.
+struct RawQ {
+    int8_t* out;
+    long    ldo;
+    int     nseg;
+    int     c0[2], clen[2], oc0[2], off[2];
+    float   qmin[2], qmax[2];
+    const float* qp[2];
+};
+
 // apply: lane = 4 consecutive channels of one row (float4 in, 4 bytes out; both sides fully coalesced).
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, long rows, long S, int C, long ldx,
                                                        const float* __restrict__ ab, int apply_silu,
                                                        const float* __restrict__ qp, float qmin, float qmax, int off,
                                                        int8_t* __restrict__ out, long ldo, float* __restrict__ yout,
-                                                       long ldy, int vec) {
+                                                       long ldy, int vec, const RawQ raw) {
     const int chunks = C >> 2;
     long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= rows * chunks) return;
@@ -107,6 +120,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     };
     QD_FAST_DISPATCH(q.fast, body);
     if (out) *reinterpret_cast<unsigned*>(out + row * ldo + c) = u;
+    if (raw.out) {
+        // segment boundaries are multiples of 16 channels (checked by the host): a lane's 4 channels share a segment
+        const bool s1 = raw.nseg > 1 && c >= raw.c0[1];           // explicit selects: no dynamically indexed kernel argument
+        const int rc0 = s1 ? raw.c0[1] : raw.c0[0], rlen = s1 ? raw.clen[1] : raw.clen[0], roc0 = s1 ? raw.oc0[1] : raw.oc0[0];
+        if (c >= rc0 && c < rc0 + rlen) {
+            const QP rq = qd_load_qp(s1 ? raw.qp[1] : raw.qp[0]);
+            const float rmin = s1 ? raw.qmin[1] : raw.qmin[0], rmax = s1 ? raw.qmax[1] : raw.qmax[0];
+            const int roff = s1 ? raw.off[1] : raw.off[0];
+            unsigned w = 0;
+            auto rbody = [&](auto ft) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    w |= (unsigned)((qd_code_t<decltype(ft)::value>(v[j], rq, rmin, rmax) - roff) & 0xff) << (8 * j);
+            };
+            QD_FAST_DISPATCH(rq.fast, rbody);
+            *reinterpret_cast<unsigned*>(raw.out + row * raw.ldo + roc0 + (c - rc0)) = w;
+        }
+    }
 }
 
 // LayerNorm: one wave per row, row held in registers (C <= 64*4*MAXV).
@@ -240,7 +271,7 @@ extern "C" int64_t qd_groupnorm_ws_bytes(int64_t B, int64_t C, int64_t S) {
 extern "C" int qd_groupnorm_silu_quant(const void* x, int x_dtype, int64_t B, int64_t S, int C, int64_t ldx, int groups,
                                        float eps, const float* gamma, const float* beta, int apply_silu,
                                        const float* qparams, int qmin, int qmax, int off, int8_t* out, int64_t ldo,
-                                       float* yout, int64_t ldy, void* ws, const float* part_in, int nchunk_in, void* stream) {
+                                       float* yout, int64_t ldy, void* ws, const float* part_in, int nchunk_in, int64_t part_ld, const qd_raw_quant* raw, void* stream) {
     QD_REQUIRE(x && ws && (out || yout), "qd_groupnorm_silu_quant: null pointer");
     QD_REQUIRE(!out || qparams, "qd_groupnorm_silu_quant: quantised output needs qparams");
     QD_REQUIRE(x_dtype == QD_F32 || x_dtype == QD_F16, "qd_groupnorm_silu_quant: dtype must be f32/f16");
@@ -252,7 +283,8 @@ extern "C" int qd_groupnorm_silu_quant(const void* x, int x_dtype, int64_t B, in
     const int vec = qd_aligned(x, x_dtype == QD_F32 ? 16 : 8) && ldx % 4 == 0;
     float* part = reinterpret_cast<float*>(ws);
     float* ab = part + (size_t)B * nchunk_own * C * 2;
-    QD_REQUIRE(!part_in || nchunk_in > 0, "qd_groupnorm_silu_quant: part_in needs nchunk_in > 0");
+    QD_REQUIRE(!part_in || (nchunk_in > 0 && (part_ld == 0 || part_ld >= C)), "qd_groupnorm_silu_quant: part_in needs nchunk_in > 0 and part_ld >= C");
+    const long ldp = part_in && part_ld ? (long)part_ld : (long)C;
     const int nchunk = part_in ? nchunk_in : nchunk_own;
     if (part_in) {
         // first statistics level came with the tensor (written by the producing GEMM's epilogue)
@@ -260,14 +292,29 @@ extern "C" int qd_groupnorm_silu_quant(const void* x, int x_dtype, int64_t B, in
         hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, (const float*)x, (long)S, C, (long)ldx, part, nchunk, vec);
     else
         hipLaunchKernelGGL(gn_partial_kernel<__half>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, (const __half*)x, (long)S, C, (long)ldx, part, nchunk, vec);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, (unsigned)B), dim3(64), 0, st, part_in ? part_in : part, nchunk, (long)S, C, groups, eps, gamma, beta, ab);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, (unsigned)B), dim3(64), 0, st, part_in ? part_in : part, nchunk, ldp, (long)S, C, groups, eps, gamma, beta, ab);
+    RawQ rq{};
+    if (raw && raw->out) {
+        QD_REQUIRE(raw->nseg == 1 || raw->nseg == 2, "qd_groupnorm_silu_quant: raw output takes 1 or 2 segments");
+        QD_REQUIRE(raw->ldo % 16 == 0 && qd_aligned(raw->out, 16), "qd_groupnorm_silu_quant: raw output rows must be 16-byte aligned");
+        rq.out = raw->out; rq.ldo = (long)raw->ldo; rq.nseg = raw->nseg;
+        for (int i = 0; i < raw->nseg; ++i) {
+            const auto& g = raw->seg[i];
+            QD_REQUIRE(g.qparams && g.c0 >= 0 && g.clen > 0 && g.c0 % 16 == 0 && g.clen % 16 == 0 && g.oc0 % 16 == 0 && g.c0 + g.clen <= C &&
+                       g.oc0 + g.clen <= raw->ldo, "qd_groupnorm_silu_quant: raw segment %d: c0 / clen / oc0 must be multiples of 16 inside the rows", i);
+            QD_REQUIRE(g.qmax - g.off <= 127 && g.qmin - g.off >= -128, "qd_groupnorm_silu_quant: raw segment %d grid does not fit int8", i);
+            QD_REQUIRE(i == 0 || g.c0 >= raw->seg[0].c0 + raw->seg[0].clen, "qd_groupnorm_silu_quant: raw segments must be ordered and disjoint");
+            rq.c0[i] = g.c0; rq.clen[i] = g.clen; rq.oc0[i] = g.oc0; rq.off[i] = g.off;
+            rq.qmin[i] = (float)g.qmin; rq.qmax[i] = (float)g.qmax; rq.qp[i] = g.qparams;
+        }
+    }
     long rows = B * S;
     long total = rows * (C / 4);
     dim3 grid((unsigned)((total + 255) / 256));
     if (x_dtype == QD_F32)
-        hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, rows, (long)S, C, (long)ldx, ab, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, yout, (long)ldy, vec);
+        hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, rows, (long)S, C, (long)ldx, ab, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, yout, (long)ldy, vec, rq);
     else
-        hipLaunchKernelGGL(gn_apply_kernel<__half>, grid, dim3(256), 0, st, (const __half*)x, rows, (long)S, C, (long)ldx, ab, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, yout, (long)ldy, vec);
+        hipLaunchKernelGGL(gn_apply_kernel<__half>, grid, dim3(256), 0, st, (const __half*)x, rows, (long)S, C, (long)ldx, ab, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, yout, (long)ldy, vec, rq);
     QD_LAUNCH_CHECK("qd_groupnorm_silu_quant");
     return 0;
 }

@@ -51,8 +51,12 @@ class Upsample(nn.Module):
         if with_conv:
             self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
 
-    def forward(self, x):
+    qd_takes_out_slot = True
+
+    def forward(self, x, out_slot=None):
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        if self.with_conv and out_slot is not None and getattr(self.conv, "qd_takes_out_slot", False):
+            return self.conv(x, out_slot=out_slot)
         return self.conv(x) if self.with_conv else x
 
 
@@ -65,10 +69,15 @@ class Downsample(nn.Module):
         if with_conv:
             self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
 
-    def forward(self, x):
+    qd_takes_out_slot = True
+
+    def forward(self, x, out_slot=None):
         if not self.with_conv:
             return F.avg_pool2d(x, kernel_size=2, stride=2)
-        return self.conv(F.pad(x, (0, 1, 0, 1), mode="constant", value=0))
+        x = F.pad(x, (0, 1, 0, 1), mode="constant", value=0)
+        if out_slot is not None and getattr(self.conv, "qd_takes_out_slot", False):
+            return self.conv(x, out_slot=out_slot)
+        return self.conv(x)
 
 
 class ResnetBlock(nn.Module):
@@ -216,30 +225,59 @@ class Model(nn.Module):
         else:
             temb = self.temb.dense[1](nonlinearity(self.temb.dense[0](temb)))
 
-        skips = [self.conv_in(x)]
+        # planned skip concatenations (see arch/ldm_unet.py UNetModel.forward and engine.CatSlot): producer k of the
+        # encoder writes side 1 of slot k, the decoder-side tensor that meets it writes side 0
+        from .. import engine, quant_block as qb
+        plan = self.__dict__.get("_cat_plan")
+        nsk = 1 + self.num_resolutions * self.num_res_blocks + (self.num_resolutions - 1)
+        slots = ([engine.CatSlot(*plan[k]) for k in range(nsk)]
+                 if (plan is not None and len(plan) == nsk and qb.CAT_SLOTS and not torch.is_grad_enabled()) else None)
+        seen = [None] * nsk
+
+        def run(mod, *args, slot=None, **kw):
+            if slot is not None and getattr(mod, "qd_takes_out_slot", False):
+                return mod(*args, out_slot=slot, **kw)
+            return mod(*args, **kw)
+
+        def enc_slot():
+            return slots[len(skips)].side(1) if slots else None
+
+        def dec_slot():
+            """side 0 of the slot whose skip tensor is popped next (None when nothing is left to concatenate)"""
+            return slots[len(skips) - 1].side(0) if (slots and skips) else None
+
+        skips = []
+        skips.append(run(self.conv_in, x, slot=enc_slot()))
         for lvl, stage in enumerate(self.down):
             for j in range(self.num_res_blocks):
-                h = stage.block[j](skips[-1], temb)
                 if len(stage.attn) > 0:
-                    h = stage.attn[j](h)
+                    h = run(stage.attn[j], stage.block[j](skips[-1], temb), slot=enc_slot())
+                else:
+                    h = run(stage.block[j], skips[-1], temb, slot=enc_slot())
                 skips.append(h)
             if lvl != self.num_resolutions - 1:
-                skips.append(stage.downsample(skips[-1]))
+                skips.append(run(stage.downsample, skips[-1], slot=enc_slot()))
 
-        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(skips[-1], temb)), temb)
+        h = run(self.mid.block_2, self.mid.attn_1(self.mid.block_1(skips[-1], temb)), temb, slot=dec_slot())
 
         use_split = bool(getattr(self.config, "split_shortcut", False))
         for lvl in reversed(range(self.num_resolutions)):
             stage = self.up[lvl]
             for j in range(self.num_res_blocks + 1):
-                cat = torch.cat([h, skips.pop()], dim=1)
-                if use_split:
-                    h = stage.block[j](cat, temb, split=h.size(1))    # reference :340-346
-                else:
-                    h = stage.block[j](cat, temb)
-                if len(stage.attn) > 0:
-                    h = stage.attn[j](h)
+                k = len(skips) - 1
+                skip = skips.pop()
+                seen[k] = (h.size(1), skip.size(1))
+                cat = qb.cat_channels(h, skip)
+                # the tensor concatenated next comes from the upsample (end of a stage above level 0), else from the
+                # attention block, else from the residual block: only that producer is given the slot
+                ends_stage = j == self.num_res_blocks and lvl != 0
+                has_attn = len(stage.attn) > 0
+                kw = {"split": h.size(1)} if use_split else {}                # reference :340-346
+                h = run(stage.block[j], cat, temb, slot=None if (has_attn or ends_stage) else dec_slot(), **kw)
+                if has_attn:
+                    h = run(stage.attn[j], h, slot=None if ends_stage else dec_slot())
             if lvl != 0:
-                h = stage.upsample(h)
+                h = run(stage.upsample, h, slot=dec_slot())
+        self.__dict__["_cat_plan"] = seen
 
         return self.conv_out(nonlinearity(self.norm_out(h)))

@@ -172,7 +172,10 @@ class SpatialTransformer(nn.Module):
             [BasicTransformerBlock(inner, n_heads, d_head, dropout=dropout, context_dim=context_dim) for _ in range(depth)])
         self.proj_out = zero_module(nn.Conv2d(inner, in_channels, kernel_size=1, stride=1, padding=0))
 
-    def forward(self, x, context=None):
+    qd_takes_out_slot = True
+
+    def forward(self, x, context=None, out_slot=None):
+        """out_slot (engine-internal, optional): engine.CatSlot side that receives the output on the integer path."""
         from .. import quant_block as qb            # lazy: quant_block imports this module's classes
         b, c, h, w = x.shape
         if qb._int_mode(self.proj_in, self.proj_out) and not (self.proj_in.split or self.proj_out.split):
@@ -188,9 +191,9 @@ class SpatialTransformer(nn.Module):
                 else:
                     t = blk(t, context)
             if t.dtype == torch.int8:
-                out = self.proj_out.forward_codes(t, 1, 1, b * h * w, residual=rows, gn_stats=True)
+                out = self.proj_out.forward_codes(t, 1, 1, b * h * w, residual=rows, gn_stats=True, slot=out_slot)
             else:
-                out = qb._linear_rows(self.proj_out, t.reshape(b * h * w, t.shape[-1]), residual=rows, gn_stats=True)
+                out = qb._linear_rows(self.proj_out, t.reshape(b * h * w, t.shape[-1]), residual=rows, gn_stats=True, slot=out_slot)
             return qb._rows_to_nchw(out, b, h, w)
         t = self.proj_in(self.norm(x))
         t = t.permute(0, 2, 3, 1).reshape(b, h * w, t.shape[1])
@@ -210,14 +213,19 @@ class TimestepBlock(nn.Module):
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
     """Routes emb / context / split to the children that take them (reference openaimodel.py:74-88)."""
 
-    def forward(self, x, emb, context=None, split=0):
-        for layer in self:
+    def forward(self, x, emb, context=None, split=0, out_slot=None):
+        """out_slot (engine-internal, optional): where the LAST layer should put its output — one side of a planned skip
+        concatenation (engine.CatSlot).  Only layers that declare `qd_takes_out_slot` are told; the others (and every
+        non-integer state) allocate as usual and the concatenation copies."""
+        last = len(self) - 1
+        for i, layer in enumerate(self):
+            kw = {"out_slot": out_slot} if (i == last and out_slot is not None and getattr(layer, "qd_takes_out_slot", False)) else {}
             if isinstance(layer, TimestepBlock):
-                x = layer(x, emb, split=split)
+                x = layer(x, emb, split=split, **kw)
             elif isinstance(layer, SpatialTransformer):
-                x = layer(x, context)
+                x = layer(x, context, **kw)
             else:
-                x = layer(x)
+                x = layer(x, **kw)
         return x
 
 
@@ -229,7 +237,9 @@ class Upsample(nn.Module):
         if use_conv:
             self.conv = nn.Conv2d(channels, self.out_channels, 3, padding=padding)
 
-    def forward(self, x):
+    qd_takes_out_slot = True
+
+    def forward(self, x, out_slot=None):
         assert x.shape[1] == self.channels
         if self.use_conv:
             from .. import quant_block as qb
@@ -243,7 +253,7 @@ class Upsample(nn.Module):
                 plan = conv.conv_plan()
                 xq = engine.quantize_rows(rows, plan, 1, c, b * h * w, (0, 1, rows.stride(0)))
                 up = xq.view(b, h, 1, w, 1, -1).expand(b, h, 2, w, 2, xq.shape[1]).reshape(b * 4 * h * w, xq.shape[1])
-                out = conv.forward_codes(up, b, 2 * h, 2 * w, gn_stats=True)
+                out = conv.forward_codes(up, b, 2 * h, 2 * w, gn_stats=True, slot=out_slot)
                 return qb._rows_to_nchw(out, b, 2 * h, 2 * w)
         x = F.interpolate(x, scale_factor=2, mode="nearest")
         return self.conv(x) if self.use_conv else x
@@ -260,8 +270,12 @@ class Downsample(nn.Module):
             assert self.channels == self.out_channels
             self.op = nn.AvgPool2d(kernel_size=2, stride=2)
 
-    def forward(self, x):
+    qd_takes_out_slot = True
+
+    def forward(self, x, out_slot=None):
         assert x.shape[1] == self.channels
+        if out_slot is not None and getattr(self.op, "qd_takes_out_slot", False):
+            return self.op(x, out_slot=out_slot)
         return self.op(x)
 
 
@@ -485,16 +499,41 @@ class UNetModel(nn.Module):
         if self.num_classes is not None:
             emb = emb + self.label_emb(y)
         h = x.type(self.dtype).contiguous(memory_format=torch.channels_last)
+        from .. import engine, quant_block as qb
+        # Skip concatenations (reference :772-777) are planned: the channel counts of both halves of every
+        # `th.cat([h, hs.pop()], dim=1)` are recorded by the first evaluation; from then on the producers of both halves
+        # write into the two column ranges of one buffer (engine.CatSlot) and cat_channels returns a view.
+        plan = self.__dict__.get("_cat_plan")
+        n_in = len(self.input_blocks)
+        slots = ([engine.CatSlot(*plan[i]) for i in range(n_in)]
+                 if (plan is not None and len(plan) == n_in and qb.CAT_SLOTS and not torch.is_grad_enabled()) else None)
+        seen = [None] * n_in
         skips = []
-        for blk in self.input_blocks:
-            h = blk(h, emb, context)
+        for i, blk in enumerate(self.input_blocks):
+            h = blk(h, emb, context, out_slot=slots[i].side(1) if slots else None)
             skips.append(h)
-        h = self.middle_block(h, emb, context)
+        h = self.middle_block(h, emb, context, out_slot=slots[-1].side(0) if slots else None)
         for blk in self.output_blocks:
             split = h.shape[1] if self.split else 0          # reference :772-777
-            from ..quant_block import cat_channels              # keeps the producers' GroupNorm statistics
-            h = blk(cat_channels(h, skips.pop()), emb, context, split=split)
-        return self.out(h.type(x.dtype))
+            i = len(skips) - 1
+            skip = skips.pop()
+            seen[i] = (h.shape[1], skip.shape[1])
+            h = blk(qb.cat_channels(h, skip), emb, context, split=split, out_slot=slots[i - 1].side(0) if (slots and i > 0) else None)
+        self.__dict__["_cat_plan"] = seen
+        return self._out(h.type(x.dtype))
+
+    def _out(self, h):
+        """GroupNorm -> SiLU -> conv (reference :778-781); on the integer path the normalisation emits the conv's int8 rows."""
+        from .. import quant_block as qb
+        conv = self.out[-1]
+        if (len(self.out) == 3 and isinstance(self.out[0], nn.GroupNorm) and isinstance(self.out[1], nn.SiLU) and h.dim() == 4
+                and qb._int_mode(conv) and conv.split == 0 and conv.kind == 'conv2d' and conv.act_quantizer.inited
+                and h.shape[1] % 16 == 0):
+            B, C, H, W = h.shape
+            rows = qb._nhwc_rows(h)
+            xq = qb._gn_silu_to(conv, rows, B, H * W, C, self.out[0])
+            return qb._rows_to_nchw(conv.forward_codes(xq, B, H, W), B, H, W)
+        return self.out(h)
 
 
 def sd_v1_config():

@@ -255,18 +255,75 @@ def conv_out_hw(H, W, plan, pad_br=None):
     return Ho, Wo
 
 
+class CatSlot:
+    """Planned destination of one skip concatenation `th.cat([h, hs.pop()], dim=1)` (openaimodel.py:776, ddim
+    diffusion.py:340): the kernel that produces the decoder-side `h` (side 0) and the kernel that produced the encoder-side
+    skip tensor (side 1) write their fp32 rows — and the first-level GroupNorm statistics of those rows — straight into
+    column ranges of ONE [M][C0 + C1] buffer (`ldo` / `gn_ld` of qd_conv2d_i8), every consumer reads its half through the
+    row stride, and the concatenation itself is a view.  A producer that does not take a slot simply ignores it; the
+    concatenation then falls back to the copy (quant_block.cat_channels checks adjacency in memory, not this object)."""
+
+    def __init__(self, c_left, c_right):
+        self.c = (int(c_left), int(c_right))
+        self.buf = None
+        self.pbuf = None
+
+    def side(self, i):
+        return _SlotSide(self, i)
+
+    def rows(self, i, M, C, device):
+        if C != self.c[i]:
+            return None
+        if self.buf is None:
+            self.buf = torch.empty((M, self.c[0] + self.c[1]), dtype=torch.float32, device=device)
+        if self.buf.shape[0] != M or self.buf.device != device:
+            return None
+        c0 = 0 if i == 0 else self.c[0]
+        return self.buf[:, c0:c0 + C]
+
+    def part(self, i, B, nchunk, C, device):
+        if C != self.c[i]:
+            return None
+        if self.pbuf is None:
+            self.pbuf = torch.empty((B * nchunk, self.c[0] + self.c[1], 2), dtype=torch.float32, device=device)
+        if self.pbuf.shape[0] != B * nchunk or self.pbuf.device != device:
+            return None
+        c0 = 0 if i == 0 else self.c[0]
+        return self.pbuf.view(B, nchunk, self.c[0] + self.c[1], 2)[:, :, c0:c0 + C]
+
+
+class _SlotSide:
+    __slots__ = ("slot", "i")
+
+    def __init__(self, slot, i):
+        self.slot, self.i = slot, i
+
+    def rows(self, M, C, device):
+        return self.slot.rows(self.i, M, C, device)
+
+    def part(self, B, nchunk, C, device):
+        return self.slot.part(self.i, B, nchunk, C, device)
+
+
 def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, residual=None, acc_out=None,
-                 out_dtype=torch.float32, pad_tl=None, splitk=None, gn_stats=False):
+                 out_dtype=torch.float32, pad_tl=None, splitk=None, gn_stats=False, slot=None):
     """Run K3/K4 on quantised rows xq [B*H*W][ldx].  Returns out [B*Ho*Wo][Cout] (row-major).
     splitk=False forbids the split-K schedule (tests compare it with the default, which lets the library decide).
     gn_stats=True: when the layer is eligible (tile-ordered int4, fp32 out, Ho*Wo % 128 == 0, not a split-K layer) the
     kernel also writes the first level of GroupNorm statistics of its output; they are attached to the returned tensor
-    as `out.qd_gn_part` ([B][Ho*Wo/128][Cout][2]) for groupnorm_silu_quant to pick up."""
+    as `out.qd_gn_part` ([B][Ho*Wo/128][Cout][2]) for groupnorm_silu_quant to pick up.
+    slot: optional CatSlot side — the output (and its statistics) land in that column range of the concatenation buffer."""
     if Ho is None:
         Ho, Wo = conv_out_hw(H, W, plan)
     M = B * Ho * Wo
     if out is None and acc_out is None:
-        out = torch.empty((M, plan.Cout), dtype=out_dtype, device=xq.device)
+        if slot is not None and out_dtype == torch.float32:
+            out = slot.rows(M, plan.Cout, xq.device)
+        if out is None:
+            slot = None
+            out = torch.empty((M, plan.Cout), dtype=out_dtype, device=xq.device)
+    else:
+        slot = None
     pad = plan.pad if pad_tl is None else pad_tl
     call = hip.ConvCall(x=xq, w=plan.pack.wq, out=out, bias=plan.bias, rowbias=rowbias,
                         residual=residual, ldx=plan.ldx, ldk=plan.pack.ldk,
@@ -278,8 +335,11 @@ def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, re
                         splitk=splitk)
     part = None
     if (gn_stats and acc_out is None and plan.pack.tiled and out.dtype == torch.float32 and (Ho * Wo) % 128 == 0
-            and out.stride(0) == plan.Cout and (splitk is False or hip.splitk_ws_bytes(call) == 0)):
-        part = torch.empty((B, Ho * Wo // 128, plan.Cout, 2), dtype=torch.float32, device=xq.device)
+            and out.stride(1) == 1 and (splitk is False or hip.splitk_ws_bytes(call) == 0)):
+        if slot is not None:
+            part = slot.part(B, Ho * Wo // 128, plan.Cout, xq.device)
+        if part is None:
+            part = torch.empty((B, Ho * Wo // 128, plan.Cout, 2), dtype=torch.float32, device=xq.device)
         call.gn_part = part
     hip.conv2d_i8(call, acc_out=acc_out)
     if part is not None:
@@ -316,24 +376,55 @@ def _workspace(nbytes, device):
     return buf
 
 
-def groupnorm_silu_quant(x_rows, B, S, C, gn, silu, plan=None, want_float=False, part=None):
-    """x_rows: channels-last rows [B*S][>=C] (fp32/fp16).  Returns (int8 rows for `plan`, float rows).
-    part: first-level statistics that came with x_rows from its producer (conv_forward(gn_stats=True))."""
-    if part is not None:
+def _part_view(part, B, S, C):
+    """Producer statistics `part` ([Bp][n][C][2], possibly a column range of a wider buffer) as [B][S/128][C][2], or None."""
+    if part is None or S % 128 != 0 or part.dim() != 4 or part.shape[2] != C or part.shape[0] * part.shape[1] * 128 != B * S:
+        return None
+    if tuple(part.shape[:2]) == (B, S // 128):
+        return part
+    try:
         # producers that ran as one [B*S]-row GEMM report [1][B*S/128]: same memory as [B][S/128] when S % 128 == 0
-        if S % 128 == 0 and part.shape[2] == C and part.shape[0] * part.shape[1] * 128 == B * S and part.is_contiguous():
-            part = part.view(B, S // 128, C, 2)
-        else:
-            part = None
+        return part.view(B, S // 128, C, 2)
+    except RuntimeError:
+        return None
+
+
+def raw_quant_segs(plan, C):
+    """Segment table of qd_raw_quant for `plan` reading a C-channel tensor, or None when the layout is not covered
+    (segment bounds must be multiples of 16 channels and tile the C channels)."""
+    segs, pos = [], 0
+    for sg, d, grid, qp in zip(plan.pack.segs, plan.segs, plan.grids, plan.qparams):
+        if sg["clen"] % 16 or sg["c0w"] % 16 or d["c0"] % 16 or sg["c0w"] != pos:
+            return None
+        segs.append(dict(c0=sg["c0w"], clen=sg["clen"], oc0=d["c0"], qparams=qp, grid=grid))
+        pos += sg["clen"]
+    return segs if pos == C and 1 <= len(segs) <= 2 else None
+
+
+def groupnorm_silu_quant(x_rows, B, S, C, gn, silu, plan=None, want_float=False, part=None, raw_plan=None):
+    """x_rows: channels-last rows [B*S][>=C] (fp32/fp16).  Returns (int8 rows for `plan`, float rows) — and, with
+    raw_plan (the ConvPlan of a 1x1 consumer of the SAME un-normalised tensor: a residual block's skip connection), a
+    third value: that consumer's int8 input rows, quantised in the same pass over x.
+    part: first-level statistics that came with x_rows from its producer (conv_forward(gn_stats=True))."""
+    part = _part_view(part, B, S, C)
     dev = x_rows.device
     ws = _workspace(hip.groupnorm_ws_bytes(B, C, S), dev)
     out = torch.empty((B * S, plan.ldx), dtype=torch.int8, device=dev) if plan is not None else None
     y = torch.empty((B * S, C), dtype=torch.float32, device=dev) if want_float else None
     if plan is not None and (len(plan.segs) != 1 or plan.pack.segs[0]["clen"] != C):
         raise hip.HipEngineError("groupnorm producer feeds single-segment consumers of the same width only")
+    raw, raw_out = None, None
+    if raw_plan is not None:
+        segs = raw_quant_segs(raw_plan, C)
+        if segs is None:
+            raise hip.HipEngineError("raw_plan: the consumer's segments must tile the channels in multiples of 16")
+        raw_out = torch.empty((B * S, raw_plan.ldx), dtype=torch.int8, device=dev)
+        raw = dict(out=raw_out, segs=segs)
     hip.groupnorm_silu_quant(x_rows, B, S, C, x_rows.stride(0), gn.num_groups, gn.eps, gn.weight, gn.bias, silu,
                              plan.qparams[0] if plan is not None else None, plan.grids[0] if plan is not None else None,
-                             out, plan.ldx if plan is not None else 0, ws, yout=y, ldy=C, part=part)
+                             out, plan.ldx if plan is not None else 0, ws, yout=y, ldy=C, part=part, raw=raw)
+    if raw_plan is not None:
+        return out, y, raw_out
     return out, y
 
 

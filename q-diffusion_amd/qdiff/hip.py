@@ -44,7 +44,17 @@ class ConvDesc(ctypes.Structure):
                 ("splitk_ws", ctypes.c_void_p), ("splitk_ws_bytes", ctypes.c_int64),
                 ("hd_H", ctypes.c_int32), ("hd_d", ctypes.c_int32), ("hd_T", ctypes.c_int32), ("hd_Tpad", ctypes.c_int32),
                 ("hd_dpad", ctypes.c_int32), ("oq_prescale", ctypes.c_float), ("hd_sum", ctypes.c_void_p),
-                ("gn_part", ctypes.c_void_p)]
+                ("gn_part", ctypes.c_void_p), ("gn_ld", ctypes.c_int64)]
+
+
+class RawSeg(ctypes.Structure):
+    _fields_ = [("c0", ctypes.c_int32), ("clen", ctypes.c_int32), ("oc0", ctypes.c_int32),
+                ("qmin", ctypes.c_int32), ("qmax", ctypes.c_int32), ("off", ctypes.c_int32), ("qparams", ctypes.c_void_p)]
+
+
+class RawQuant(ctypes.Structure):
+    _fields_ = [("out", ctypes.c_void_p), ("ldo", ctypes.c_int64), ("nseg", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("seg", RawSeg * 2)]
 
 
 EPI_LINEAR, EPI_GEGLU_I8, EPI_HEADS_I8, EPI_HEADS_T_I8 = 0, 1, 2, 3
@@ -82,7 +92,7 @@ def load():
     lib.qd_conv2d_i8_splitk_ws_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.qd_conv2d_i8_splitk_ws_bytes.restype = ctypes.c_int64
     lib.qd_groupnorm_silu_quant.argtypes = [vp, i32, i64, i64, i32, i64, i32, f32, vp, vp, i32, vp, i32, i32, i32, vp,
-                                            i64, vp, i64, vp, vp, i32, vp]
+                                            i64, vp, i64, vp, vp, i32, i64, ctypes.POINTER(RawQuant), vp]
     lib.qd_layernorm_quant.argtypes = [vp, i32, i64, i32, i64, f32, vp, vp, i32, ctypes.POINTER(vp),
                                        ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32),
                                        ctypes.POINTER(vp), i64, vp]
@@ -94,7 +104,7 @@ def load():
     lib.qd_temb_mlp.argtypes = [vp, i64, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i64, vp]
     lib.qd_bmm_qk_i8.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i64, i64, vp]
     lib.qd_bmm_pv_i8.argtypes = [vp, i64, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i64, i64, vp]
-    if lib.qd_abi_version() != 10:
+    if lib.qd_abi_version() != 11:
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -261,6 +271,8 @@ def _conv_desc(c):
     else:
         d.out_dtype = _dtype(c.out) if c.out is not None else F32
     d.gn_part = _ptr(c.gn_part, "gn_part")
+    if c.gn_part is not None:
+        d.gn_ld = part_ld(c.gn_part)
     d.nseg = len(c.segs)
     for i, s in enumerate(c.segs):
         g = d.seg[i]
@@ -274,14 +286,46 @@ def groupnorm_ws_bytes(B, C, S):
     return int(load().qd_groupnorm_ws_bytes(B, C, S))
 
 
+def part_ld(part):
+    """Channels per chunk row of a first-level GroupNorm statistics buffer [B][nchunk][C][2] — C for a buffer of its own,
+    more for a column range of a wider one (the two halves of a skip concatenation share one buffer: engine.CatSlot)."""
+    B, n, C, two = part.shape
+    ld2 = part.stride(1) if n > 1 else (part.stride(0) // max(n, 1) if B > 1 else 2 * C)
+    if (two != 2 or part.stride(3) != 1 or part.stride(2) != 2 or ld2 % 2 or ld2 < 2 * C
+            or (B > 1 and part.stride(0) != n * ld2)):
+        raise HipEngineError(f"GroupNorm statistics buffer has an unsupported layout: shape {tuple(part.shape)} strides {part.stride()}")
+    return ld2 // 2
+
+
+def raw_quant_desc(raw):
+    """raw: None or dict(out=int8 rows [M][ldo], segs=[dict(c0, clen, oc0, qparams, grid), ...]) -> (RawQuant | None, keepalive)."""
+    if raw is None:
+        return None, None
+    r = RawQuant()
+    r.out, r.ldo, r.nseg = _ptr(raw["out"], "raw out"), raw["out"].stride(0), len(raw["segs"])
+    keep = []
+    for i, sg in enumerate(raw["segs"]):
+        qp = _qp(sg["qparams"])
+        keep.append(qp)
+        g = r.seg[i]
+        g.c0, g.clen, g.oc0 = sg["c0"], sg["clen"], sg["oc0"]
+        g.qmin, g.qmax, g.off = sg["grid"].qmin, sg["grid"].qmax, sg["grid"].off
+        g.qparams = _ptr(qp, "raw qparams")
+    return r, keep
+
+
 def groupnorm_silu_quant(x, B, S, C, ldx, groups, eps, gamma, beta, silu, qparams, grid, out, ldo, ws, yout=None, ldy=0,
-                         part=None):
-    """part: optional [B][nchunk][C][2] fp32 first-level statistics written by the producer of x (ConvCall.gn_part)."""
+                         part=None, raw=None):
+    """part: optional [B][nchunk][C][2] fp32 first-level statistics written by the producer of x (ConvCall.gn_part);
+    raw: optional second output, the un-normalised input quantised for the residual block's 1x1 skip connection
+    (include/qdiff_hip.h qd_raw_quant)."""
     g = grid or Grid(0, 0, 0)
+    rq, keep = raw_quant_desc(raw)
     _check(load().qd_groupnorm_silu_quant(_ptr(x), _dtype(x), B, S, C, ldx, groups, float(eps), _ptr(gamma), _ptr(beta),
                                           1 if silu else 0, _ptr(_qp(qparams)), g.qmin, g.qmax, g.off, _ptr(out), ldo,
                                           _ptr(yout), ldy, _ptr(ws), _ptr(part), part.shape[1] if part is not None else 0,
-                                          _stream()), "qd_groupnorm_silu_quant")
+                                          part_ld(part) if part is not None else 0,
+                                          ctypes.byref(rq) if rq is not None else None, _stream()), "qd_groupnorm_silu_quant")
 
 
 def layernorm_quant(x, M, C, ldx, eps, gamma, beta, qparams_list, grids, outs, ldo):

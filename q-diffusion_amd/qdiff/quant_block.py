@@ -30,13 +30,18 @@ logger = logging.getLogger(__name__)
 # helpers
 # ------------------------------------------------------------------------------------------------
 def _nhwc_rows(x):
-    """[B,C,H,W] (any strides) -> channels-last rows view [B*H*W, C]."""
+    """[B,C,H,W] channels-last (possibly a column range of wider rows: row stride ld >= C) -> rows view [B*H*W, C] with
+    stride (ld, 1); any other layout is copied to channels-last first."""
     B, C, H, W = x.shape
-    if x.stride(1) != 1 or x.stride(3) != C or x.stride(2) != W * C or x.stride(0) != H * W * C:
+    ld = x.stride(3) if W > 1 else (x.stride(2) if H > 1 else (x.stride(0) if B > 1 else C))
+    ok = (ld >= C and (C == 1 or x.stride(1) == 1) and (W == 1 or x.stride(3) == ld) and (H == 1 or x.stride(2) == W * ld)
+          and (B == 1 or x.stride(0) == H * W * ld))
+    if not ok:
         x = x.contiguous(memory_format=torch.channels_last)
-        if x.stride(1) != 1:  # degenerate shapes where channels_last == contiguous
+        if x.stride(1) != 1 and C > 1:  # degenerate shapes where channels_last == contiguous
             x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
-    rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+        ld = C
+    rows = x.as_strided((B * H * W, C), (ld, 1), x.storage_offset())
     _carry_gn_part(x, rows)
     return rows
 
@@ -54,13 +59,41 @@ def _rows_to_nchw(rows, B, H, W):
     return _carry_gn_part(rows, rows.view(B, H, W, rows.shape[1]).permute(0, 3, 1, 2))
 
 
+def _adjacent(a, b, dim, unit):
+    """`a` and `b` are views of ONE buffer that differ only in a column range along `dim` (element stride `unit`), `b`
+    starting where `a` ends: their concatenation along `dim` is the view returned here (None otherwise)."""
+    if (a.dtype != b.dtype or a.device != b.device or a.dim() != b.dim() or a.stride() != b.stride() or a.stride(dim) != unit
+            or any(a.shape[i] != b.shape[i] for i in range(a.dim()) if i != dim)
+            or a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr()
+            or b.storage_offset() != a.storage_offset() + a.shape[dim] * unit):
+        return None
+    shape = list(a.shape)
+    shape[dim] += b.shape[dim]
+    # the rows must be wide enough to hold both halves (true by construction for engine.CatSlot buffers)
+    row = min((a.stride(i) for i in range(a.dim()) if i != dim and a.shape[i] > 1 and a.stride(i) > unit), default=None)
+    if row is not None and row < shape[dim] * unit:
+        return None
+    return a.as_strided(shape, a.stride(), a.storage_offset())
+
+
 def cat_channels(a, b):
-    """torch.cat([a, b], dim=1) of two NCHW activations that keeps the producers' GroupNorm statistics."""
-    out = torch.cat([a, b], dim=1)
+    """torch.cat([a, b], dim=1) of two NCHW activations that keeps the producers' GroupNorm statistics.  When both
+    producers wrote into the two halves of one planned buffer (engine.CatSlot) the result is a view: no copy."""
+    out = _adjacent(a, b, 1, 1)
+    if out is None:
+        out = torch.cat([a, b], dim=1)
     pa, pb = getattr(a, "qd_gn_part", None), getattr(b, "qd_gn_part", None)
     if pa is not None and pb is not None and pa.shape[0] * pa.shape[1] == pb.shape[0] * pb.shape[1]:
         n = pa.shape[0] * pa.shape[1]
-        out.qd_gn_part = torch.cat([pa.reshape(1, n, -1, 2), pb.reshape(1, n, -1, 2)], dim=2)
+        if pa.shape[:2] != pb.shape[:2]:
+            try:
+                pb = pb.view(pa.shape[0], pa.shape[1], pb.shape[2], 2)
+            except RuntimeError:
+                pb = pb.reshape(pa.shape[0], pa.shape[1], pb.shape[2], 2)
+        part = _adjacent(pa, pb, 2, 2)
+        if part is None:
+            part = torch.cat([pa.reshape(1, n, -1, 2), pb.reshape(1, n, -1, 2)], dim=2)
+        out.qd_gn_part = part
     return out
 
 
@@ -83,13 +116,16 @@ def _aq_ready(*quantizers):
     return all(q.inited and not q.running_stat for q in quantizers)
 
 
-def _gn_silu_to(conv, rows, B, S, C, gn, silu=True):
-    """GroupNorm(+SiLU) -> int8 rows for `conv`; initialises conv's act quantiser on first use."""
+def _gn_silu_to(conv, rows, B, S, C, gn, silu=True, raw_plan=None):
+    """GroupNorm(+SiLU) -> int8 rows for `conv`; initialises conv's act quantiser on first use.
+    raw_plan: also return the int8 rows of a 1x1 consumer of the un-normalised `rows` (the skip connection), quantised
+    in the same pass."""
     if not conv.act_quantizer.inited:
         y = F.group_norm(rows.view(B, S, C).permute(0, 2, 1).float(), gn.num_groups, gn.weight, gn.bias, gn.eps)
         conv._init_act_quantizers(F.silu(y) if silu else y)
-    xq, _ = engine.groupnorm_silu_quant(rows, B, S, C, gn, silu, plan=conv.conv_plan(), part=getattr(rows, "qd_gn_part", None))
-    return xq
+    res = engine.groupnorm_silu_quant(rows, B, S, C, gn, silu, plan=conv.conv_plan(), part=getattr(rows, "qd_gn_part", None),
+                                      raw_plan=raw_plan)
+    return (res[0], res[2]) if raw_plan is not None else res[0]
 
 
 def _ln_to(consumers, rows, M, C, ln):
@@ -101,13 +137,13 @@ def _ln_to(consumers, rows, M, C, ln):
     return engine.layernorm_quant(rows, M, C, ln, [m.conv_plan() for m in consumers])
 
 
-def _linear_rows(lin, rows, residual=None, gn_stats=False):
+def _linear_rows(lin, rows, residual=None, gn_stats=False, slot=None):
     """QuantModule linear on float rows [M,K] -> [M,N] (quantise + integer GEMM)."""
     lin._init_act_quantizers(rows)
     plan = lin.conv_plan()
     M, K = rows.shape
     xq = engine.quantize_rows(rows, plan, 1, K, M, (0, rows.stride(1), rows.stride(0)))
-    return engine.conv_forward(plan, xq, 1, 1, M, 1, M, residual=residual, gn_stats=gn_stats)
+    return engine.conv_forward(plan, xq, 1, 1, M, 1, M, residual=residual, gn_stats=gn_stats, slot=slot)
 
 
 # A/B knob for measurements only (tools/r02_ab.sh): "0" evaluates the embedding projections layer by layer
@@ -166,6 +202,8 @@ class EmbGroup:
 
 
 _CTX_BRANCH = os.environ.get("QDIFF_CTX_BRANCH", "1") != "0"     # A/B knob for measurements only
+_FUSE_SKIP_QUANT = os.environ.get("QDIFF_FUSE_SKIP_QUANT", "1") != "0"     # A/B knob: skip-connection rows from the GroupNorm pass
+CAT_SLOTS = os.environ.get("QDIFF_CAT_SLOTS", "1") != "0"         # A/B knob: planned skip-concatenation buffers (engine.CatSlot)
 
 
 class ContextKV:
@@ -344,20 +382,23 @@ class QuantResBlock(BaseQuantBlock, ldm_unet.TimestepBlock):
                      "skip_connection"):
             setattr(self, name, getattr(res, name))
 
-    def forward(self, x, emb=None, split=0):
+    qd_takes_out_slot = True
+
+    def forward(self, x, emb=None, split=0, out_slot=None):
+        """out_slot (engine-internal, optional): engine.CatSlot side that receives the block's output."""
         # the split argument is only forwarded until the skip connection has recorded it (reference :75-81)
         if split != 0 and self.skip_connection.split == 0:
-            return self._forward(x, emb, split)
-        return self._forward(x, emb)
+            return self._forward(x, emb, split, out_slot)
+        return self._forward(x, emb, 0, out_slot)
 
-    def _forward(self, x, emb, split=0):
+    def _forward(self, x, emb, split=0, out_slot=None):
         if emb is None:
             x, emb = x
         assert x.shape[2] == x.shape[3]
         conv1, conv2 = self.in_layers[-1], self.out_layers[-1]
         if (not self.updown and not self.use_scale_shift_norm and _int_mode(conv1, conv2, self.emb_layers[-1])
                 and conv1.split == 0 and conv2.split == 0):
-            return self._forward_int(x, emb, split, conv1, conv2)
+            return self._forward_int(x, emb, split, conv1, conv2, out_slot)
         return self._forward_sim(x, emb, split)
 
     def _forward_sim(self, x, emb, split=0):
@@ -379,11 +420,28 @@ class QuantResBlock(BaseQuantBlock, ldm_unet.TimestepBlock):
             return self.skip_connection(x, split=split) + h
         return self.skip_connection(x) + h
 
-    def _forward_int(self, x, emb, split, conv1, conv2):
+    def _skip_plan(self, split, C):
+        """ConvPlan of the 1x1 skip connection when its int8 input rows can be produced by the GroupNorm pass that
+        already reads x (engine.groupnorm_silu_quant(raw_plan=...)), else None (the module quantises x itself)."""
+        sk = self.skip_connection
+        if not (_FUSE_SKIP_QUANT and isinstance(sk, QuantModule) and sk.kind == 'conv2d' and _int_mode(sk)):
+            return None
+        if split != 0 and sk.split == 0:
+            return None                                   # the first call records the split: module path
+        if not all(q.inited for q in sk._act_quantizers()) or sk._geometry() != (1, 1, 1, 0):
+            return None
+        plan = sk.conv_plan()
+        return plan if engine.raw_quant_segs(plan, C) is not None else None
+
+    def _forward_int(self, x, emb, split, conv1, conv2, out_slot=None):
         B, C, H, W = x.shape
         S = H * W
         rows = _nhwc_rows(x)
-        xq = _gn_silu_to(conv1, rows, B, S, C, self.in_layers[0])
+        skp = None if isinstance(self.skip_connection, nn.Identity) else self._skip_plan(split, C)
+        if skp is not None:
+            xq, skq = _gn_silu_to(conv1, rows, B, S, C, self.in_layers[0], raw_plan=skp)
+        else:
+            xq = _gn_silu_to(conv1, rows, B, S, C, self.in_layers[0])
         grp = self.__dict__.get("_emb_group")
         e = grp.get(self, emb) if grp is not None else None           # all blocks' projections in one launch (K6)
         if e is None:
@@ -392,10 +450,12 @@ class QuantResBlock(BaseQuantBlock, ldm_unet.TimestepBlock):
         hq = _gn_silu_to(conv2, h, B, S, self.out_channels, self.out_layers[0])
         if isinstance(self.skip_connection, nn.Identity):
             res = rows
+        elif skp is not None:
+            res = self.skip_connection.forward_codes(skq, B, H, W)
         else:
             sk = self.skip_connection(x, split=split) if split != 0 else self.skip_connection(x)
             res = _nhwc_rows(sk)
-        out = conv2.forward_codes(hq, B, H, W, residual=res, gn_stats=True)     # the next block normalises this
+        out = conv2.forward_codes(hq, B, H, W, residual=res, gn_stats=True, slot=out_slot)   # the next block normalises this
         return _rows_to_nchw(out, B, H, W)
 
 
@@ -480,8 +540,10 @@ class QuantAttentionBlock(BaseQuantBlock, _AttnQuant):
             if isinstance(m, (QuantQKMatMul, QuantSMVMatMul)):
                 m.set_quant_state(weight_quant, act_quant)
 
-    def forward(self, x):
-        return self._forward(x)
+    qd_takes_out_slot = True
+
+    def forward(self, x, out_slot=None):
+        return self._forward(x, out_slot)
 
     def _fusable(self):
         att = self.attention
@@ -490,15 +552,15 @@ class QuantAttentionBlock(BaseQuantBlock, _AttnQuant):
                 and smv.use_act_quant and _int_mode(self.qkv, self.proj_out)
                 and _aq_ready(qk.act_quantizer_q, qk.act_quantizer_k, smv.act_quantizer_v, smv.act_quantizer_w))
 
-    def _forward(self, x):
+    def _forward(self, x, out_slot=None):
         b, c, *spatial = x.shape
         if x.dim() == 4 and self._fusable():
-            return self._forward_int(x)
+            return self._forward_int(x, out_slot)
         xf = x.reshape(b, c, -1)
         h = self.proj_out(self.attention(self.qkv(self.norm(xf))))
         return (xf + h).reshape(b, c, *spatial)
 
-    def _forward_int(self, x):
+    def _forward_int(self, x, out_slot=None):
         B, C, H, W = x.shape
         T, nh = H * W, self.num_heads
         d = C // nh
@@ -514,17 +576,17 @@ class QuantAttentionBlock(BaseQuantBlock, _AttnQuant):
         ld = qkv.stride(0)
         strides = (T * ld, ld, 3 * d, 1)
         att = engine.attention(ap, qkv, qkv[:, d:], qkv[:, 2 * d:], B, T, T, nh, d, strides, strides, strides)
-        out = _linear_like_conv1d(self.proj_out, att, B, T, residual=rows)
+        out = _linear_like_conv1d(self.proj_out, att, B, T, residual=rows, gn_stats=True, slot=out_slot)
         return _rows_to_nchw(out, B, H, W)
 
 
-def _linear_like_conv1d(mod, rows, B, T, residual=None):
+def _linear_like_conv1d(mod, rows, B, T, residual=None, gn_stats=False, slot=None):
     """conv1d(k=1) QuantModule applied to token rows [B*T, C]."""
     mod._init_act_quantizers(rows.view(B, T, -1).permute(0, 2, 1))
     plan = mod.conv_plan()
     M, K = rows.shape
     xq = engine.quantize_rows(rows, plan, 1, K, M, (0, rows.stride(1), rows.stride(0)))
-    return engine.conv_forward(plan, xq, B, 1, T, 1, T, residual=residual)
+    return engine.conv_forward(plan, xq, B, 1, T, 1, T, residual=residual, gn_stats=gn_stats, slot=slot)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -686,11 +748,13 @@ class QuantResnetBlock(BaseQuantBlock):
             else:
                 self.nin_shortcut = res.nin_shortcut
 
-    def forward(self, x, temb=None, split=0):
+    qd_takes_out_slot = True
+
+    def forward(self, x, temb=None, split=0, out_slot=None):
         if temb is None:
             x, temb = x
         if _int_mode(self.conv1, self.conv2, self.temb_proj):
-            return self._forward_int(x, temb, split)
+            return self._forward_int(x, temb, split, out_slot)
         h = self.conv1(ddim_unet.nonlinearity(self.norm1(x)))
         h = h + self.temb_proj(ddim_unet.nonlinearity(temb))[:, :, None, None]
         h = self.conv2(self.dropout(ddim_unet.nonlinearity(self.norm2(h))))
@@ -698,23 +762,41 @@ class QuantResnetBlock(BaseQuantBlock):
             x = self.conv_shortcut(x) if self.use_conv_shortcut else self.nin_shortcut(x, split=split)
         return x + h
 
-    def _forward_int(self, x, temb, split):
+    def _skip_plan(self, split, C):
+        """see QuantResBlock._skip_plan: the 1x1 `nin_shortcut` reads the tensor norm1 normalises"""
+        if self.in_channels == self.out_channels or self.use_conv_shortcut:
+            return None
+        sk = self.nin_shortcut
+        if not (_FUSE_SKIP_QUANT and isinstance(sk, QuantModule) and sk.kind == 'conv2d' and _int_mode(sk)):
+            return None
+        if (split != 0 and sk.split != split) or not all(q.inited for q in sk._act_quantizers()) or sk._geometry() != (1, 1, 1, 0):
+            return None
+        plan = sk.conv_plan()
+        return plan if engine.raw_quant_segs(plan, C) is not None else None
+
+    def _forward_int(self, x, temb, split, out_slot=None):
         B, C, H, W = x.shape
         S = H * W
         rows = _nhwc_rows(x)
-        xq = _gn_silu_to(self.conv1, rows, B, S, C, self.norm1)
+        skp = self._skip_plan(split, C)
+        if skp is not None:
+            xq, skq = _gn_silu_to(self.conv1, rows, B, S, C, self.norm1, raw_plan=skp)
+        else:
+            xq = _gn_silu_to(self.conv1, rows, B, S, C, self.norm1)
         grp = self.__dict__.get("_emb_group")
         e = grp.get(self, temb) if grp is not None else None
         if e is None:
             e = self.temb_proj(ddim_unet.nonlinearity(temb)).float().contiguous()
-        h = self.conv1.forward_codes(xq, B, H, W, rowbias=e)
+        h = self.conv1.forward_codes(xq, B, H, W, rowbias=e, gn_stats=True)
         hq = _gn_silu_to(self.conv2, h, B, S, self.out_channels, self.norm2)
-        if self.in_channels != self.out_channels:
+        if skp is not None:
+            res = self.nin_shortcut.forward_codes(skq, B, H, W)
+        elif self.in_channels != self.out_channels:
             sk = self.conv_shortcut(x) if self.use_conv_shortcut else self.nin_shortcut(x, split=split)
             res = _nhwc_rows(sk)
         else:
             res = rows
-        out = self.conv2.forward_codes(hq, B, H, W, residual=res)
+        out = self.conv2.forward_codes(hq, B, H, W, residual=res, gn_stats=True, slot=out_slot)
         return _rows_to_nchw(out, B, H, W)
 
 
@@ -730,10 +812,12 @@ class QuantAttnBlock(BaseQuantBlock, _AttnQuant):
         params_w['n_bits'] = sm_abit
         self.act_quantizer_w = UniformAffineQuantizer(**params_w)
 
-    def forward(self, x):
+    qd_takes_out_slot = True
+
+    def forward(self, x, out_slot=None):
         if (self.use_act_quant and _int_mode(self.q, self.k, self.v, self.proj_out)
                 and _aq_ready(self.act_quantizer_q, self.act_quantizer_k, self.act_quantizer_v, self.act_quantizer_w)):
-            return self._forward_int(x)
+            return self._forward_int(x, out_slot)
         hn = self.norm(x)
         q, k, v = self.q(hn), self.k(hn), self.v(hn)
         b, c, h, w = q.shape
@@ -749,30 +833,31 @@ class QuantAttnBlock(BaseQuantBlock, _AttnQuant):
         out = th.bmm(v, w_).reshape(b, c, h, w)
         return x + self.proj_out(out)
 
-    def _forward_int(self, x):
+    def _forward_int(self, x, out_slot=None):
         B, C, H, W = x.shape
         T = H * W
         rows = _nhwc_rows(x)
         # one GroupNorm, three consumers with their own act quantisers
         ws_plan = None
-        _, y = engine.groupnorm_silu_quant(rows, B, T, C, self.norm, False, plan=ws_plan, want_float=True)
+        _, y = engine.groupnorm_silu_quant(rows, B, T, C, self.norm, False, plan=ws_plan, want_float=True,
+                                           part=getattr(rows, "qd_gn_part", None))
         q = _linear_like_conv2d(self.q, y, B, H, W)
         k = _linear_like_conv2d(self.k, y, B, H, W)
         v = _linear_like_conv2d(self.v, y, B, H, W)
         ap = self._attn_plan(self, int(C) ** (-0.5), 1.0, x.device)
         st = (T * C, C, C, 1)
         o = engine.attention(ap, q, k, v, B, T, T, 1, C, st, st, st)
-        out = _linear_like_conv2d(self.proj_out, o, B, H, W, residual=rows)
+        out = _linear_like_conv2d(self.proj_out, o, B, H, W, residual=rows, gn_stats=True, slot=out_slot)
         return _rows_to_nchw(out, B, H, W)
 
 
-def _linear_like_conv2d(mod, rows, B, H, W, residual=None):
+def _linear_like_conv2d(mod, rows, B, H, W, residual=None, gn_stats=False, slot=None):
     """1x1 Conv2d QuantModule applied to channels-last rows."""
     mod._init_act_quantizers(rows)
     plan = mod.conv_plan()
     M, K = rows.shape
     xq = engine.quantize_rows(rows, plan, 1, K, M, (0, rows.stride(1), rows.stride(0)))
-    return engine.conv_forward(plan, xq, B, H, W, H, W, residual=residual)
+    return engine.conv_forward(plan, xq, B, H, W, H, W, residual=residual, gn_stats=gn_stats, slot=slot)
 
 
 # ------------------------------------------------------------------------------------------------

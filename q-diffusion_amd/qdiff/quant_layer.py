@@ -387,7 +387,7 @@ class QuantModule(nn.Module):
             if q.running_stat:
                 q.act_momentum_update(xs)
 
-    def _forward_int(self, x):
+    def _forward_int(self, x, out_slot=None):
         self._init_act_quantizers(x)
         plan = self.conv_plan()
         if self.kind == 'conv2d':
@@ -398,7 +398,7 @@ class QuantModule(nn.Module):
                 sb, sc, sh, sw = x.stride()
             xq = engine.quantize_rows(x, plan, B, C, H * W, (sb, sc, sw))
             Ho, Wo = engine.conv_out_hw(H, W, plan)
-            out = engine.conv_forward(plan, xq, B, H, W, Ho, Wo, gn_stats=True)   # most conv outputs feed a GroupNorm
+            out = engine.conv_forward(plan, xq, B, H, W, Ho, Wo, gn_stats=True, slot=out_slot)   # most conv outputs feed a GroupNorm
             y = out.view(B, Ho, Wo, plan.Cout).permute(0, 3, 1, 2)
             if hasattr(out, "qd_gn_part"):
                 y.qd_gn_part = out.qd_gn_part
@@ -447,16 +447,21 @@ class QuantModule(nn.Module):
             cache[0] = key
         return cache[1]
 
-    def forward_codes(self, xq, B, H, W, Ho=None, Wo=None, rowbias=None, residual=None, pad_tl=None, gn_stats=False):
-        """Integer path for a producer that already emitted this module's int8 rows (fused blocks)."""
+    def forward_codes(self, xq, B, H, W, Ho=None, Wo=None, rowbias=None, residual=None, pad_tl=None, gn_stats=False, slot=None):
+        """Integer path for a producer that already emitted this module's int8 rows (fused blocks).
+        slot: engine.CatSlot side that receives the output (a planned skip concatenation), see engine.conv_forward."""
         return engine.conv_forward(self.conv_plan(), xq, B, H, W, Ho, Wo, rowbias=rowbias, residual=residual,
-                                   pad_tl=pad_tl, gn_stats=gn_stats)
+                                   pad_tl=pad_tl, gn_stats=gn_stats, slot=slot)
 
     # -- forward ------------------------------------------------------------------------------
-    def forward(self, input: torch.Tensor, split: int = 0):
+    qd_takes_out_slot = True
+
+    def forward(self, input: torch.Tensor, split: int = 0, out_slot=None):
+        """out_slot (engine-internal, optional): destination of the output inside a planned skip-concatenation buffer
+        (engine.CatSlot); honoured on the integer conv2d path only, ignored (plain allocation) everywhere else."""
         self._note_split(split)
         if not torch.is_grad_enabled() and self.int_ready():
-            return self.activation_function(self._forward_int(input))
+            return self.activation_function(self._forward_int(input, out_slot))
         # simulated / floating-point states: (False, *), weights-only, or calibration under autograd
         if not self.disable_act_quant and self.use_act_quant and self.act_quant_mode == 'qdiff':
             parts = [q(xs) for q, xs in zip(self._act_quantizers(), self._input_slices(input))]

@@ -197,8 +197,8 @@ def conv2d_i8(c, acc_out=None):
         return
     c.out[:, :c.Cout] = rows.to(c.out.dtype)
     if getattr(c, "gn_part", None) is not None:                  # first level of GroupNorm statistics, 128-row chunks
-        ch = c.out[:, :c.Cout].float().view(-1, 128, c.Cout)
-        c.gn_part.view(-1, c.Cout, 2).copy_(torch.stack([ch.sum(1), (ch * ch).sum(1)], dim=-1))
+        ch = c.out[:, :c.Cout].float().reshape(-1, 128, c.Cout)
+        c.gn_part.copy_(torch.stack([ch.sum(1), (ch * ch).sum(1)], dim=-1).view(c.gn_part.shape))   # may be a column range (gn_ld)
 
 
 def groupnorm_ws_bytes(B, C, S):
@@ -206,11 +206,16 @@ def groupnorm_ws_bytes(B, C, S):
 
 
 def groupnorm_silu_quant(x, B, S, C, ldx, groups, eps, gamma, beta, silu, qparams, grid, out, ldo, ws, yout=None, ldy=0,
-                         part=None):
-    v = x[:, :C].float().view(B, S, C).permute(0, 2, 1)
+                         part=None, raw=None):
+    v = x[:, :C].float().reshape(B, S, C).permute(0, 2, 1)
+    if raw is not None:
+        # qd_raw_quant: the un-normalised input quantised per channel segment for the 1x1 skip connection
+        for sg in raw["segs"]:
+            xs = x[:, sg["c0"]:sg["c0"] + sg["clen"]].float()
+            raw["out"][:, sg["oc0"]:sg["oc0"] + sg["clen"]] = (_codes(xs, sg["qparams"], sg["grid"]) - sg["grid"].off).to(torch.int8)
     if part is not None:
         # statistics from the producer's partial sums (what the kernel does with part_in), fp64 second level
-        st = part.double().view(B, -1, groups, C // groups, 2).sum(dim=(1, 3))
+        st = part.double().reshape(B, -1, groups, C // groups, 2).sum(dim=(1, 3))
         n = S * (C // groups)
         mean = st[..., 0] / n
         var = (st[..., 1] / n - mean * mean).clamp_min(0)

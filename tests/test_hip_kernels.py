@@ -592,6 +592,73 @@ def test_conv_emits_groupnorm_statistics(cuda, B, C, H, Cout, k):
     assert diff.max().item() <= 1 and (diff > 0).float().mean().item() <= 1e-3
 
 
+@pytest.mark.parametrize("B,H,C1,C2,Cmid", [(2, 16, 320, 160, 320), (1, 32, 640, 320, 160)])
+def test_concatenation_slot_and_raw_quant(cuda, B, H, C1, C2, Cmid):
+    """engine.CatSlot: two convolutions write their outputs and GroupNorm statistics into the two column ranges of one
+    buffer (ldo / gn_ld); the concatenation is a view whose values and statistics equal those of the separately
+    allocated outputs, and GroupNorm over the view — reading strided rows and strided statistics (part_ld) — gives the
+    codes of GroupNorm over the copied concatenation.  qd_raw_quant: the split 1x1 skip connection's int8 rows written
+    by the same pass are bit-identical to qd_quantize_act's."""
+    from qdiff import engine, quant_block as qb
+    g = torch.Generator().manual_seed(71)
+    S = H * H
+    plans, xqs, outs_plain = [], [], []
+    for Cout in (C1, C2):
+        x = F.silu(torch.randn(B, Cmid, H, H, generator=g))
+        w = torch.randn(Cout, Cmid, 3, 3, generator=g) * 0.05
+        d, z = R.uaq_init_scale(x, 8, False, False, "max")
+        plan = engine.build_conv_plan(engine.pack_module_weights(w.to(cuda), [_weight_quantizer(w, 4, True, g)], 0), [_aq(d, z)], 3, 3, 1, 1,
+                                      torch.randn(Cout, generator=g).to(cuda))
+        plans.append(plan)
+        xqs.append(engine.quantize_rows(x.to(cuda), plan, B, Cmid, S, (Cmid * S, S, 1)))
+        outs_plain.append(engine.conv_forward(plan, xqs[-1], B, H, H, gn_stats=True, splitk=False))
+    slot = engine.CatSlot(C1, C2)
+    a = engine.conv_forward(plans[0], xqs[0], B, H, H, gn_stats=True, splitk=False, slot=slot.side(0))
+    b = engine.conv_forward(plans[1], xqs[1], B, H, H, gn_stats=True, splitk=False, slot=slot.side(1))
+    torch.cuda.synchronize()
+    assert a.stride(0) == C1 + C2 and b.stride(0) == C1 + C2 and b.data_ptr() == a.data_ptr() + 4 * C1
+    assert torch.equal(a, outs_plain[0]) and torch.equal(b, outs_plain[1])
+    assert torch.equal(a.qd_gn_part, outs_plain[0].qd_gn_part) and torch.equal(b.qd_gn_part, outs_plain[1].qd_gn_part)
+    cat = qb.cat_channels(qb._rows_to_nchw(a, B, H, H), qb._rows_to_nchw(b, B, H, H))
+    copy = torch.cat([qb._rows_to_nchw(outs_plain[0], B, H, H), qb._rows_to_nchw(outs_plain[1], B, H, H)], dim=1)
+    assert cat.data_ptr() == a.data_ptr() and torch.equal(cat, copy)                   # a view of the slot buffer
+    assert cat.qd_gn_part.data_ptr() == a.qd_gn_part.data_ptr() and cat.qd_gn_part.shape[2] == C1 + C2
+    # consumers of the concatenation: GroupNorm -> conv1's rows, and the split skip connection's rows from the same pass
+    C = C1 + C2
+    gn = torch.nn.GroupNorm(32, C).to(cuda)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C, generator=g)); gn.bias.copy_(torch.randn(C, generator=g))
+    y = F.silu(gn(copy)).cpu()
+    dy, zy = R.uaq_init_scale(y, 8, False, False, "max")
+    w1 = torch.randn(32, C, 1, 1, generator=g) * 0.05
+    plan1 = engine.build_conv_plan(engine.pack_module_weights(w1.to(cuda), [_weight_quantizer(w1, 4, True, g)], 0), [_aq(dy, zy)], 1, 1, 1, 0, None)
+    wsk = torch.randn(64, C, 1, 1, generator=g) * 0.05
+    qs = [_weight_quantizer(wsk[:, :C1], 4, True, g), _weight_quantizer(wsk[:, C1:], 4, True, g)]
+    cc = copy.cpu()
+    aqs = [_aq(*R.uaq_init_scale(cc[:, :C1], 8, False, False, "max")), _aq(*R.uaq_init_scale(cc[:, C1:], 8, False, False, "max"))]
+    plan_sk = engine.build_conv_plan(engine.pack_module_weights(wsk.to(cuda), qs, C1), aqs, 1, 1, 1, 0, None)
+    rows_view, rows_copy = qb._nhwc_rows(cat), qb._nhwc_rows(copy)
+    assert rows_view.stride(0) == C and rows_view.data_ptr() == a.data_ptr()
+    ref_codes, _ = engine.groupnorm_silu_quant(rows_copy, B, S, C, gn, True, plan=plan1)                    # two-pass statistics, copy
+    got_codes, _, got_raw = engine.groupnorm_silu_quant(rows_view, B, S, C, gn, True, plan=plan1, part=rows_view.qd_gn_part,
+                                                        raw_plan=plan_sk)
+    ref_raw = engine.quantize_rows(copy, plan_sk, B, C, S, (C * S, 1, C))
+    torch.cuda.synchronize()
+    diff = (ref_codes.int() - got_codes.int()).abs()
+    assert diff.max().item() <= 1 and (diff > 0).float().mean().item() <= 1e-3
+    assert torch.equal(got_raw, ref_raw)
+    # one side of the slot read on its own (the encoder's next block): strided rows and a strided statistics column range
+    gn2 = torch.nn.GroupNorm(32, C2).to(cuda)
+    y2 = F.silu(gn2(qb._rows_to_nchw(outs_plain[1], B, H, H))).cpu()
+    d2, z2 = R.uaq_init_scale(y2, 8, False, False, "max")
+    w2 = torch.randn(32, C2, 1, 1, generator=g) * 0.05
+    plan2 = engine.build_conv_plan(engine.pack_module_weights(w2.to(cuda), [_weight_quantizer(w2, 4, True, g)], 0), [_aq(d2, z2)], 1, 1, 1, 0, None)
+    r1, _ = engine.groupnorm_silu_quant(outs_plain[1], B, S, C2, gn2, True, plan=plan2, part=outs_plain[1].qd_gn_part)
+    r2, _ = engine.groupnorm_silu_quant(b, B, S, C2, gn2, True, plan=plan2, part=b.qd_gn_part)
+    torch.cuda.synchronize()
+    assert torch.equal(r1, r2)
+
+
 def test_linear_residual_to_int8_rows_matches_unfused(cuda):
     """QD_EPI_HEADS_I8 with one full-width head + fp32 residual == fp32 Linear(+residual) followed by K1."""
     from qdiff import engine

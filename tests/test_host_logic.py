@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     from qdiff import hip
     assert sorted(hip.EXPORTS) == declared
     lib.qd_abi_version.restype = ctypes.c_int
-    assert lib.qd_abi_version() == 10
+    assert lib.qd_abi_version() == 11
     assert lib.qd_device_ok() in (0, 1)                  # no compute calls without a GPU
 
 
@@ -41,7 +41,8 @@ def test_conv_desc_layout_matches_header():
     """ctypes mirror of qd_conv_desc / qd_conv_seg has the C layout (sizes from the header's field list)."""
     from qdiff import hip
     assert ctypes.sizeof(hip.ConvSeg) == 4 * 4 + 6 * 8
-    assert ctypes.sizeof(hip.ConvDesc) == 6 * 8 + 5 * 8 + 16 * 4 + 2 * ctypes.sizeof(hip.ConvSeg) + 8 + 4 * 4 + 16 + 5 * 4 + 4 + 8 + 8
+    assert ctypes.sizeof(hip.ConvDesc) == 6 * 8 + 5 * 8 + 16 * 4 + 2 * ctypes.sizeof(hip.ConvSeg) + 8 + 4 * 4 + 16 + 5 * 4 + 4 + 8 + 8 + 8
+    assert ctypes.sizeof(hip.RawSeg) == 6 * 4 + 8 and ctypes.sizeof(hip.RawQuant) == 8 + 8 + 4 + 4 + 2 * ctypes.sizeof(hip.RawSeg)
 
 
 def test_conv_desc_offsets_match_the_compiled_header(tmp_path):
@@ -58,6 +59,11 @@ def test_conv_desc_offsets_match_the_compiled_header(tmp_path):
         lines.append(f'printf("seg.{name} %zu\\n", offsetof(qd_conv_seg, {name}));')
     for name, _ in hip.ConvDesc._fields_:
         lines.append(f'printf("desc.{name} %zu\\n", offsetof(qd_conv_desc, {name}));')
+    lines += ['printf("qd_raw_seg %zu\\n", sizeof(qd_raw_seg));', 'printf("qd_raw_quant %zu\\n", sizeof(qd_raw_quant));']
+    for name, _ in hip.RawSeg._fields_:
+        lines.append(f'printf("rseg.{name} %zu\\n", offsetof(qd_raw_seg, {name}));')
+    for name, _ in hip.RawQuant._fields_:
+        lines.append(f'printf("raw.{name} %zu\\n", offsetof(qd_raw_quant, {name}));')
     lines.append('return 0;}')
     src = tmp_path / "layout.c"
     src.write_text("\n".join(lines))
@@ -70,6 +76,11 @@ def test_conv_desc_offsets_match_the_compiled_header(tmp_path):
         assert int(got[f"seg.{name}"]) == getattr(hip.ConvSeg, name).offset, name
     for name, _ in hip.ConvDesc._fields_:
         assert int(got[f"desc.{name}"]) == getattr(hip.ConvDesc, name).offset, name
+    assert int(got["qd_raw_seg"]) == ctypes.sizeof(hip.RawSeg) and int(got["qd_raw_quant"]) == ctypes.sizeof(hip.RawQuant)
+    for name, _ in hip.RawSeg._fields_:
+        assert int(got[f"rseg.{name}"]) == getattr(hip.RawSeg, name).offset, name
+    for name, _ in hip.RawQuant._fields_:
+        assert int(got[f"raw.{name}"]) == getattr(hip.RawQuant, name).offset, name
 
 
 def test_integer_path_refuses_to_run_on_the_host():
@@ -382,3 +393,52 @@ def test_running_stat_updates_match_the_simulation_path(emu, name):
                 if isinstance(m, UniformAffineQuantizer) and m.inited and m.leaf_param and m.delta.shape == torch.Size([])
                 and abs(float(m.delta) - float(m0.delta)) > 5e-3 * float(m0.delta))
     assert moved > 20
+
+
+@pytest.mark.parametrize("name", ["cifar_tiny", "ldm_tiny", "sd_tiny"])
+def test_planned_concatenation_is_a_view_and_changes_nothing(emu, name, monkeypatch):
+    """Skip concatenations (openaimodel.py:776, ddim diffusion.py:340) planned through engine.CatSlot + the skip
+    connection's int8 rows taken from the GroupNorm pass (qd_raw_quant): from the second evaluation on no `cat` copy runs
+    any more, and the output is that of the copying path bit for bit."""
+    from qdiff import quant_block as qb
+    fx = load_fixture(f"model_{name}.pt")
+    qnn = _resume_cpu(fx)
+    x, t, c = fixture_inputs(fx, "test")
+    args = (x, t) + ((c,) if c is not None else ())
+    with torch.no_grad():
+        y0 = qnn(*args)                               # first evaluation: records the channel plan, concatenates by copy
+    calls = {"cat": 0, "view": 0, "raw": 0}
+    real_cat, real_adj, real_gn = torch.cat, qb._adjacent, qb.engine.groupnorm_silu_quant
+
+    def counting_cat(ts, dim=0, **kw):
+        if dim == 1 and len(ts) == 2 and ts[0].dim() == 4 and ts[0].is_floating_point():
+            calls["cat"] += 1
+        return real_cat(ts, dim=dim, **kw)
+
+    def counting_adj(a, b, dim, unit):
+        out = real_adj(a, b, dim, unit)
+        if out is not None and dim == 1:
+            calls["view"] += 1
+        return out
+
+    def counting_gn(*a, **kw):
+        if kw.get("raw_plan") is not None:
+            calls["raw"] += 1
+        return real_gn(*a, **kw)
+
+    monkeypatch.setattr(torch, "cat", counting_cat)
+    monkeypatch.setattr(qb, "_adjacent", counting_adj)
+    monkeypatch.setattr(qb.engine, "groupnorm_silu_quant", counting_gn)
+    with torch.no_grad():
+        y1 = qnn(*args)                               # planned: views
+    n_cat = len(qnn.model.__dict__["_cat_plan"])
+    assert calls["view"] == n_cat and calls["cat"] == 0, calls
+    assert calls["raw"] > 0, "no skip connection took its rows from the GroupNorm pass"
+    assert torch.equal(y0, y1)
+    monkeypatch.setattr(qb, "CAT_SLOTS", False)
+    monkeypatch.setattr(qb, "_FUSE_SKIP_QUANT", False)
+    calls.update(cat=0, view=0, raw=0)
+    with torch.no_grad():
+        y2 = qnn(*args)
+    assert calls["cat"] == n_cat and calls["view"] == 0 and calls["raw"] == 0, calls
+    assert torch.equal(y1, y2)
