@@ -333,16 +333,21 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
         }
     const unsigned b_off = A_BYTES + wn * NT * TB + (fhalf * 32 + frow) * (WB * 2);   // + ks*(TB/2) + j*TB
 
-    float pr_scale = 0.f, pr_bias = 0.f;
-    int   pr_zc = 0, pr_zw = 0;
+    constexpr int NPR = (BN + 255) / 256;              // per-channel constants fetched by each thread (BN may exceed the block size)
+    float pr_scale[NPR], pr_bias[NPR];
+    int   pr_zc[NPR], pr_zw[NPR];
     {
         const SegD& sgl = p.seg[p.nseg - 1];
-        const int pn = n0 + (int)threadIdx.x;
-        if ((int)threadIdx.x < BN && pn < p.Cout) {
-            pr_scale = sgl.scale[pn];
-            if (sgl.zc) pr_zc = sgl.zc[pn];
-            if (sgl.zw) pr_zw = sgl.zw[pn];
-            if (p.bias) pr_bias = p.bias[pn];
+#pragma unroll
+        for (int u = 0; u < NPR; ++u) {
+            const int cl = (int)threadIdx.x + 256 * u, pn = n0 + cl;
+            pr_scale[u] = 0.f; pr_bias[u] = 0.f; pr_zc[u] = 0; pr_zw[u] = 0;
+            if (cl < BN && pn < p.Cout) {
+                pr_scale[u] = sgl.scale[pn];
+                if (sgl.zc) pr_zc[u] = sgl.zc[pn];
+                if (sgl.zw) pr_zw[u] = sgl.zw[pn];
+                if (p.bias) pr_bias[u] = p.bias[pn];
+            }
         }
     }
 
@@ -353,11 +358,15 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
 #pragma unroll
     for (int d = 0; d < PER; ++d) issue_one(STAGE, d);
     advance();
-    if ((int)threadIdx.x < BN) {                       // visible to every wave after the main loop's barriers
-        sScale[threadIdx.x] = pr_scale;
-        sZc[threadIdx.x]    = pr_zc;
-        sZw[threadIdx.x]    = pr_zw;
-        sBias[threadIdx.x]  = pr_bias;
+#pragma unroll
+    for (int u = 0; u < NPR; ++u) {                    // visible to every wave after the main loop's barriers
+        const int cl = (int)threadIdx.x + 256 * u;
+        if (cl < BN) {
+            sScale[cl] = pr_scale[u];
+            sZc[cl]    = pr_zc[u];
+            sZw[cl]    = pr_zw[u];
+            sBias[cl]  = pr_bias[u];
+        }
     }
 
     auto flush_segment0 = [&]() __attribute__((always_inline)) {
@@ -779,9 +788,9 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
     }
     if (gn) {
         __syncthreads();
-        const int c = threadIdx.x;
-        if (c < BN && n0 + c < p.Cout) {
-            constexpr int WPC = 4 / MT;                       // waves (along M) per 128-row chunk
+        for (int c = threadIdx.x; c < BN; c += 256)
+        if (n0 + c < p.Cout) {
+            constexpr int WPC = MT >= 4 ? 1 : 4 / MT;         // waves (along M) per 128-row chunk
             const int wnc = c / WCOLS, cw = c - wnc * WCOLS;
 #pragma unroll
             for (int ch = 0; ch < BM / 128; ++ch) {
@@ -941,7 +950,8 @@ int dispatch(ConvD& k, bool split, int out, hipStream_t st, int nsplit = 1) {
         hipLaunchKernelGGL((igemm_kernel<MT, NT, WM, WN, SP, O, WB>), grid, block, 0, st, k);       \
         return 0;                                                                                   \
     }
-    QD_CASE(false, O_F32) QD_CASE(false, O_F16)
+    QD_CASE(false, O_F32)
+    if constexpr (WM == 4) { QD_CASE(false, O_F16) }
     if constexpr (MT == 1 && WM == 4) { QD_CASE(false, O_I32) QD_CASE(true, O_F32) QD_CASE(true, O_F16) QD_CASE(false, O_PART) }
     if constexpr (WB == 4 && WM == 4) { QD_CASE(false, O_HROWS) QD_CASE(false, O_HTR) }
     if constexpr (NT == 4 && WB == 4 && WM == 4) { QD_CASE(false, O_GEGLU) }
@@ -1080,6 +1090,9 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
     static const int force_mt = getenv("QD_TILE_MT") ? atoi(getenv("QD_TILE_MT")) : 0;       // tuning knob: 1 / 2, 0 = heuristic
     static const int force_gmt = getenv("QD_GEGLU_MT") ? atoi(getenv("QD_GEGLU_MT")) : 0;
     static const int mt2_mink = getenv("QD_MT2_MINK") ? atoi(getenv("QD_MT2_MINK")) : 0;
+    static const int fat_tile = getenv("QD_FAT_TILE") ? atoi(getenv("QD_FAT_TILE")) : 0;      // measurement knob (0 = off)
+    static const int fat_mink = getenv("QD_FAT_MINK") ? atoi(getenv("QD_FAT_MINK")) : 1280;
+    static const int fat_minblk = getenv("QD_FAT_MINBLK") ? atoi(getenv("QD_FAT_MINBLK")) : 200;
     const long Ktot = (long)k.taps * d->seg[0].clen;
     const bool linear_out = out == O_F32 || out == O_F16;
     // 256-row tiles (two 32-row tiles per wave: half the B-fragment reads and nibble unpacks per MFMA) whenever they still
@@ -1099,6 +1112,13 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
     } else if (geglu) {
         if (force_gmt == 2) rc = dispatch<2, 4, 4, 1>(k, split, out, st);
         else rc = dispatch<1, 4, 4, 1>(k, split, out, st);
+    } else if (fat_tile && N % 320 == 0 && out == O_F32 && !split && Ktot >= fat_mink && blocks(256, 320) >= fat_minblk) {
+        // 2 x 2 waves of 128 x 160: one 256 x 320 block per CU, one wave per SIMD with the whole register file (512 VGPRs).
+        // Per MFMA half the B-fragment reads / nibble unpacks of the 64-row wave tile, and 38 % fewer L2 -> LDS bytes per
+        // flop than the 256 x 160 block (profiles/r02_igemm_kstep_ablation.md, consequence 1).
+        rc = dispatch<4, 5, 2, 2>(k, split, out, st);
+    } else if (fat_tile >= 2 && N % 320 == 0 && out == O_F32 && !split && Ktot >= fat_mink && blocks(128, 320) >= fat_minblk) {
+        rc = dispatch<2, 5, 2, 2>(k, split, out, st);
     } else if (N % 160 == 0) {
         if (want_mt2(160)) rc = dispatch<2, 5, 4, 1>(k, split, out, st);
         else rc = dispatch<1, 5, 4, 1>(k, split, out, st);

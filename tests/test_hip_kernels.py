@@ -249,6 +249,42 @@ def test_conv_fp32_matches_fake_quant(cuda, case, w_bits):
     assert (got - want).abs().max().item() <= tol
 
 
+WIDE_CASES = [
+    # name,             B, Cin,  H,  W, Cout, k   — N % 320 == 0: the shapes the 2 x 2-wave tiles (256 x 320, 128 x 320) cover
+    ("n320_ragged_m",   3, 96, 13, 13, 320, 3),   # 507 rows: ragged last M block
+    ("n640_k1",         2, 320, 16, 16, 640, 1),
+    ("n320_k960",       1, 960, 24, 24, 320, 3),
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=[c[0] for c in WIDE_CASES])
+def test_conv_wide_tiles_match_fake_quant(cuda, case):
+    """fp32 output (+ row bias + residual) of 320-multiple-wide layers vs the reference's simulation, 2e-5 of range.  With
+    QD_FAT_TILE=1|2 QD_FAT_MINBLK=1 QD_FAT_MINK=64 in the environment (tools/r02b_call1.sh) these shapes take the
+    256 x 320 / 128 x 320 tiles of four 128 x 160 / 64 x 160 waves; without it the default 256 x 160 / 128 x 160 tiles."""
+    from qdiff import engine
+    _, B, Cin, H, W, Cout, k = case
+    g = torch.Generator().manual_seed(23)
+    x = F.silu(torch.randn(B, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
+    bias = torch.randn(Cout, generator=g)
+    q = _weight_quantizer(w, 4, True, g)
+    d, z = R.uaq_init_scale(x, 8, False, False, "max")
+    aq = _aq(d, z)
+    plan = engine.build_conv_plan(engine.pack_module_weights(w.to(cuda), [q], 0), [aq], k, k, 1, k // 2, bias.to(cuda))
+    xq = engine.quantize_rows(x.to(cuda), plan, B, Cin, H * W, (Cin * H * W, H * W, 1))
+    rowbias = torch.randn(B, Cout, generator=g).to(cuda)
+    residual = torch.randn(B * H * W, Cout, generator=g).to(cuda)
+    a = engine.conv_forward(plan, xq, B, H, W, rowbias=rowbias, residual=residual, splitk=False)
+    torch.cuda.synchronize()
+    want = R.quant_module_forward(x, w, bias, "conv2d", dict(stride=1, padding=k // 2),
+                                  [dict(delta=q.delta, zero_point=q.zero_point, alpha=q.alpha, n_levels=q.n_levels)],
+                                  [dict(delta=aq.delta, zero_point=z, n_bits=8, sym=False)])
+    want = want + rowbias.cpu()[:, :, None, None] + residual.cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
+    got = a.cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
+    assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+
+
 def test_conv_split_two_segments(cuda):
     """1x1 split shortcut (quant_layer.py:257-269): two activation + two weight quantisers."""
     from qdiff import engine
