@@ -1090,9 +1090,10 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
     static const int force_mt = getenv("QD_TILE_MT") ? atoi(getenv("QD_TILE_MT")) : 0;       // tuning knob: 1 / 2, 0 = heuristic
     static const int force_gmt = getenv("QD_GEGLU_MT") ? atoi(getenv("QD_GEGLU_MT")) : 0;
     static const int mt2_mink = getenv("QD_MT2_MINK") ? atoi(getenv("QD_MT2_MINK")) : 0;
-    static const int fat_tile = getenv("QD_FAT_TILE") ? atoi(getenv("QD_FAT_TILE")) : 0;      // measurement knob (0 = off)
-    static const int fat_mink = getenv("QD_FAT_MINK") ? atoi(getenv("QD_FAT_MINK")) : 1280;
-    static const int fat_minblk = getenv("QD_FAT_MINBLK") ? atoi(getenv("QD_FAT_MINBLK")) : 200;
+    // 128 x 320 tiles: 0 = off, 1 = where the 256 x 160 tile gives < 2 blocks per CU (default), 2 = wherever they fit (A/B knob)
+    static const int wide_tile = getenv("QD_WIDE_TILE") ? atoi(getenv("QD_WIDE_TILE")) : 1;
+    static const int wide_mink = getenv("QD_WIDE_MINK") ? atoi(getenv("QD_WIDE_MINK")) : 1280;
+    static const int wide_minblk = getenv("QD_WIDE_MINBLK") ? atoi(getenv("QD_WIDE_MINBLK")) : 200;
     const long Ktot = (long)k.taps * d->seg[0].clen;
     const bool linear_out = out == O_F32 || out == O_F16;
     // 256-row tiles (two 32-row tiles per wave: half the B-fragment reads and nibble unpacks per MFMA) whenever they still
@@ -1112,12 +1113,12 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
     } else if (geglu) {
         if (force_gmt == 2) rc = dispatch<2, 4, 4, 1>(k, split, out, st);
         else rc = dispatch<1, 4, 4, 1>(k, split, out, st);
-    } else if (fat_tile && N % 320 == 0 && out == O_F32 && !split && Ktot >= fat_mink && blocks(256, 320) >= fat_minblk) {
-        // 2 x 2 waves of 128 x 160: one 256 x 320 block per CU, one wave per SIMD with the whole register file (512 VGPRs).
-        // Per MFMA half the B-fragment reads / nibble unpacks of the 64-row wave tile, and 38 % fewer L2 -> LDS bytes per
-        // flop than the 256 x 160 block (profiles/r02_igemm_kstep_ablation.md, consequence 1).
-        rc = dispatch<4, 5, 2, 2>(k, split, out, st);
-    } else if (fat_tile >= 2 && N % 320 == 0 && out == O_F32 && !split && Ktot >= fat_mink && blocks(128, 320) >= fat_minblk) {
+    } else if (wide_tile && N % 320 == 0 && out == O_F32 && !split && Ktot >= wide_mink && blocks(128, 320) >= wide_minblk &&
+               (wide_tile >= 2 || blocks(256, 160) < 2 * 256)) {
+        // 2 x 2 waves of 64 x 160: a 128 x 320 block moves 18 KB per K-step into LDS for 40960 MACs per K element where the
+        // 256 x 160 block of 4 x 1 waves moves 21 KB — the long-K convolutions are bound by exactly that L2 -> LDS traffic
+        // (profiles/r02_igemm_kstep_ablation.md).  Measured (profiles/r02b_igemm_tiles.md): -7 .. -13 % on the 32 x 32 level
+        // (M = 16384, N = 640).  A 256 x 320 block of four 128 x 160 waves (one wave per SIMD, 512 VGPRs) was 2.2x SLOWER.
         rc = dispatch<2, 5, 2, 2>(k, split, out, st);
     } else if (N % 160 == 0) {
         if (want_mt2(160)) rc = dispatch<2, 5, 4, 1>(k, split, out, st);

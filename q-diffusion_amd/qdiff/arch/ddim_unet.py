@@ -216,7 +216,8 @@ class Model(nn.Module):
         if t is None:
             x, t = x
         assert x.shape[2] == x.shape[3] == self.resolution
-        x = x.contiguous(memory_format=torch.channels_last)
+        if x.is_cuda or not torch.is_grad_enabled():       # see arch/ldm_unet.py UNetModel.forward
+            x = x.contiguous(memory_format=torch.channels_last)
         temb = get_timestep_embedding(t, self.ch)
         from ..quant_block import time_mlp
         from ..quant_layer import QuantModule

@@ -498,7 +498,11 @@ class UNetModel(nn.Module):
         emb = self.time_embed(timestep_embedding(timesteps, self.model_channels))
         if self.num_classes is not None:
             emb = emb + self.label_emb(y)
-        h = x.type(self.dtype).contiguous(memory_format=torch.channels_last)
+        h = x.type(self.dtype)
+        if h.is_cuda or not torch.is_grad_enabled():
+            # channels-last is the integer engine's layout; the host autograd path keeps NCHW (calibration on a CPU: the
+            # CPU GroupNorm backward of this PyTorch build crashes on channels-last inputs)
+            h = h.contiguous(memory_format=torch.channels_last)
         from .. import engine, quant_block as qb
         # Skip concatenations (reference :772-777) are planned: the channel counts of both halves of every
         # `th.cat([h, hs.pop()], dim=1)` are recorded by the first evaluation; from then on the producers of both halves

@@ -1,0 +1,105 @@
+"""Calibration driver — the flow the reference's scripts spell out inline (scripts/sample_diffusion_ddim.py:150-234,
+scripts/sample_diffusion_ldm.py, scripts/txt2img.py:393-488), as two library functions:
+
+    recon_model(qnn, **kwargs)      walk the wrapped UNet: QuantModule children -> layer_reconstruction, BaseQuantBlock
+                                    children -> block_reconstruction, anything else -> recurse (scripts' `recon_model`)
+    calibrate_model(qnn, cali_data, ...)   initialise weight quantisers -> weight (AdaRound) phase -> initialise activation
+                                    quantisers (+ optional EMA range tracking) -> activation step-size phase -> the
+                                    reference-format state dict (utils.export_cali_state_dict)
+
+On MI355X the whole calibration set, the unit caches and the model live in HBM (288 GB); nothing is paged from the
+host between iterations (qdiff/recon.py).  SURVEY.md §8(f) N2.
+"""
+import logging
+
+import numpy as np
+import torch
+
+from .block_recon import block_reconstruction
+from .layer_recon import layer_reconstruction
+from .quant_block import BaseQuantBlock
+from .quant_layer import QuantModule
+
+logger = logging.getLogger(__name__)
+
+
+def recon_model(qnn, module=None, on_unit=None, **kwargs):
+    """Block reconstruction over `module` (default: the whole QuantModel); the first and the last convolution, which are
+    bare QuantModules, get layer reconstruction.  `on_unit(name, unit)` is called after each unit (checkpointing hook: the
+    reference saves a temporary checkpoint before the output blocks, txt2img.py:422-428)."""
+    module = qnn if module is None else module
+    for name, child in module.named_children():
+        if isinstance(child, QuantModule):
+            if child.ignore_reconstruction is True:
+                logger.info('Ignore reconstruction of layer {}'.format(name))
+                continue
+            logger.info('Reconstruction for layer {}'.format(name))
+            layer_reconstruction(qnn, child, **kwargs)
+        elif isinstance(child, BaseQuantBlock):
+            if child.ignore_reconstruction is True:
+                logger.info('Ignore reconstruction of block {}'.format(name))
+                continue
+            logger.info('Reconstruction for block {}'.format(name))
+            block_reconstruction(qnn, child, **kwargs)
+        else:
+            recon_model(qnn, child, on_unit=on_unit, **kwargs)
+            continue
+        if on_unit is not None:
+            on_unit(name, child)
+
+
+def _to_dev(qnn, *ts):
+    dev = next(qnn.parameters()).device
+    return tuple(t.to(dev) for t in ts)
+
+
+def calibrate_model(qnn, cali_data, cond=False, quant_act=True, cali_batch_size=32, cali_iters=20000, cali_iters_a=5000,
+                    cali_lr=4e-4, cali_p=2.4, running_stat=False, rs_sm_only=False, init_batch=8, act_init_batch=16,
+                    resume_w=False, is_sm=False, on_unit=None):
+    """The scripts' calibration sequence; returns the reference-format state dict (what `torch.save(qnn.state_dict())`
+    writes there after the Parameter wrapping of delta / zero_point).  cali_data = (xs, ts[, conds])."""
+    from . import engine
+    from .utils import export_cali_state_dict
+    with engine.simulation():           # quantiser initialisation and range tracking see the reference's fp32 arithmetic
+        _calibrate(qnn, cali_data, cond, quant_act, cali_batch_size, cali_iters, cali_iters_a, cali_lr, cali_p, running_stat,
+                   rs_sm_only, init_batch, act_init_batch, resume_w, is_sm, on_unit)
+    return export_cali_state_dict(qnn)
+
+
+def _calibrate(qnn, cali_data, cond, quant_act, cali_batch_size, cali_iters, cali_iters_a, cali_lr, cali_p, running_stat,
+               rs_sm_only, init_batch, act_init_batch, resume_w, is_sm, on_unit):
+    xs, ts = cali_data[0], cali_data[1]
+    cs = cali_data[2] if cond else None
+
+    def run(sel):
+        args = _to_dev(qnn, xs[sel], ts[sel]) + (_to_dev(qnn, cs[sel]) if cond else ())
+        return qnn(*args)
+
+    if not resume_w:
+        logger.info("Initializing weight quantization parameters")
+        qnn.set_quant_state(True, False)
+        with torch.no_grad():
+            run(slice(0, init_batch))
+        kwargs = dict(cali_data=cali_data, batch_size=cali_batch_size, iters=cali_iters, weight=0.01, asym=True,
+                      b_range=(20, 2), warmup=0.2, act_quant=False, opt_mode='mse', cond=cond, is_sm=is_sm)
+        logger.info("Doing weight calibration")
+        recon_model(qnn, on_unit=on_unit, **kwargs)
+        qnn.set_quant_state(weight_quant=True, act_quant=False)
+    if quant_act:
+        logger.info("Doing activation calibration")
+        qnn.set_quant_state(True, True)
+        with torch.no_grad():
+            inds = np.random.choice(xs.shape[0], min(act_init_batch, xs.shape[0]), replace=False)
+            run(torch.as_tensor(inds))
+            if running_stat:
+                logger.info('Running stat for activation quantization')
+                order = np.arange(xs.shape[0])
+                np.random.shuffle(order)
+                qnn.set_running_stat(True, rs_sm_only)
+                for i in range(int(xs.size(0) / act_init_batch)):
+                    run(torch.as_tensor(order[i * act_init_batch:(i + 1) * act_init_batch]))
+                qnn.set_running_stat(False, rs_sm_only)
+        kwargs = dict(cali_data=cali_data, batch_size=cali_batch_size, iters=cali_iters_a, act_quant=True, opt_mode='mse',
+                      lr=cali_lr, p=cali_p, cond=cond, is_sm=is_sm)
+        recon_model(qnn, on_unit=on_unit, **kwargs)
+        qnn.set_quant_state(weight_quant=True, act_quant=True)

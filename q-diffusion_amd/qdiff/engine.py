@@ -20,6 +20,22 @@ from .hip import Grid, pad16, pad32
 SIMULATE = False
 
 
+class simulation:
+    """`with engine.simulation():` — every (True, True) module runs the reference's fp32 fake-quant arithmetic inside the
+    block (calibration is DEFINED on that arithmetic: qdiff/recon.py, qdiff/calibrate.py; bench.py times it as the GPU
+    fake-quant denominator)."""
+
+    def __enter__(self):
+        global SIMULATE
+        self.prev, SIMULATE = SIMULATE, True
+        return self
+
+    def __exit__(self, *exc):
+        global SIMULATE
+        SIMULATE = self.prev
+        return False
+
+
 # ------------------------------------------------------------------------------------------------
 # quantiser views
 # ------------------------------------------------------------------------------------------------

@@ -1,10 +1,14 @@
-"""layer_reconstruction — importable for script compatibility (reference qdiff/layer_recon.py:13-17).
-See block_recon.py: calibration is the offline producer of the checkpoint, out of scope here."""
+"""layer_reconstruction — counterpart of the reference's qdiff/layer_recon.py:13-119 (the first / last convolutions and any
+QuantModule outside a block); the loop lives in qdiff/recon.py."""
+from .quant_layer import QuantModule
+from .recon import LinearTempDecay, LossFunction, reconstruct  # noqa: F401
 
 
-def layer_reconstruction(model, layer, cali_data, batch_size=32, iters=20000, weight=0.001, opt_mode='mse',
-                         asym=False, include_act_func=True, b_range=(20, 2), warmup=0.0, act_quant=False,
-                         lr=4e-5, p=2.0, multi_gpu=False, cond=False, is_sm=False):
-    raise NotImplementedError(
-        "calibration (layer reconstruction) is an offline step outside this engine's scope; calibrate with the "
-        "reference implementation and load the checkpoint with qdiff.utils.resume_cali_model")
+def layer_reconstruction(model, layer: QuantModule, cali_data, batch_size: int = 32, iters: int = 20000,
+                         weight: float = 0.001, opt_mode: str = 'mse', asym: bool = False, include_act_func: bool = True,
+                         b_range: tuple = (20, 2), warmup: float = 0.0, act_quant: bool = False, lr: float = 4e-5,
+                         p: float = 2.0, multi_gpu: bool = False, cond: bool = False, is_sm: bool = False):
+    """Optimise the output of a single quantised layer (AdaRound); parameters as block_reconstruction."""
+    reconstruct(model, layer, cali_data, batch_size=batch_size, iters=iters, weight=weight, opt_mode=opt_mode, asym=asym,
+                include_act_func=include_act_func, b_range=b_range, warmup=warmup, act_quant=act_quant, lr=lr, p=p,
+                multi_gpu=multi_gpu, cond=cond, is_sm=is_sm)

@@ -2,13 +2,16 @@
 `convert_adaround`, `resume_cali_model`, plus `export_cali_state_dict` — the save sequence the
 reference scripts spell out inline (sample_diffusion_ddim.py:223-234, txt2img.py:477-488).
 
-Calibration-time data capture (`save_inp_oup_data`, `GetLayerInpOut`, ... reference :18-322) belongs
-to the offline reconstruction pipeline, which is out of scope for this engine.
+Calibration-time data capture (`save_inp_oup_data`, `save_grad_data`, `GetLayerInpOut`, `GetLayerGrad`,
+`quantize_model_till`: reference :18-322) feeds qdiff/recon.py.
 """
 import logging
+from typing import Union
 
+import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .adaptive_rounding import AdaRoundQuantizer
 from .quant_block import BaseQuantBlock
@@ -247,3 +250,191 @@ def load_packed_ckpt(qnn, ckpt, free_weights=True):
                     wq.alpha.data = torch.empty(0, device=dev)
     qnn.set_quant_state(True, True)
     return qnn
+
+
+# ------------------------------------------------------------------------------------------------
+# calibration-time capture of a unit's inputs / outputs / output gradients  (reference utils.py:18-322)
+# ------------------------------------------------------------------------------------------------
+class StopForwardException(Exception):
+    """Raised by the capture hook to abandon the rest of the UNet evaluation (reference :183-187)."""
+
+
+class DataSaverHook:
+    """Forward hook keeping the (positional) inputs and the output of a unit (reference :190-210)."""
+
+    def __init__(self, store_input=False, store_output=False, stop_forward=False):
+        self.store_input, self.store_output, self.stop_forward = store_input, store_output, stop_forward
+        self.input_store = None
+        self.output_store = None
+
+    def __call__(self, module, input_batch, output_batch):
+        if self.store_input:
+            self.input_store = input_batch
+        if self.store_output:
+            self.output_store = output_batch
+        if self.stop_forward:
+            raise StopForwardException
+
+
+class GetLayerInpOut:
+    """(input[, second input]), output of `layer` for one calibration batch (reference :213-255): the output always
+    comes from the full-precision network; with `asym` the input is re-captured from the network quantised up to here
+    (weights, and activations when act_quant) — BRECQ's asymmetric reconstruction."""
+
+    def __init__(self, model, layer, device, asym: bool = False, act_quant: bool = False):
+        self.model, self.layer, self.device, self.asym, self.act_quant = model, layer, device, asym, act_quant
+        self.data_saver = DataSaverHook(store_input=True, store_output=True, stop_forward=True)
+
+    def _run(self, x, timesteps, context):
+        try:
+            self.model(x, timesteps, context)
+        except StopForwardException:
+            pass
+
+    def __call__(self, x, timesteps, context=None):
+        self.model.eval()
+        self.model.set_quant_state(False, False)
+        handle = self.layer.register_forward_hook(self.data_saver)
+        try:
+            with torch.no_grad():
+                self._run(x, timesteps, context)
+                if self.asym:
+                    self.data_saver.store_output = False
+                    self.model.set_quant_state(weight_quant=True, act_quant=self.act_quant)
+                    self._run(x, timesteps, context)
+                    self.data_saver.store_output = True
+        finally:
+            handle.remove()
+        self.model.set_quant_state(False, False)
+        self.layer.set_quant_state(True, self.act_quant)
+        self.model.train()
+        inp, out = self.data_saver.input_store, self.data_saver.output_store
+        if len(inp) > 1 and torch.is_tensor(inp[1]):
+            return (inp[0].detach(), inp[1].detach()), out.detach()
+        return inp[0].detach(), out.detach()
+
+
+def save_inp_oup_data(model, layer: Union[QuantModule, BaseQuantBlock], cali_data, asym: bool = False, act_quant: bool = False,
+                      batch_size: int = 32, keep_gpu: bool = True, cond: bool = False, is_sm: bool = False):
+    """Inputs and full-precision outputs of `layer` over the calibration set (reference :18-149).  Units that take two
+    tensors (x, emb) / (x, context) return `[xs, seconds]`.  `is_sm`: when the unit's input or output is a 4096 x 4096
+    attention map only a random half of the calibration samples is kept (the reference's memory guard, :38-70 — kept
+    because it decides WHICH samples the unit is calibrated on)."""
+    device = next(model.parameters()).device
+    get_inp_out = GetLayerInpOut(model, layer, device=device, asym=asym, act_quant=act_quant)
+    if cond:
+        cali_xs, cali_ts, cali_conds = cali_data
+    else:
+        (cali_xs, cali_ts), cali_conds = cali_data, None
+
+    def capture(sel):
+        args = [cali_xs[sel].to(device), cali_ts[sel].to(device)]
+        if cond:
+            args.append(cali_conds[sel].to(device))
+        return get_inp_out(*args)
+
+    inds = None
+    if is_sm:
+        test_inp, test_out = capture(slice(0, 1))
+        is_sm = False
+        if isinstance(test_inp, tuple) and test_inp[0].dim() > 2 and test_inp[0].shape[1] == test_inp[0].shape[2] == 4096:
+            is_sm = True
+        if test_out.dim() > 2 and test_out.shape[1] == test_out.shape[2] == 4096:
+            is_sm = True
+        if is_sm:
+            logger.info("attention-map unit: calibrating on a random half of the samples")
+            inds = np.random.choice(cali_xs.size(0), cali_xs.size(0) // 2, replace=False)
+    num = int(cali_xs.size(0) / batch_size)
+    if is_sm:
+        num //= 2
+    store = (lambda t: t) if keep_gpu else (lambda t: t.cpu())
+    ins0, ins1, outs = [], [], []
+    for i in range(num):
+        sel = slice(i * batch_size, (i + 1) * batch_size)
+        cur_inp, cur_out = capture(torch.as_tensor(inds[sel]) if inds is not None else sel)
+        if isinstance(cur_inp, tuple):
+            ins0.append(store(cur_inp[0]))
+            ins1.append(store(cur_inp[1]))
+        else:
+            ins0.append(store(cur_inp))
+        outs.append(store(cur_out))
+    cached_inps = [torch.cat(ins0), torch.cat(ins1)] if ins1 else torch.cat(ins0)
+    cached_outs = torch.cat(outs)
+    if device.type == 'cuda':
+        torch.cuda.empty_cache()
+    return cached_inps, cached_outs
+
+
+class GradSaverHook:
+    """Backward hook keeping the gradient w.r.t. a unit's output (reference :258-268)."""
+
+    def __init__(self, store_grad=True):
+        self.store_grad = store_grad
+        self.stop_backward = False
+        self.grad_out = None
+
+    def __call__(self, module, grad_input, grad_output):
+        if self.store_grad:
+            self.grad_out = grad_output[0]
+        if self.stop_backward:
+            raise StopForwardException
+
+
+def quantize_model_till(model, layer, act_quant: bool = False):
+    """Quantise every unit up to and including `layer`, in module order (reference :313-322)."""
+    model.set_quant_state(False, False)
+    for _, module in model.named_modules():
+        if isinstance(module, (QuantModule, BaseQuantBlock)):
+            module.set_quant_state(True, act_quant)
+        if module is layer:
+            break
+
+
+class GetLayerGrad:
+    """Gradient of KL(quantised-up-to-here || full precision) w.r.t. the unit's output: the Fisher-information weights
+    of opt_mode 'fisher_diag' / 'fisher_full' (reference :271-310)."""
+
+    def __init__(self, model, layer, device, act_quant: bool = False):
+        self.model, self.layer, self.device, self.act_quant = model, layer, device, act_quant
+        self.data_saver = GradSaverHook(True)
+
+    def __call__(self, model_input):
+        self.model.eval()
+        handle = self.layer.register_full_backward_hook(self.data_saver)
+        try:
+            with torch.enable_grad():
+                try:
+                    self.model.zero_grad()
+                    inputs = tuple(t.to(self.device) for t in model_input) if isinstance(model_input, (tuple, list)) else (model_input.to(self.device),)
+                    self.model.set_quant_state(False, False)
+                    out_fp = self.model(*inputs)
+                    quantize_model_till(self.model, self.layer, self.act_quant)
+                    out_q = self.model(*inputs)
+                    loss = F.kl_div(F.log_softmax(out_q, dim=1), F.softmax(out_fp, dim=1), reduction='batchmean')
+                    loss.backward()
+                except StopForwardException:
+                    pass
+        finally:
+            handle.remove()
+        self.model.set_quant_state(False, False)
+        self.layer.set_quant_state(True, self.act_quant)
+        self.model.train()
+        return self.data_saver.grad_out.data
+
+
+def save_grad_data(model, layer, cali_data, damping: float = 1., act_quant: bool = False, batch_size: int = 32, keep_gpu: bool = True):
+    """|dL/d(output)| + 1 of `layer` over the calibration set (reference :152-180).  `cali_data` may be the (xs, ts[, conds])
+    tuple of the diffusion scripts (the reference indexes a single tensor here, a leftover of its classification origin)."""
+    device = next(model.parameters()).device
+    get_grad = GetLayerGrad(model, layer, device, act_quant=act_quant)
+    n = cali_data[0].size(0) if isinstance(cali_data, (tuple, list)) else cali_data.size(0)
+    grads = []
+    for i in range(int(n / batch_size)):
+        sel = slice(i * batch_size, (i + 1) * batch_size)
+        batch = tuple(t[sel] for t in cali_data) if isinstance(cali_data, (tuple, list)) else cali_data[sel]
+        g = get_grad(batch)
+        grads.append(g if keep_gpu else g.cpu())
+    cached = torch.cat(grads).abs() + 1.0
+    if device.type == 'cuda':
+        torch.cuda.empty_cache()
+    return cached

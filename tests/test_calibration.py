@@ -1,0 +1,171 @@
+"""N2 — calibration (block / layer reconstruction) against fixtures produced by the REAL reference's calibration code
+(tools/make_golden_recon.py: the reference's block_recon.py / layer_recon.py / utils.py driven by the `recon_model` walk of
+its scripts, same seeds, same synthetic weights, a few iterations per unit, CPU).  The simulation graph autograd
+differentiates here is this repo's (`_forward_sim` compositions, QuantModule's fp32 path) — the same operations as the
+reference's, so the trained parameters agree to fp32 rounding; Adam's normalised steps (|step| = lr whatever the
+gradient's size) turn a sign flip of a ~0 gradient into a 2*lr difference, hence the small per-element allowance."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import build_engine_model, load_fixture, quant_params
+
+
+def _inputs(spec, batch, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((batch,) + tuple(spec["x"]), generator=g)
+    t = torch.randint(0, 1000, (batch,), generator=g)
+    if spec["family"] == "cifar":
+        t = t.float()
+    c = torch.randn((batch,) + tuple(spec["ctx"]), generator=g) if spec["ctx"] else None
+    return x, t, c
+
+
+def _summary(t):
+    f = t.detach().flatten().double()
+    step = max(1, f.numel() // 64)
+    return dict(numel=f.numel(), n_up=int((f >= 0).sum()), sum=float(f.sum()), l2=float(f.norm()), sample=f[::step][:64].float())
+
+
+@pytest.mark.parametrize("name", ["cifar_tiny", "sd_tiny"])
+def test_calibration_matches_the_reference(name):
+    import qdiff
+    from qdiff.adaptive_rounding import AdaRoundQuantizer
+    from qdiff.calibrate import recon_model
+    from qdiff.quant_layer import UniformAffineQuantizer
+    fx = load_fixture(f"recon_{name}.pt")
+    spec = fx["spec"]
+    cond = spec["ctx"] is not None
+    wq, aq = quant_params(spec)
+    xs, ts, cs = _inputs(spec, fx["n_cal"], fx["cal_seed"])
+    cali = (xs, ts, cs) if cond else (xs, ts)
+    test = tuple(a for a in _inputs(spec, 2, fx["test_seed"]) if a is not None)
+    qnn = qdiff.QuantModel(build_engine_model(spec), wq, aq, sm_abit=spec["sm_abit"]).eval()
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(*cali)
+    torch.manual_seed(fx["seed"])
+    np.random.seed(fx["seed"])
+    recon_model(qnn, cali_data=cali, batch_size=fx["batch"], iters=fx["iters_w"], weight=0.01, asym=True, b_range=(20, 2),
+                warmup=0.2, act_quant=False, opt_mode='mse', cond=cond)
+    qnn.set_quant_state(True, False)
+    got = {k: _summary(m.alpha) for k, m in qnn.named_modules() if isinstance(m, AdaRoundQuantizer)}
+    assert set(got) == set(fx["alphas"]), "the set of AdaRound quantisers differs from the reference's"
+    lr = 1e-3                                             # Adam default: the size of one step
+    flips = total = 0
+    for k, want in fx["alphas"].items():
+        g = got[k]
+        assert g["numel"] == want["numel"], k
+        d = (g["sample"] - want["sample"]).abs()
+        assert d.max().item() <= 2 * lr * fx["iters_w"] + 1e-5, (k, d.max().item())     # never further than every step reversed
+        assert (d > 1e-4).float().mean().item() <= 0.05, (k, (d > 1e-4).float().mean().item())
+        flips += abs(g["n_up"] - want["n_up"])
+        total += want["numel"]
+        assert abs(g["l2"] - want["l2"]) <= 1e-3 * want["l2"] + 1e-4, k
+    assert flips <= 1e-4 * total, f"{flips} of {total} rounding decisions differ"
+    qnn.eval()
+    with torch.no_grad():
+        y = qnn(*test)
+    assert (y - fx["out_w"]).abs().max().item() <= 2e-3 * fx["out_w"].abs().max().item()
+    # activation phase
+    from qdiff import engine
+    qnn.set_quant_state(True, True)
+    with torch.no_grad(), engine.simulation():
+        inds = torch.as_tensor(np.random.choice(xs.shape[0], 4, replace=False))
+        qnn(*(a[inds] for a in cali))
+    recon_model(qnn, cali_data=cali, batch_size=fx["batch"], iters=fx["iters_a"], act_quant=True, opt_mode='mse', lr=4e-4, p=2.4,
+                cond=cond)
+    qnn.set_quant_state(True, True)
+    deltas = {k: m.delta.detach() for k, m in qnn.named_modules()
+              if isinstance(m, UniformAffineQuantizer) and getattr(m, "leaf_param", False) and m.inited and torch.is_tensor(m.delta)}
+    assert set(deltas) == set(fx["deltas"])
+    moved = 0
+    for k, want in fx["deltas"].items():
+        g = deltas[k]
+        assert torch.allclose(g.reshape(-1), want.reshape(-1), rtol=5e-3, atol=2 * 4e-4 * fx["iters_a"]), (k, g, want)
+        moved += 1
+    assert moved > 20
+    qnn.eval()
+    with torch.no_grad(), engine.simulation():
+        y = qnn(*test)
+    # a fake-quantised network amplifies the 1e-3-level step-size differences above through round() ties
+    cos = torch.nn.functional.cosine_similarity(y.flatten(), fx["out_wa"].flatten(), dim=0).item()
+    assert (y - fx["out_wa"]).abs().max().item() <= 0.12 * fx["out_wa"].abs().max().item() and cos >= 0.99, cos
+
+
+def test_temperature_schedule_and_loss_terms():
+    """LinearTempDecay / LossFunction against closed forms (reference block_recon.py:169-252)."""
+    from qdiff.block_recon import LinearTempDecay, LossFunction
+    td = LinearTempDecay(100, rel_start_decay=0.2, start_b=20, end_b=2)
+    assert td(0) == 20 and td(19) == 20 and td(100) == 2
+    assert abs(td(60) - (2 + 18 * (1 - 40 / 80))) < 1e-12
+
+    class Q(torch.nn.Module):
+        def get_soft_targets(self):
+            return torch.tensor([0.0, 0.25, 0.5, 1.0])
+    import qdiff
+    m = qdiff.QuantModule(torch.nn.Linear(4, 4), dict(n_bits=4, channel_wise=True, scale_method="max"),
+                          dict(n_bits=8, channel_wise=False, scale_method="max"))
+    m.weight_quantizer = Q()
+    lf = LossFunction(m, round_loss='relaxation', weight=0.5, max_count=10, rec_loss='mse', b_range=(20, 2), warmup=0.2, p=2.0)
+    pred, tgt = torch.ones(2, 3), torch.zeros(2, 3)
+    assert float(lf(pred, tgt)) == 3.0                               # count 1 < warm-up: reconstruction term only
+    lf.count = 5
+    b = lf.temp_decay(6)
+    want = 3.0 + 0.5 * float((1 - ((torch.tensor([0.0, 0.25, 0.5, 1.0]) - .5).abs() * 2).pow(b)).sum())
+    assert abs(float(lf(pred, tgt)) - want) < 1e-6
+
+
+def test_capture_hooks_see_both_block_inputs():
+    """save_inp_oup_data returns [xs, embs] for units called with two tensors and the full-precision output; with `asym`
+    the inputs come from the quantised network (they differ from the fp inputs after the first quantised layer)."""
+    import qdiff
+    from qdiff.quant_block import QuantResnetBlock
+    from qdiff.utils import save_inp_oup_data
+    fx = load_fixture("recon_cifar_tiny.pt")
+    spec = fx["spec"]
+    wq, aq = quant_params(spec)
+    qnn = qdiff.QuantModel(build_engine_model(spec), wq, aq, sm_abit=spec["sm_abit"]).eval()
+    xs, ts, _ = _inputs(spec, 8, 300)
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(xs, ts)
+    blocks = [m for m in qnn.modules() if isinstance(m, QuantResnetBlock)]
+    inp_fp, out_fp = save_inp_oup_data(qnn, blocks[2], (xs, ts), asym=False, act_quant=False, batch_size=4, keep_gpu=False)
+    inp_q, out_q = save_inp_oup_data(qnn, blocks[2], (xs, ts), asym=True, act_quant=False, batch_size=4, keep_gpu=False)
+    assert isinstance(inp_fp, list) and inp_fp[0].shape[0] == 8 and inp_fp[1].shape[0] == 8 and out_fp.shape[0] == 8
+    assert torch.equal(out_fp, out_q)                       # outputs always come from the full-precision network
+    assert not torch.equal(inp_fp[0], inp_q[0]) and not torch.equal(inp_fp[1], inp_q[1])   # (the time embedding is quantised too)
+    assert qnn.training and blocks[2].use_weight_quant and not blocks[0].use_weight_quant
+
+
+def test_calibrate_then_resume_round_trip(tmp_path):
+    """calibrate_model -> reference-format checkpoint -> resume_cali_model on a fresh model reproduces the calibrated
+    model's output (the producer and the consumer of the checkpoint agree on every key)."""
+    import qdiff
+    from qdiff import engine
+    from qdiff.calibrate import calibrate_model
+    from qdiff.utils import resume_cali_model
+    fx = load_fixture("recon_cifar_tiny.pt")
+    spec = fx["spec"]
+    wq, aq = quant_params(spec)
+    xs, ts, _ = _inputs(spec, 8, 300)
+    test = tuple(a for a in _inputs(spec, 2, 200) if a is not None)
+    qnn = qdiff.QuantModel(build_engine_model(spec), wq, aq, sm_abit=spec["sm_abit"]).eval()
+    torch.manual_seed(7)
+    np.random.seed(7)
+    seen = []
+    sd = calibrate_model(qnn, (xs, ts), cond=False, quant_act=True, cali_batch_size=4, cali_iters=2, cali_iters_a=2,
+                         act_init_batch=4, on_unit=lambda n, u: seen.append(n))
+    assert len(seen) > 10 and any(k.endswith("weight_quantizer.alpha") for k in sd) and any(k.endswith("act_quantizer.delta") for k in sd)
+    qnn.eval()
+    with torch.no_grad(), engine.simulation():
+        want = qnn(*test)
+    path = tmp_path / "ckpt.pth"
+    torch.save(sd, path)
+    q2 = qdiff.QuantModel(build_engine_model(spec), wq, aq, sm_abit=spec["sm_abit"]).eval()
+    with engine.simulation():
+        resume_cali_model(q2, str(path), (xs[:1], ts[:1]), quant_act=True, cond=False)
+        with torch.no_grad():
+            got = q2(*test)
+    assert torch.equal(got, want)
