@@ -1090,8 +1090,8 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
     static const int force_mt = getenv("QD_TILE_MT") ? atoi(getenv("QD_TILE_MT")) : 0;       // tuning knob: 1 / 2, 0 = heuristic
     static const int force_gmt = getenv("QD_GEGLU_MT") ? atoi(getenv("QD_GEGLU_MT")) : 0;
     static const int mt2_mink = getenv("QD_MT2_MINK") ? atoi(getenv("QD_MT2_MINK")) : 0;
-    // 128 x 320 tiles: 0 = off, 1 = where the 256 x 160 tile gives < 2 blocks per CU (default), 2 = wherever they fit (A/B knob)
-    static const int wide_tile = getenv("QD_WIDE_TILE") ? atoi(getenv("QD_WIDE_TILE")) : 1;
+    // 128 x 320 tiles: 0 = off, 1 = only where the 256 x 160 tile gives < 2 blocks per CU, 2 = wherever they fit (default)
+    static const int wide_tile = getenv("QD_WIDE_TILE") ? atoi(getenv("QD_WIDE_TILE")) : 2;
     static const int wide_mink = getenv("QD_WIDE_MINK") ? atoi(getenv("QD_WIDE_MINK")) : 1280;
     static const int wide_minblk = getenv("QD_WIDE_MINBLK") ? atoi(getenv("QD_WIDE_MINBLK")) : 200;
     const long Ktot = (long)k.taps * d->seg[0].clen;
@@ -1117,8 +1117,9 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
                (wide_tile >= 2 || blocks(256, 160) < 2 * 256)) {
         // 2 x 2 waves of 64 x 160: a 128 x 320 block moves 18 KB per K-step into LDS for 40960 MACs per K element where the
         // 256 x 160 block of 4 x 1 waves moves 21 KB — the long-K convolutions are bound by exactly that L2 -> LDS traffic
-        // (profiles/r02_igemm_kstep_ablation.md).  Measured (profiles/r02b_igemm_tiles.md): -7 .. -13 % on the 32 x 32 level
-        // (M = 16384, N = 640).  A 256 x 320 block of four 128 x 160 waves (one wave per SIMD, 512 VGPRs) was 2.2x SLOWER.
+        // (profiles/r02_igemm_kstep_ablation.md).  Measured (profiles/r02b_igemm_tiles.md): -5 .. -13 % on the 32 x 32 level
+        // (M = 16384, N = 640), -5 .. -8 % on the 64 x 64 level (M = 65536, N = 320).  A 256 x 320 block of four 128 x 160
+        // waves (one wave per SIMD, 512 VGPRs) was 2.2x SLOWER.
         rc = dispatch<2, 5, 2, 2>(k, split, out, st);
     } else if (N % 160 == 0) {
         if (want_mt2(160)) rc = dispatch<2, 5, 4, 1>(k, split, out, st);
