@@ -203,6 +203,29 @@ def cpu_baseline(qnn, qspec, kind, cfg, k=2):
     return (time.time() - t0) / k
 
 
+def first_stage_decode_ms(kind, n, dev, k=3):
+    """Latents -> images for the n images of one sampler batch (qdiff/arch/first_stage.py; not part of the denoising metric:
+    reported so that the end-to-end cost of an image is visible next to the 51 / 200 UNet evaluations it follows)."""
+    from qdiff import synthetic
+    from qdiff.arch import first_stage as fs
+    m, scale = fs.sd_v1_first_stage() if kind == "sd" else fs.lsun_beds_first_stage()
+    synthetic.load_synthetic_weights(m, seed=0)
+    m = m.to(dev).eval()
+    z = torch.randn((n, 4, 64, 64) if kind == "sd" else (n, 3, 64, 64), device=dev)
+    res = {}
+    for name, dt in (("fp32", None), ("bf16_autocast", torch.bfloat16)):
+        fs.decode_first_stage(m, z, scale, autocast_dtype=dt, to_uint8=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            img = fs.decode_first_stage(m, z, scale, autocast_dtype=dt, to_uint8=True)
+        torch.cuda.synchronize()
+        res[name + "_ms_per_image"] = round((time.perf_counter() - t0) * 1000.0 / k / n, 3)
+    res["images"] = n
+    res["output"] = list(img.shape)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,6 +236,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-denominators", action="store_true", help="skip the fp32 / fake-quant GPU denominators")
+    ap.add_argument("--decode", action="store_true", help="also time the first-stage decode of the image batch (sd / ldm; extra field)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -361,6 +385,8 @@ def main():
             out["cpu_baseline"] = {"value": round(1.0 / per_image, 6), "unit": "images/s", "cores": torch.get_num_threads(),
                                    "kind": "port", "sample": f"UNet evaluations of one sample on the host cores: 1 warm-up + 2 timed, {dt:.1f} s "
                                                              f"each; extrapolated to {evals} evaluations x {2 if guide != 1.0 else 1} samples per image"}
+        if a.decode and kind in ("sd", "ldm"):
+            out["first_stage_decode"] = first_stage_decode_ms(kind, n, dev)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

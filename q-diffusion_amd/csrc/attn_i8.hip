@@ -58,35 +58,17 @@ struct AttnK {
 //   * key masking exists only in the last (ragged) tile;
 // and the next K tile / this tile's V tile are prefetched into registers ahead of the softmax math, so
 // the L2 latency of the (tiny, shared) K/V stream hides behind ~1k VALU cycles.
-// KZ: per-key zero-point term from a table in LDS instead of constant-operand MFMAs (see attn_lean_kernel below).
-template <int DT, bool P16, bool ASYM, bool KZ = false>
+template <int DT, bool P16, bool ASYM>
 // (3 blocks per CU was tried for DT=2/P16: 168 VGPRs + 100 B of scratch, 16% slower end to end.)
 __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_kernel(const AttnK p) {
-    extern __shared__ __attribute__((aligned(16))) int sKzG[];      // [Spad] (KZ only)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frow = lane & 31, half = lane >> 5;
     const int bh = blockIdx.y;
     const int q0 = (blockIdx.x * 4 + wave) * 32;
-    const float cs2 = p.prm[0] * 1.4426950408889634f;            // scores -> log2 domain
-    const int nzq = -(int)p.prm[1];
-    if constexpr (ASYM && KZ) {
-        for (int key = threadIdx.x; key < p.Spad; key += 256) {
-            const v4i* kr = reinterpret_cast<const v4i*>(p.k + ((long)bh * p.Spad + key) * p.dpad);
-            int sum = 0;
-#pragma unroll
-            for (int c = 0; c < DT * 2; ++c) {
-                const v4i w = kr[c];
-                sum = __builtin_amdgcn_sdot4(w.x, 0x01010101, sum, false);
-                sum = __builtin_amdgcn_sdot4(w.y, 0x01010101, sum, false);
-                sum = __builtin_amdgcn_sdot4(w.z, 0x01010101, sum, false);
-                sum = __builtin_amdgcn_sdot4(w.w, 0x01010101, sum, false);
-            }
-            sKzG[key] = nzq * sum;
-        }
-        __syncthreads();
-    }
     if (q0 >= p.T) return;
 
+    const float cs2 = p.prm[0] * 1.4426950408889634f;            // scores -> log2 domain
+    const int nzq = -(int)p.prm[1];
     const float dw = p.prm[3], zpw = p.prm[4], oscale = p.prm[5];
     const int zv = (int)p.prm[6];
     const int izpw = (int)zpw;
@@ -115,21 +97,8 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_k
         for (int kk = 0; kk < DT; ++kk) kf[kk] = *reinterpret_cast<const v4i*>(kp + kk * 32);
     };
     // d[4g+e] = (score of key jt*32 + e + 8g + 4*half) - base, per-query constants dropped
-    auto scores = [&](const v4i (&kf)[DT], int base, int (&d)[16], int jt) __attribute__((always_inline)) {
+    auto scores = [&](const v4i (&kf)[DT], int base, int (&d)[16]) __attribute__((always_inline)) {
         v16i acc;
-        if constexpr (ASYM && KZ) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const v4i z = *reinterpret_cast<const v4i*>(sKzG + jt * 32 + 8 * g + 4 * half);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[4 * g + e] = z[e] - base;
-            }
-#pragma unroll
-            for (int kk = 0; kk < DT; ++kk) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], qf[kk], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) d[r] = acc[r];
-            return;
-        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = -base;
 #pragma unroll
@@ -154,7 +123,7 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_k
         load_k(0, kf);
         {   // seed the running max with tile 0's (so every later difference s - mi is small and exact in fp32)
             int d[16];
-            scores(kf, 0, d, 0);
+            scores(kf, 0, d);
             if (tail_tile == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) if (!key_ok(0, r)) d[r] = MASKED;
@@ -169,7 +138,7 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_k
             constexpr bool tail = decltype(tail_tag)::value;
             if (jt + 1 < ntile) load_k(jt + 1, kfn);
             int d[16];
-            scores(kf, mi, d, jt);                            // d = s - mi
+            scores(kf, mi, d);                                // d = s - mi
             if (tail) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) if (!key_ok(jt, r)) d[r] = MASKED;
@@ -233,7 +202,7 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_k
             for (int t = 0; t < DT; ++t) vf[t] = *reinterpret_cast<const v4i*>(vbase + (long)t * 32 * p.Spad + jt * 32);
             if (jt + 1 < ntile) load_k(jt + 1, kfn);
             int d[16];
-            scores(kf, mi, d, jt);                            // d = s - rowmax <= 0
+            scores(kf, mi, d);                                // d = s - rowmax <= 0
             unsigned ub[16];                                      // float bits of uu + MAGIC: low 16 bits == uu
             const v2f cs2v = {cs2, cs2}, invv = {inv, inv}, ubv = {ubias, ubias}, magic = {MAGIC, MAGIC};
 #pragma unroll
@@ -345,42 +314,19 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_k
 //     of the output tile is sum_j code_j — no v_dot4 in the loop.
 __device__ __attribute__((aligned(16))) int qd_ones16[4] = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
 
-// KZ (with ASYM): the per-key zero-point term -zq' * sum_d k'[key][d] comes from a table in LDS instead of the matrix pipe.
-// It does not depend on the query: the constant-operand MFMAs recompute it for each of the T/32 query tiles and in both
-// sweeps — 4 of the 12 MFMAs per 32 x 32 tile at d = 40, on a kernel whose matrix and vector phases do not overlap.  Each
-// block builds the table once (v_dot4 over the key rows it is about to stream anyway: S * dpad bytes out of L2, 16 KB of LDS
-// at S = 4096), and the accumulators start at  init + table[key]  (a v_add where the v_mov of `init` was) — the same
-// integers, hence the same results bit for bit.
-template <int DT, bool P16, bool ASYM, bool KZ = false>
+template <int DT, bool P16, bool ASYM>
 #ifndef QD_ATTN_LEAN_OCC
 #define QD_ATTN_LEAN_OCC 3
 #endif
 __global__ __launch_bounds__(256, QD_ATTN_LEAN_OCC) void attn_lean_kernel(const AttnK p) {
-    extern __shared__ __attribute__((aligned(16))) int sKz[];       // [Spad] (KZ only)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frow = lane & 31, half = lane >> 5;
     const int bh = blockIdx.y;
     const int q0 = (blockIdx.x * 4 + wave) * 32;
-    const float cs2 = p.prm[0] * 1.4426950408889634f;
-    const int nzq = -(int)p.prm[1];
-    if constexpr (ASYM && KZ) {
-        for (int key = threadIdx.x; key < p.Spad; key += 256) {
-            const v4i* kr = reinterpret_cast<const v4i*>(p.k + ((long)bh * p.Spad + key) * p.dpad);
-            int sum = 0;
-#pragma unroll
-            for (int c = 0; c < DT * 2; ++c) {
-                const v4i w = kr[c];
-                sum = __builtin_amdgcn_sdot4(w.x, 0x01010101, sum, false);
-                sum = __builtin_amdgcn_sdot4(w.y, 0x01010101, sum, false);
-                sum = __builtin_amdgcn_sdot4(w.z, 0x01010101, sum, false);
-                sum = __builtin_amdgcn_sdot4(w.w, 0x01010101, sum, false);
-            }
-            sKz[key] = nzq * sum;
-        }
-        __syncthreads();
-    }
     if (q0 >= p.T) return;
 
+    const float cs2 = p.prm[0] * 1.4426950408889634f;
+    const int nzq = -(int)p.prm[1];
     const float dw = p.prm[3], zpw = p.prm[4], oscale = p.prm[5];
     const int zv = (int)p.prm[6];
     const int izpw = (int)zpw;
@@ -408,18 +354,7 @@ __global__ __launch_bounds__(256, QD_ATTN_LEAN_OCC) void attn_lean_kernel(const 
         for (int kk = 0; kk < DT; ++kk) kf[kk] = *reinterpret_cast<const v4i*>(kp + kk * 32);
     };
     // acc[4g+e] = init + score of key jt*32 + e + 8g + 4*half (per-query constants dropped)
-    auto scores = [&](const v4i (&kf)[DT], int init, v16i& acc, int jt) __attribute__((always_inline)) {
-        if constexpr (ASYM && KZ) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const v4i z = *reinterpret_cast<const v4i*>(sKz + jt * 32 + 8 * g + 4 * half);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[4 * g + e] = init + z[e];
-            }
-#pragma unroll
-            for (int kk = 0; kk < DT; ++kk) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], qf[kk], acc, 0, 0, 0);
-            return;
-        }
+    auto scores = [&](const v4i (&kf)[DT], int init, v16i& acc) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = init;
 #pragma unroll
@@ -443,7 +378,7 @@ __global__ __launch_bounds__(256, QD_ATTN_LEAN_OCC) void attn_lean_kernel(const 
         load_k(0, kf);
         {
             v16i acc;
-            scores(kf, 0, acc, 0);
+            scores(kf, 0, acc);
             if (tail_tile == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) if (!key_ok(0, r)) acc[r] = MASKED;
@@ -460,7 +395,7 @@ __global__ __launch_bounds__(256, QD_ATTN_LEAN_OCC) void attn_lean_kernel(const 
                 constexpr bool tail = decltype(tail_tag)::value;
                 if (jt + 1 < ntile) load_k(jt + 1, kfn);
                 v16i acc;
-                scores(kf, init, acc, jt);
+                scores(kf, init, acc);
                 if (tail) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) if (!key_ok(jt, r)) acc[r] = 0;
@@ -534,7 +469,7 @@ __global__ __launch_bounds__(256, QD_ATTN_LEAN_OCC) void attn_lean_kernel(const 
             for (int t = 0; t < DT; ++t) vf[t] = *reinterpret_cast<const v4i*>(vp[t] + (long)jt * vstep[t]);
             if (jt + 1 < ntile) load_k(jt + 1, kfn);
             v16i acc;
-            scores(kf, init, acc, jt);
+            scores(kf, init, acc);
             unsigned ub[16];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
@@ -629,14 +564,6 @@ __global__ __launch_bounds__(256, QD_ATTN_LEAN_OCC) void attn_lean_kernel(const 
 template <int DT>
 int launch_lean(const AttnK& k, bool p16, bool asym, hipStream_t st) {
     dim3 grid((unsigned)((k.T + 127) / 128), (unsigned)k.BH);
-    // key-sum table in LDS (see attn_lean_kernel): up to 12288 keys (48 KB; three blocks per CU keep their occupancy)
-    static const bool kz_ok = !(getenv("QD_ATTN_KZ") && atoi(getenv("QD_ATTN_KZ")) == 0);       // A/B knob
-    const size_t kz_bytes = (size_t)k.Spad * sizeof(int);
-    if (asym && kz_ok && kz_bytes <= 48 * 1024) {
-        if (p16) hipLaunchKernelGGL((attn_lean_kernel<DT, true, true, true>), grid, dim3(256), kz_bytes, st, k);
-        else hipLaunchKernelGGL((attn_lean_kernel<DT, false, true, true>), grid, dim3(256), kz_bytes, st, k);
-        return 0;
-    }
     if (p16 && asym) hipLaunchKernelGGL((attn_lean_kernel<DT, true, true>), grid, dim3(256), 0, st, k);
     else if (p16) hipLaunchKernelGGL((attn_lean_kernel<DT, true, false>), grid, dim3(256), 0, st, k);
     else if (asym) hipLaunchKernelGGL((attn_lean_kernel<DT, false, true>), grid, dim3(256), 0, st, k);
@@ -647,13 +574,6 @@ int launch_lean(const AttnK& k, bool p16, bool asym, hipStream_t st) {
 template <int DT>
 int launch_dt(const AttnK& k, bool p16, bool asym, hipStream_t st) {
     dim3 grid((unsigned)((k.T + 127) / 128), (unsigned)k.BH);
-    static const bool kz_ok = !(getenv("QD_ATTN_KZ") && atoi(getenv("QD_ATTN_KZ")) == 0);       // A/B knob
-    const size_t kz_bytes = (size_t)k.Spad * sizeof(int);
-    if (asym && kz_ok && kz_bytes <= 32 * 1024) {
-        if (p16) hipLaunchKernelGGL((attn_kernel<DT, true, true, true>), grid, dim3(256), kz_bytes, st, k);
-        else hipLaunchKernelGGL((attn_kernel<DT, false, true, true>), grid, dim3(256), kz_bytes, st, k);
-        return 0;
-    }
     if (p16 && asym) hipLaunchKernelGGL((attn_kernel<DT, true, true>), grid, dim3(256), 0, st, k);
     else if (p16) hipLaunchKernelGGL((attn_kernel<DT, true, false>), grid, dim3(256), 0, st, k);
     else if (asym) hipLaunchKernelGGL((attn_kernel<DT, false, true>), grid, dim3(256), 0, st, k);
