@@ -73,6 +73,7 @@ struct ConvD {
     float* gnpart;            // O_F32, optional: per-(sample, 128-row chunk, channel) {sum, sum of squares} of the output,
     int    gn_nchunk;         //   i.e. the first level of GroupNorm's statistics (layout of gn_partial_kernel); S/128
     long   gn_ld;             //   channels per chunk row of gnpart (>= Cout: column range of a wider statistics buffer)
+    int    pointwise;         // 1x1 convolution / linear layer without padding or stride: output row m is input pixel m
 };
 
 // O_PART: split-K partial.  The block contracts K-steps [y*it_per, (y+1)*it_per) only and stores
@@ -167,6 +168,21 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
     unsigned a_mask[NA];                          // bit t: tap t of that row lies inside the image
     bool a_valid[NA];
     const int HoWo = p.Ho * p.Wo;
+    // 1x1 / linear layers (three quarters of the launches of a UNet evaluation, most of them short-K): output row m IS input
+    // pixel m, so the im2col decomposition (two integer divisions per row, two more per tap for the in-image mask: ~40
+    // instructions each) is skipped — the prologue is a large share of a block's life when K is 320.
+    if (p.pointwise) {                            // set by the host: taps == 1, stride 1, no padding, Ho x Wo == H x W
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int r = (wave + 4 * i) * 16 + lr16;
+            const int m = m0 + r;
+            a_valid[i] = m < p.M;
+            const int mm = a_valid[i] ? m : 0;
+            a_org[i] = p.x + (long)mm * p.ldx + a_chunk;
+            a_mask[i] = a_valid[i] ? 1u : 0u;
+            if (p.rowbias != nullptr && slot == 0) sRowB[r] = mm / HoWo;
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int r = (wave + 4 * i) * 16 + lr16;
@@ -185,6 +201,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
         }
         a_mask[i] = msk;
         if (slot == 0) sRowB[r] = b;
+    }
     }
 
     // ---- loader state (uniform) + per-lane running source pointers -------------------------------------------
@@ -1003,6 +1020,8 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
     k.B = d->B; k.H = d->H; k.W = d->W; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout;
     k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad_t = d->pad_t; k.pad_l = d->pad_l;
     k.M = d->B * d->Ho * d->Wo; k.taps = d->kh * d->kw; k.nseg = d->nseg;
+    static const bool pw_ok = !(getenv("QD_POINTWISE") && atoi(getenv("QD_POINTWISE")) == 0);          // A/B knob
+    k.pointwise = pw_ok && k.taps == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->H == d->Ho && d->W == d->Wo;
     k.ntiles = (d->Cout + 31) / 32;
     for (int s = 0; s < d->nseg; ++s) {
         const qd_conv_seg& g = d->seg[s];
