@@ -68,6 +68,7 @@ struct ConvD {
     int   oqoff;
     int   it_per;             // O_PART: K-steps per split (blockIdx.y = split index)
     int   hdH, hdd, hdT, hdTpad, hddpad;   // O_HROWS / O_HTR: heads, head dim, tokens per sample, padded dims
+    unsigned hdrcp;           // ceil(2^32 / hdd): n / hdd == umulhi(n, hdrcp) for n < 2^16 (host checks Cout)
     float oqpre;              // O_HROWS / O_HTR: multiplier applied before the output quantiser
     int32_t* hdsum;           // O_HTR: [(b*H+h)][dpad] column sums of the stored bytes (atomically accumulated)
     float* gnpart;            // O_F32, optional: per-(sample, 128-row chunk, channel) {sum, sum of squares} of the output,
@@ -211,8 +212,11 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
     int seg_c0 = p.seg[0].c0, seg_clen = p.seg[0].clen, seg_nst = p.seg[0].nsteps_tap;
     const int8_t* zero16 = reinterpret_cast<const int8_t*>(qd_zero16);
     const int8_t* seg_fill = p.seg[0].fill16 ? p.seg[0].fill16 : zero16;
-    int ltap = it_begin / seg_nst, lc = it_begin - ltap * seg_nst;
-    int lrr = ltap / p.kw, lq = ltap - lrr * p.kw;
+    int ltap = 0, lc = 0, lrr = 0, lq = 0;           // only split-K partials start in the middle of the K range
+    if constexpr (OUT == O_PART) {
+        ltap = it_begin / seg_nst; lc = it_begin - ltap * seg_nst;
+        lrr = ltap / p.kw; lq = ltap - lrr * p.kw;
+    }
     int krem = seg_clen - lc * 64;                // channels left in this tap from the next K-step on (>= 64: no K tail in it)
     const int8_t* a_cur[NA];                      // source of the NEXT K-step for DMA instruction i
     int           a_inc[NA];                      // 64 for real pixels, 0 for fill / zero sources
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
             const int n4 = wcol0 + j * 32 + c4;        // first of this lane's 4 columns in phase 2
             const bool nok = n4 < p.Cout;
             const int nn = nok ? n4 : 0;
-            const int h = nn / p.hdd, dd = nn - h * p.hdd;
+            const int h = (int)__umulhi((unsigned)nn, p.hdrcp), dd = nn - h * p.hdd;     // nn / hdd (exact: nn < 2^16)
             int8_t* ob = o8 + (((long)bidx * p.hdH + h) * p.hdTpad + t0) * p.hddpad + dd;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -621,7 +625,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
             const int cl = wn * WCOLS + j * 32 + frow;
             const bool nok = n0 + cl < p.Cout;
             const int nn = nok ? n0 + cl : 0;
-            const int h = nn / p.hdd, dd = nn - h * p.hdd;
+            const int h = (int)__umulhi((unsigned)nn, p.hdrcp), dd = nn - h * p.hdd;     // nn / hdd (exact: nn < 2^16)
             const float sc = sScale[cl];
             const int zc_n = sZc[cl], zw_n = sZw[cl];
             const float bias_n = sBias[cl];
@@ -1057,6 +1061,8 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
         k.oq = d->oq_params; k.oqmin = (float)d->oq_min; k.oqmax = (float)d->oq_max; k.oqoff = d->oq_off;
         k.hdH = d->hd_H; k.hdd = d->hd_d; k.hdT = d->hd_T; k.hdTpad = d->hd_Tpad; k.hddpad = d->hd_dpad;
         k.oqpre = d->oq_prescale; k.hdsum = d->hd_sum;
+        QD_REQUIRE(d->Cout < 65536, "qd_conv2d_i8: heads epilogue: Cout must be < 65536");
+        k.hdrcp = (unsigned)((0x100000000ULL + (unsigned)d->hd_d - 1) / (unsigned)d->hd_d);
     }
     if (d->gn_part) {
         QD_REQUIRE(!iout && !heads && !geglu && d->out_dtype == QD_F32, "qd_conv2d_i8: gn_part needs the plain fp32 epilogue");
