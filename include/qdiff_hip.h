@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 11
+#define QD_ABI_VERSION 12
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -329,6 +329,21 @@ int qd_bmm_qk_i8(const int8_t* q, const int8_t* k, int BH, int T, int S, int d, 
 int qd_bmm_pv_i8(const float* w, int64_t ldw, int64_t wbstride, const int8_t* vt, const int32_t* vsum,
                  int BH, int T, int S, int d, int Spad, int dpad, const float* prm, int wbits, int wmin, int wmax,
                  float* out, int64_t ldo, int64_t obstride, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Calibration: fused fake-quantisation of an activation tensor, forward and backward, for the
+ *     step-size phase of block / layer reconstruction (qdiff/block_recon.py:72-110 trains `delta` by autograd through
+ *     UniformAffineQuantizer.forward, quant_layer.py:82-88, with the straight-through rounding of :16-20).
+ *     y      = (clamp(rint(x / delta) + zp, qmin, qmax) - zp) * delta
+ *     gx     = d(loss)/dx       (the gradient passes where the un-clamped code lies in [qmin, qmax])
+ *     gdelta_part[b] = block b's share of d(loss)/d(delta); the caller sums qd_fakequant_blocks(n) partials.
+ *     delta / zero_point are device scalars (the reference keeps them as tensors / Parameters).  fp32 only.
+ * ------------------------------------------------------------------------------------------ */
+int64_t qd_fakequant_blocks(int64_t n);
+int qd_fakequant_fwd(const float* x, int64_t n, const float* delta, const float* zero_point, int qmin, int qmax, float* y,
+                     void* stream);
+int qd_fakequant_bwd(const float* x, const float* gy, int64_t n, const float* delta, const float* zero_point, int qmin, int qmax,
+                     float* gx, float* gdelta_part, void* stream);
 
 #ifdef __cplusplus
 }

@@ -64,7 +64,8 @@ EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_make_qparams",
            "qd_pack_weights_t8",
            "qd_conv2d_i8", "qd_conv2d_i8_splitk_ws_bytes",
            "qd_conv2d_i8_acc", "qd_groupnorm_ws_bytes", "qd_groupnorm_silu_quant", "qd_layernorm_quant",
-           "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8", "qd_bmm_qk_i8", "qd_bmm_pv_i8", "qd_temb_mlp"]
+           "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8", "qd_bmm_qk_i8", "qd_bmm_pv_i8", "qd_temb_mlp",
+           "qd_fakequant_blocks", "qd_fakequant_fwd", "qd_fakequant_bwd"]
 
 _lib = None
 
@@ -104,7 +105,11 @@ def load():
     lib.qd_temb_mlp.argtypes = [vp, i64, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i64, vp]
     lib.qd_bmm_qk_i8.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i64, i64, vp]
     lib.qd_bmm_pv_i8.argtypes = [vp, i64, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i64, i64, vp]
-    if lib.qd_abi_version() != 11:
+    lib.qd_fakequant_blocks.restype = ctypes.c_int64
+    lib.qd_fakequant_blocks.argtypes = [i64]
+    lib.qd_fakequant_fwd.argtypes = [vp, i64, vp, vp, i32, i32, vp, vp]
+    lib.qd_fakequant_bwd.argtypes = [vp, vp, i64, vp, vp, i32, i32, vp, vp, vp]
+    if lib.qd_abi_version() != 12:
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -376,6 +381,23 @@ def bmm_pv_i8(w, v8t, vsum, BH, T, S, d, Spad, dpad, prm, wbits, wmin, wmax, out
     """w [BH][T][S] fp32 probabilities -> quantised (prm[3..6]) -> out [BH][d][T] fp32."""
     _check(load().qd_bmm_pv_i8(_ptr(w), w.stride(1), w.stride(0), _ptr(v8t), _ptr(vsum), BH, T, S, d, Spad, dpad, _ptr(prm),
                                wbits, wmin, wmax, _ptr(out), out.stride(1), out.stride(0), _stream()), "qd_bmm_pv_i8")
+
+
+def fakequant_fwd(x, delta, zero_point, qmin, qmax):
+    """y = (clamp(rint(x / delta) + zp, qmin, qmax) - zp) * delta, one launch (calibration: qdiff/quant_layer.FusedFakeQuant)."""
+    y = torch.empty_like(x)
+    _check(load().qd_fakequant_fwd(_ptr(x, "x"), x.numel(), _ptr(delta, "delta"), _ptr(zero_point, "zero_point"), int(qmin), int(qmax),
+                                   _ptr(y), _stream()), "qd_fakequant_fwd")
+    return y
+
+
+def fakequant_bwd(x, gy, delta, zero_point, qmin, qmax):
+    """(d loss / dx, d loss / d delta) of fakequant_fwd given d loss / dy."""
+    gx = torch.empty_like(x)
+    part = torch.empty(int(load().qd_fakequant_blocks(x.numel())), dtype=torch.float32, device=x.device)
+    _check(load().qd_fakequant_bwd(_ptr(x, "x"), _ptr(gy, "gy"), x.numel(), _ptr(delta, "delta"), _ptr(zero_point, "zero_point"),
+                                   int(qmin), int(qmax), _ptr(gx), _ptr(part), _stream()), "qd_fakequant_bwd")
+    return gx, part.sum()
 
 
 class _TembLayer(ctypes.Structure):

@@ -15,6 +15,8 @@ import logging
 import warnings
 from typing import Union
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -43,6 +45,32 @@ def lp_loss(pred, tgt, p=2.0, reduction='none'):
     """L_p reconstruction loss (reference quant_layer.py:26-33)."""
     err = (pred - tgt).abs().pow(p)
     return err.sum(1).mean() if reduction == 'none' else err.mean()
+
+
+class FusedFakeQuant(torch.autograd.Function):
+    """y = (clamp(round_ste(x / delta) + zp, lo, hi) - zp) * delta as ONE HIP launch forward and ONE backward
+    (csrc/fakequant.hip) instead of the ~18 elementwise kernels autograd runs for the composition — the activation phase
+    of calibration differentiates this expression for every quantised activation of a unit, every iteration
+    (reference block_recon.py:72-110, quant_layer.py:82-88).  Same arithmetic operation by operation: y and dL/dx are
+    bit-identical to the composition, dL/d(delta) differs by summation order only."""
+
+    @staticmethod
+    def forward(ctx, x, delta, zp, lo, hi):
+        from . import hip
+        xc = x.contiguous()
+        ctx.save_for_backward(xc, delta, zp)
+        ctx.grid = (lo, hi)
+        return hip.fakequant_fwd(xc, delta, zp, lo, hi).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import hip
+        x, delta, zp = ctx.saved_tensors
+        gx, gd = hip.fakequant_bwd(x, gy.contiguous(), delta, zp, *ctx.grid)
+        return gx.view(gy.shape), gd.reshape(delta.shape), None, None, None
+
+
+FUSED_FAKEQUANT = os.environ.get("QDIFF_FUSED_FAKEQUANT", "1") != "0"
 
 
 class UniformAffineQuantizer(nn.Module):
@@ -92,6 +120,12 @@ class UniformAffineQuantizer(nn.Module):
         if self.running_stat:
             self.act_momentum_update(x)
         lo, hi = self.code_range()
+        if (FUSED_FAKEQUANT and x.is_cuda and torch.is_grad_enabled() and x.dtype == torch.float32 and torch.is_tensor(self.delta)
+                and self.delta.numel() == 1 and self.delta.dtype == torch.float32 and (x.requires_grad or self.delta.requires_grad)):
+            # calibration on the GPU (autograd through the quantiser): fused forward / backward kernels
+            zp = self.zero_point
+            zp = zp.detach().reshape(1).float() if torch.is_tensor(zp) else torch.full((1,), float(zp), device=x.device)
+            return FusedFakeQuant.apply(x, self.delta, zp, lo, hi)
         codes = torch.clamp(round_ste(x / self.delta) + self.zero_point, lo, hi)
         return (codes - self.zero_point) * self.delta
 

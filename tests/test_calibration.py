@@ -169,3 +169,49 @@ def test_calibrate_then_resume_round_trip(tmp_path):
         with torch.no_grad():
             got = q2(*test)
     assert torch.equal(got, want)
+
+
+def _dp_worker(rank, world, port, out_dir):
+    """Data-parallel calibration: each rank reconstructs the same unit on ITS half of the calibration samples; gradients
+    are averaged with an all-reduce every iteration (recon.reconstruct(multi_gpu=True)), so the trained parameters stay
+    identical on all ranks although the data differ."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import qdiff
+    from qdiff.adaptive_rounding import AdaRoundQuantizer
+    from qdiff.quant_block import QuantResnetBlock
+    fx = load_fixture("recon_cifar_tiny.pt")
+    spec = fx["spec"]
+    wq, aq = quant_params(spec)
+    xs, ts, _ = _inputs(spec, 16, 300)
+    qnn = qdiff.QuantModel(build_engine_model(spec), wq, aq, sm_abit=spec["sm_abit"]).eval()
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(xs[:8], ts[:8])                               # same initialisation batch on every rank
+    sel = slice(rank * 8, rank * 8 + 8)                   # ... but each rank calibrates on its own shard
+    blk = [m for m in qnn.modules() if isinstance(m, QuantResnetBlock)][1]
+    torch.manual_seed(11)                                 # same mini-batch index sequence (indices into different shards)
+    qdiff.block_reconstruction(qnn, blk, (xs[sel], ts[sel]), batch_size=4, iters=4, weight=0.01, asym=True, warmup=0.2,
+                               act_quant=False, opt_mode='mse', multi_gpu=True)
+    alphas = {k: m.alpha.detach().clone() for k, m in blk.named_modules() if isinstance(m, AdaRoundQuantizer)}
+    torch.save(alphas, os.path.join(out_dir, f"alphas_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_calibration_two_ranks_gloo(tmp_path):
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a0 = torch.load(os.path.join(tmp_path, "alphas_0.pt"))
+    a1 = torch.load(os.path.join(tmp_path, "alphas_1.pt"))
+    assert len(a0) >= 2 and set(a0) == set(a1)
+    for k in a0:
+        assert torch.equal(a0[k], a1[k]), k               # averaged gradients -> identical Adam trajectories

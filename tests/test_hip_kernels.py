@@ -801,3 +801,32 @@ def test_temb_mlp_equals_generic_path(cuda, w_bits, B, K, widths):
             else:
                 bad = (got != want).float().mean().item()
                 assert bad <= 2e-2 and (got - want).abs().max().item() <= 2e-3 * want.abs().max().item(), (bad,)
+
+
+@pytest.mark.parametrize("sym,shape", [(False, (4, 320, 32, 32)), (True, (3, 77, 768)), (False, (5, 1031))])
+def test_fused_fakequant_forward_backward_matches_autograd(cuda, sym, shape):
+    """csrc/fakequant.hip vs the autograd composition of UniformAffineQuantizer.forward (reference quant_layer.py:82-88 with
+    round_ste :16-20): y and dL/dx bit-identical, dL/d(delta) to summation order (1e-5 relative)."""
+    from qdiff import quant_layer as ql
+    g = torch.Generator().manual_seed(91)
+    x = (torch.randn(shape, generator=g) * 1.3).to(cuda)
+    w = torch.randn(shape, generator=g).to(cuda)
+    q = ql.UniformAffineQuantizer(n_bits=8, symmetric=sym, channel_wise=False, scale_method="max", leaf_param=True)
+    with torch.no_grad():
+        q(x * 0.8)                                            # data-dependent init on a narrower tensor: some codes clamp
+    res = {}
+    for fused in (False, True):
+        ql.FUSED_FAKEQUANT = fused
+        xi = x.clone().requires_grad_(True)
+        q.delta.grad = None
+        y = q(xi)
+        (y * w).sum().backward()
+        res[fused] = (y.detach().clone(), xi.grad.clone(), q.delta.grad.clone())
+    ql.FUSED_FAKEQUANT = True
+    assert torch.equal(res[True][0], res[False][0])
+    assert torch.equal(res[True][1], res[False][1])
+    gd_f, gd_c = res[True][2].double(), res[False][2].double()
+    assert abs(float(gd_f - gd_c)) <= 1e-5 * abs(float(gd_c)) + 1e-6, (float(gd_f), float(gd_c))
+    lo, hi = q.code_range()
+    codes = torch.round(x / q.delta.detach()) + (q.zero_point if torch.is_tensor(q.zero_point) else float(q.zero_point))
+    assert bool(((codes < lo) | (codes > hi)).any()), "the test tensor never clamps"
