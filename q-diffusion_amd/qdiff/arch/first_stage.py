@@ -250,11 +250,22 @@ def lsun_beds_first_stage():
 
 
 @torch.no_grad()
-def decode_first_stage(first_stage, z, scale_factor=1.0, force_not_quantize=False, autocast_dtype=None, to_uint8=False):
+def decode_first_stage(first_stage, z, scale_factor=1.0, force_not_quantize=False, autocast_dtype=None, to_uint8=False,
+                       max_activation_bytes=1 << 30):
     """`LatentDiffusion.decode_first_stage` (ddpm.py:710-770, the un-tiled branch): images = decode(z / scale_factor).
     On the GPU the latents go channels-last (MIOpen NHWC convolutions); `autocast_dtype` reproduces the reference scripts'
     `precision=autocast` mode; `to_uint8` applies the scripts' clamp((x + 1) / 2, 0, 1) * 255 post-processing
-    (txt2img.py: `torch.clamp((x_samples + 1.0) / 2.0, min=0.0, max=1.0)`) on the device."""
+    (txt2img.py: `torch.clamp((x_samples + 1.0) / 2.0, min=0.0, max=1.0)`) on the device.
+    The batch is decoded in chunks whose largest activation (ch x H_out x W_out fp32 per image) stays below
+    `max_activation_bytes`: library convolutions index with 32-bit byte offsets, and 64 LDM-4 images put exactly 2^31 bytes
+    into one tensor (measured: a GPU memory fault inside the convolution; the reference decodes its small script batches)."""
+    dec = first_stage.decoder
+    up = 2 ** (dec.num_resolutions - 1)
+    per_image = dec.ch * z.shape[2] * up * z.shape[3] * up * 4
+    chunk = max(1, int(max_activation_bytes // max(per_image, 1)))
+    if z.shape[0] > chunk:
+        return torch.cat([decode_first_stage(first_stage, z[i:i + chunk], scale_factor, force_not_quantize, autocast_dtype, to_uint8,
+                                             max_activation_bytes) for i in range(0, z.shape[0], chunk)], dim=0)
     z = (1.0 / scale_factor) * z
     if z.is_cuda:
         z = z.contiguous(memory_format=torch.channels_last)

@@ -545,6 +545,52 @@ def head_buffers(device, BH, T, S, d):
     return bufs
 
 
+# V^T column sums (hd_sum of QD_EPI_HEADS_T_I8) are ACCUMULATED by the projection epilogue, so they must be zero when it
+# starts.  One memset per attention block per evaluation (16 tiny launches in SD) becomes one: every block owns a slice of
+# a per-device arena that QuantModel's forward pre-hook zeroes once per UNet evaluation (begin_evaluation); a block whose
+# slice is not known to be clean — called outside a QuantModel evaluation, or twice in one — zeroes it itself.
+_VSUM = {}
+_VSUM_ARENA_INTS = 4 << 20
+
+
+def vsum_slice(owner, device, shape):
+    """int32 tensor of `shape` for `owner` (any hashable), carved out of the device arena."""
+    st = _VSUM.get(device)
+    if st is None:
+        st = _VSUM[device] = dict(arena=torch.zeros(_VSUM_ARENA_INTS, dtype=torch.int32, device=device), used=0, views={}, clean=set())
+    key = (owner, tuple(shape))
+    v = st["views"].get(key)
+    if v is None:
+        n = 1
+        for e in shape:
+            n *= e
+        n_pad = (n + 63) // 64 * 64
+        if st["used"] + n_pad > st["arena"].numel():
+            v = torch.zeros(shape, dtype=torch.int32, device=device)         # arena exhausted: a buffer of its own
+        else:
+            v = st["arena"][st["used"]:st["used"] + n].view(shape)
+            st["used"] += n_pad
+            st["clean"].add(id(v))                                            # the arena starts zeroed
+        st["views"][key] = v
+    return v
+
+
+def begin_evaluation():
+    """Start of a UNet evaluation (QuantModel forward pre-hook): one memset for all attention blocks' V^T column sums."""
+    for st in _VSUM.values():
+        if st["used"]:
+            st["arena"][:st["used"]].zero_()
+            st["clean"] = {id(v) for v in st["views"].values() if v.untyped_storage().data_ptr() == st["arena"].untyped_storage().data_ptr()}
+
+
+def _vsum_prepare(vsum):
+    st = _VSUM.get(vsum.device)
+    if st is not None and id(vsum) in st["clean"]:
+        st["clean"].discard(id(vsum))
+        return
+    vsum.zero_()
+
+
 def heads_fusable(plan, T, H):
     """The projection `plan` can write its output directly as attention operand bytes (QD_EPI_HEADS_*)."""
     return bool(plan.pack.tiled and plan.pack.wbits == 4 and len(plan.segs) == 1 and T % 128 == 0 and plan.Cout % H == 0
@@ -556,7 +602,7 @@ def project_heads(plan, xq, B, T, H, ap, which, out8, vsum=None):
     own act quantiser inside the GEMM epilogue and stored in the operand layout of the attention kernel."""
     d = plan.Cout // H
     if which == 2:
-        vsum.zero_()
+        _vsum_prepare(vsum)
     call = hip.ConvCall(x=xq, w=plan.pack.wq, out=out8, bias=plan.bias, ldx=plan.ldx, ldk=plan.pack.ldk, ldo=0,
                         B=B, H=1, W=T, Ho=1, Wo=T, Cout=plan.Cout, kh=1, kw=1, stride=1, pad_t=0, pad_l=0,
                         wbits=plan.pack.wbits, w_tiled=True, segs=plan.segs,

@@ -671,6 +671,8 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
         inner = att.to_q.conv_plan().Cout
         d = inner // h
         q8, k8, v8, vsum = engine.head_buffers(rows.device, B * h, T, S, d)
+        if kv is None:
+            vsum = engine.vsum_slice(id(att), rows.device, tuple(vsum.shape))   # this block's own slice of the per-evaluation arena
         if kv is not None:
             k8, v8, vsum = kv
 

@@ -9,6 +9,8 @@ reference's.  On top of the reference surface it offers
 import logging
 
 import torch
+
+from . import engine
 import torch.nn as nn
 
 from types import MethodType
@@ -80,7 +82,7 @@ class QuantModel(nn.Module):
         for m in self.model.modules():
             if isinstance(m, QuantBasicTransformerBlock):
                 ctx.register(m)
-        self.model.register_forward_pre_hook(lambda _m, _a: (group.reset(), ctx.reset()) and None)
+        self.model.register_forward_pre_hook(lambda _m, _a: (group.reset(), ctx.reset(), engine.begin_evaluation()) and None)
         te = getattr(self.model, "time_embed", None)
         if (isinstance(te, nn.Sequential) and len(te) == 3 and isinstance(te[0], QuantModule) and isinstance(te[2], QuantModule)
                 and isinstance(te[1], nn.SiLU)):

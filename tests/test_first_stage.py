@@ -103,3 +103,17 @@ def test_decoder_on_gpu_matches_the_reference_golden(cuda):
         m = _build(case, kind).to(cuda)
         out = fs.decode_first_stage(m, case["z"].to(cuda), 1.0, force_not_quantize=True)
         assert (out.cpu() - case["out"]).abs().max().item() <= 1e-4 * case["out"].abs().max().item()
+
+
+def test_decode_chunks_large_batches():
+    """decode_first_stage splits the batch so that no activation exceeds max_activation_bytes; results are those of the
+    unsplit call."""
+    from qdiff.arch import first_stage as fs
+    fx = load_fixture("first_stage.pt")
+    case = fx["kl_tiny"]
+    m = _build(case, "kl")
+    z = torch.cat([case["z"], case["z"] * 0.5, -case["z"]], dim=0)           # 6 latents
+    whole = fs.decode_first_stage(m, z, 1.0)
+    per_image = m.decoder.ch * 32 * 32 * 4
+    parts = fs.decode_first_stage(m, z, 1.0, max_activation_bytes=2 * per_image)   # chunks of 2
+    assert parts.shape == whole.shape and torch.equal(parts, whole)
