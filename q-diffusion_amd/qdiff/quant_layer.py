@@ -58,6 +58,8 @@ class FusedFakeQuant(torch.autograd.Function):
     def forward(ctx, x, delta, zp, lo, hi):
         from . import hip
         xc = x.contiguous()
+        if xc.data_ptr() % 16:                             # a contiguous VIEW at an odd offset: the kernels use 16-byte accesses
+            xc = xc.clone()
         ctx.save_for_backward(xc, delta, zp)
         ctx.grid = (lo, hi)
         return hip.fakequant_fwd(xc, delta, zp, lo, hi).view(x.shape)
@@ -66,7 +68,10 @@ class FusedFakeQuant(torch.autograd.Function):
     def backward(ctx, gy):
         from . import hip
         x, delta, zp = ctx.saved_tensors
-        gx, gd = hip.fakequant_bwd(x, gy.contiguous(), delta, zp, *ctx.grid)
+        gy = gy.contiguous()
+        if gy.data_ptr() % 16:
+            gy = gy.clone()
+        gx, gd = hip.fakequant_bwd(x, gy, delta, zp, *ctx.grid)
         return gx.view(gy.shape), gd.reshape(delta.shape), None, None, None
 
 

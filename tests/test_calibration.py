@@ -215,3 +215,37 @@ def test_data_parallel_calibration_two_ranks_gloo(tmp_path):
     assert len(a0) >= 2 and set(a0) == set(a1)
     for k in a0:
         assert torch.equal(a0[k], a1[k]), k               # averaged gradients -> identical Adam trajectories
+
+
+@pytest.mark.gpu
+def test_calibration_runs_on_the_gpu(cuda, tmp_path):
+    """The whole calibration sequence on the MI355X (HBM-resident unit caches, fused fake-quant kernels in the step-size
+    phase), then the checkpoint it wrote drives the INTEGER engine: keys as produced on the CPU, finite values, and the
+    integer evaluation of the calibrated model close to its fp32 simulation (bound: the envelope of DESIGN.md §6)."""
+    import qdiff
+    from qdiff import engine
+    from qdiff.calibrate import calibrate_model
+    from qdiff.utils import resume_cali_model
+    fx = load_fixture("recon_cifar_tiny.pt")
+    spec = fx["spec"]
+    wq, aq = quant_params(spec)
+    xs, ts, _ = _inputs(spec, 8, 300)
+    test = tuple(a.to(cuda) for a in _inputs(spec, 2, 200) if a is not None)
+    qnn = qdiff.QuantModel(build_engine_model(spec).to(cuda), wq, aq, sm_abit=spec["sm_abit"]).to(cuda).eval()
+    torch.manual_seed(7)
+    np.random.seed(7)
+    sd = calibrate_model(qnn, (xs, ts), cond=False, quant_act=True, cali_batch_size=4, cali_iters=2, cali_iters_a=2, act_init_batch=4)
+    assert any(k.endswith("weight_quantizer.alpha") for k in sd) and any(k.endswith("act_quantizer.delta") for k in sd)
+    assert all(torch.isfinite(v.float()).all() for v in sd.values() if torch.is_tensor(v) and v.is_floating_point())
+    qnn.eval()
+    with torch.no_grad(), engine.simulation():
+        sim = qnn(*test).float().cpu()
+    path = tmp_path / "ckpt.pth"
+    torch.save({k: v.cpu() for k, v in sd.items()}, path)
+    q2 = qdiff.QuantModel(build_engine_model(spec).to(cuda), wq, aq, sm_abit=spec["sm_abit"]).to(cuda).eval()
+    resume_cali_model(q2, str(path), (xs[:1], ts[:1]), quant_act=True, cond=False)
+    with torch.no_grad():
+        got = q2(*test).float().cpu()                       # integer engine
+    assert torch.isfinite(got).all()
+    cos = torch.nn.functional.cosine_similarity(got.flatten(), sim.flatten(), dim=0).item()
+    assert (got - sim).abs().max().item() <= 0.15 * sim.abs().max().item() and cos >= 0.99, cos
