@@ -335,12 +335,14 @@ def reference_classes():
         out.update(ResBlock=ref_oai.ResBlock, AttentionBlock=ref_oai.AttentionBlock, QKMatMul=ref_oai.QKMatMul,
                    SMVMatMul=ref_oai.SMVMatMul, BasicTransformerBlock=ref_att.BasicTransformerBlock,
                    TimestepBlock=ref_oai.TimestepBlock, SpatialTransformer=ref_att.SpatialTransformer,
-                   Upsample=ref_oai.Upsample, UNetModel=ref_oai.UNetModel)
+                   Upsample=ref_oai.Upsample, Downsample=ref_oai.Downsample, UNetModel=ref_oai.UNetModel,
+                   TimestepEmbedSequential=ref_oai.TimestepEmbedSequential)
     except Exception:  # noqa: BLE001 - optional dependency
         pass
     try:
         from ddim.models import diffusion as ref_ddim
-        out.update(ResnetBlock=ref_ddim.ResnetBlock, AttnBlock=ref_ddim.AttnBlock)
+        out.update(ResnetBlock=ref_ddim.ResnetBlock, AttnBlock=ref_ddim.AttnBlock, DdimModel=ref_ddim.Model,
+                   DdimUpsample=ref_ddim.Upsample, DdimDownsample=ref_ddim.Downsample)
     except Exception:  # noqa: BLE001
         pass
     if out:

@@ -7,6 +7,7 @@ reference's.  On top of the reference surface it offers
 `capture_graph()/forward` replay of a whole UNet evaluation as one HIP graph (qdiff/graph.py).
 """
 import logging
+import os
 
 import torch
 
@@ -19,7 +20,7 @@ from .quant_block import (BaseQuantBlock, ContextKV, EmbGroup, QuantAttentionBlo
                           QuantQKMatMul, QuantResBlock, QuantResnetBlock, QuantSMVMatMul, get_specials, reference_classes,
                           time_mlp)
 from .quant_layer import QuantModule, StraightThrough
-from .arch import ldm_unet
+from .arch import ddim_unet, ldm_unet
 
 logger = logging.getLogger(__name__)
 
@@ -94,9 +95,13 @@ class QuantModel(nn.Module):
         and state-dict keys, and get this repo's forward bound onto them —
           * SpatialTransformer: GroupNorm -> proj_in int8 rows, FF-out -> proj_out int8 rows, `+ x` in the epilogue;
           * Upsample: quantise the small map, replicate int8 rows;
-          * the skip concatenation `th.cat([h, hs.pop()], dim=1)` of UNetModel.forward (openaimodel.py:776) drops the
-            GroupNorm statistics that travel with the two producers' outputs: hooks on the input / middle / output
-            blocks keep a shadow stack of them and re-attach the concatenated statistics to the block input."""
+          * UNetModel / TimestepEmbedSequential / Downsample, in the INTEGER state only: this repo's walk
+            (arch/ldm_unet.py UNetModel.forward: planned skip-concatenation buffers, engine.CatSlot; the output head on the
+            integer path) — every other state runs the reference's own forward, bit for bit;
+          * should the reference's forward run on the integer path after all (`QDIFF_REF_WALK=1`): the skip concatenation
+            `th.cat([h, hs.pop()], dim=1)` (openaimodel.py:776) drops the GroupNorm statistics that travel with the two
+            producers' outputs: hooks on the input / middle / output blocks keep a shadow stack of them and re-attach the
+            concatenated statistics to the block input."""
         ref = reference_classes()
         st, up = ref.get("SpatialTransformer"), ref.get("Upsample")
         for m in self.model.modules():
@@ -104,9 +109,29 @@ class QuantModel(nn.Module):
                 m.forward = MethodType(ldm_unet.SpatialTransformer.forward, m)
             elif up is not None and type(m) is up and getattr(m, "dims", 2) == 2:
                 m.forward = MethodType(ldm_unet.Upsample.forward, m)
+        ddim = ref.get("DdimModel")
+        if ddim is not None and type(self.model) is ddim and os.environ.get("QDIFF_REF_WALK", "0") != "1":
+            # the reference's DDIM `Model` (ddim/models/diffusion.py:199-348): same treatment, integer state only
+            qm, model, ref_forward = self, self.model, self.model.forward
+
+            def ddim_forward(m, x, t=None, context=None):
+                if qm._quant_state == (True, True) and not torch.is_grad_enabled() and not engine.SIMULATE:
+                    return ddim_unet.Model.forward(m, x, t, context)
+                return ref_forward(x, t, context)
+            model.forward = MethodType(ddim_forward, model)
+            for m in model.modules():
+                if type(m) is ref.get("DdimUpsample"):
+                    m.forward = MethodType(ddim_unet.Upsample.forward, m)
+                    m.qd_takes_out_slot = True
+                elif type(m) is ref.get("DdimDownsample"):
+                    m.forward = MethodType(ddim_unet.Downsample.forward, m)
+                    m.qd_takes_out_slot = True
+            return
         unet = ref.get("UNetModel")
         if unet is None or type(self.model) is not unet:
             return
+        if os.environ.get("QDIFF_REF_WALK", "0") != "1":
+            self._adopt_reference_walk(ref)
         state = {"stack": [], "last": None}
 
         def part_of(t):
@@ -124,6 +149,8 @@ class QuantModel(nn.Module):
         def reattach(_m, args):
             pb = state["stack"].pop() if state["stack"] else None
             pa, h = state["last"], args[0]
+            if torch.is_tensor(h) and getattr(h, "qd_gn_part", None) is not None:
+                return                                     # this repo's walk already concatenated the statistics (as a view)
             if pa is not None and pb is not None and torch.is_tensor(h) and pa.shape[0] * pa.shape[1] == pb.shape[0] * pb.shape[1] \
                     and pa.shape[2] + pb.shape[2] == h.shape[1]:
                 n = pa.shape[0] * pa.shape[1]
@@ -136,6 +163,43 @@ class QuantModel(nn.Module):
         for blk in self.model.output_blocks:
             blk.register_forward_pre_hook(reattach)
             blk.register_forward_hook(keep_last)
+
+    def _adopt_reference_walk(self, ref):
+        """Bind this repo's UNet walk onto the reference's UNetModel for the integer state (see _adopt_reference_modules)."""
+        qm, model = self, self.model
+        ref_forward = model.forward                        # bound method of the reference class
+        ref_st, ref_seq, ref_down = ref.get("SpatialTransformer"), ref.get("TimestepEmbedSequential"), ref.get("Downsample")
+
+        def unet_forward(m, x, timesteps=None, context=None, y=None, **kw):
+            if (qm._quant_state == (True, True) and not torch.is_grad_enabled() and not engine.SIMULATE
+                    and not getattr(m, "predict_codebook_ids", False)):
+                return ldm_unet.UNetModel.forward(m, x, timesteps, context, y, **kw)
+            return ref_forward(x, timesteps, context, y, **kw)
+
+        def seq_forward(seq, x, emb, context=None, split=0, out_slot=None):
+            last = len(seq) - 1
+            for i, layer in enumerate(seq):
+                kw = {"out_slot": out_slot} if (i == last and out_slot is not None and getattr(layer, "qd_takes_out_slot", False)) else {}
+                if isinstance(layer, ref["TimestepBlock"]):
+                    x = layer(x, emb, split=split, **kw)
+                elif ref_st is not None and isinstance(layer, ref_st):
+                    x = layer(x, context, **kw)
+                else:
+                    x = layer(x, **kw)
+            return x
+
+        model.forward = MethodType(unet_forward, model)
+        model._out = MethodType(ldm_unet.UNetModel._out, model)
+        for m in model.modules():
+            if ref_seq is not None and type(m) is ref_seq:
+                m.forward = MethodType(seq_forward, m)
+            elif ref_st is not None and type(m) is ref_st:
+                m.qd_takes_out_slot = True                 # its forward is this repo's SpatialTransformer.forward
+            elif ref_down is not None and type(m) is ref_down and getattr(m, "dims", 2) == 2:
+                m.forward = MethodType(ldm_unet.Downsample.forward, m)
+                m.qd_takes_out_slot = True
+            elif ref.get("Upsample") is not None and type(m) is ref["Upsample"] and getattr(m, "dims", 2) == 2:
+                m.qd_takes_out_slot = True
 
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
         self._quant_state = (bool(weight_quant), bool(act_quant))

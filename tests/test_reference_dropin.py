@@ -146,3 +146,42 @@ def test_groupnorm_statistics_survive_the_reference_cat(monkeypatch):
     # decoder ResBlocks at 16x16 (256 rows per sample) see concatenated inputs of 64 / 96 channels
     cat_inputs = [(C, part) for C, part in calls if C in (64, 96)]
     assert cat_inputs and any(part for _, part in cat_inputs), cat_inputs
+
+
+@pytest.mark.parametrize("name", ["sd_tiny", "ldm_tiny", "cifar_tiny"])
+def test_reference_unet_takes_the_planned_concatenation_walk(monkeypatch, name):
+    """On the REFERENCE's UNetModel the integer state runs this repo's walk (QuantModel._adopt_reference_walk): from the
+    second evaluation on every skip concatenation is a view (no `cat` copy of activations), and the output equals the one
+    obtained through the reference's own forward + th.cat (QDIFF_REF_WALK=1) bit for bit."""
+    from qdiff import quant_block as qb
+    abi_emulator.install(monkeypatch)
+    fx = load_fixture(f"model_{name}.pt")
+    x, t, c = fixture_inputs(fx, "test")
+    run = lambda q: (q(x, t, c) if c is not None else q(x, t))
+    monkeypatch.setenv("QDIFF_REF_WALK", "1")
+    q_ref = _wrap_and_resume(fx)
+    with torch.no_grad():
+        want = run(q_ref)
+    monkeypatch.delenv("QDIFF_REF_WALK")
+    qnn = _wrap_and_resume(fx)
+    with torch.no_grad():
+        y0 = run(qnn)                                   # records the channel plan
+    views = {"n": 0, "cat": 0}
+    real_adj, real_cat = qb._adjacent, torch.cat
+
+    def adj(a, b, dim, unit):
+        out = real_adj(a, b, dim, unit)
+        if out is not None and dim == 1:
+            views["n"] += 1
+        return out
+
+    def cat(ts, dim=0, **kw):
+        if dim == 1 and len(ts) == 2 and ts[0].dim() == 4 and ts[0].is_floating_point():
+            views["cat"] += 1
+        return real_cat(ts, dim=dim, **kw)
+    monkeypatch.setattr(qb, "_adjacent", adj)
+    monkeypatch.setattr(torch, "cat", cat)
+    with torch.no_grad():
+        y1 = run(qnn)
+    assert views["n"] == len(qnn.model.__dict__["_cat_plan"]) and views["cat"] == 0, views
+    assert torch.equal(y0, want) and torch.equal(y1, want)
