@@ -25,7 +25,9 @@ logger = logging.getLogger(__name__)
 
 def recon_model(qnn, module=None, on_unit=None, **kwargs):
     """Block reconstruction over `module` (default: the whole QuantModel); the first and the last convolution, which are
-    bare QuantModules, get layer reconstruction.  `on_unit(name, unit)` is called after each unit (checkpointing hook: the
+    bare QuantModules, get layer reconstruction.  A QuantAttentionBlock built for quantised activations is walked INTO:
+    the reference leaves the LDM AttentionBlock unwrapped in that mode (quant_block.py:389-401), so its qkv / proj_out
+    layers and its QuantQKMatMul / QuantSMVMatMul blocks are reconstruction units of their own.  `on_unit(name, unit)` is called after each unit (checkpointing hook: the
     reference saves a temporary checkpoint before the output blocks, txt2img.py:422-428)."""
     module = qnn if module is None else module
     for name, child in module.named_children():
@@ -35,7 +37,7 @@ def recon_model(qnn, module=None, on_unit=None, **kwargs):
                 continue
             logger.info('Reconstruction for layer {}'.format(name))
             layer_reconstruction(qnn, child, **kwargs)
-        elif isinstance(child, BaseQuantBlock):
+        elif isinstance(child, BaseQuantBlock) and not getattr(child, "quant_matmuls", False):
             if child.ignore_reconstruction is True:
                 logger.info('Ignore reconstruction of block {}'.format(name))
                 continue

@@ -473,7 +473,7 @@ class QuantQKMatMul(BaseQuantBlock):
         self.act_quantizer_k = UniformAffineQuantizer(**act_quant_params)
 
     def forward(self, q, k):
-        if (self.use_act_quant and not torch.is_grad_enabled() and q.dim() == 3 and q.shape[1] % 4 == 0
+        if (self.use_act_quant and not torch.is_grad_enabled() and not engine.SIMULATE and q.dim() == 3 and q.shape[1] % 4 == 0
                 and _aq_ready(self.act_quantizer_q, self.act_quantizer_k) and not self.act_quantizer_q.running_stat
                 and self.act_quantizer_q.n_bits <= 8 and self.act_quantizer_k.n_bits <= 8):
             # standalone use (this module called outside the fused QuantAttentionBlock path): integer engine,
@@ -501,7 +501,7 @@ class QuantSMVMatMul(BaseQuantBlock):
         self.act_quantizer_w = UniformAffineQuantizer(**params_w)
 
     def forward(self, weight, v):
-        if (self.use_act_quant and not torch.is_grad_enabled() and v.dim() == 3 and v.shape[1] % 4 == 0
+        if (self.use_act_quant and not torch.is_grad_enabled() and not engine.SIMULATE and v.dim() == 3 and v.shape[1] % 4 == 0
                 and _aq_ready(self.act_quantizer_v, self.act_quantizer_w) and not self.act_quantizer_v.running_stat
                 and not self.act_quantizer_w.running_stat and self.act_quantizer_v.n_bits <= 8):
             return engine.smv_matmul_int(self.act_quantizer_w, self.act_quantizer_v, weight, v.float())
@@ -527,6 +527,10 @@ class QuantAttentionBlock(BaseQuantBlock, _AttnQuant):
         self.qkv = attn.qkv
         self.attention = attn.attention
         self.proj_out = attn.proj_out
+        # reference quant_model.py:45-61 + quant_block.py:389-401: with quantised activations the reference does NOT wrap the
+        # AttentionBlock (its qkv / proj_out QuantModules and the two Quant*MatMul blocks are separate units); calibration
+        # walks into this wrapper in that mode (qdiff/calibrate.recon_model) so that the units are the reference's
+        self.quant_matmuls = bool(quant_matmuls)
         if quant_matmuls:
             # quantised-activation mode: the two matmul modules inside QKVAttentionLegacy become their
             # quantised counterparts (what the reference's recursion does, quant_model.py:45-61)
