@@ -442,3 +442,39 @@ def test_planned_concatenation_is_a_view_and_changes_nothing(emu, name, monkeypa
         y2 = qnn(*args)
     assert calls["cat"] == n_cat and calls["view"] == 0 and calls["raw"] == 0, calls
     assert torch.equal(y1, y2)
+
+
+def test_cat_channels_only_takes_the_view_when_it_is_one():
+    """quant_block._adjacent must never call two tensors 'the two halves of one buffer' unless concatenating them IS the
+    strided view it returns: every near-miss falls back to the copy."""
+    from qdiff import engine, quant_block as qb
+    B, H, W, C1, C2 = 2, 4, 4, 8, 4
+    slot = engine.CatSlot(C1, C2)
+    dev = torch.device("cpu")
+    a = qb._rows_to_nchw(slot.rows(0, B * H * W, C1, dev), B, H, W)
+    b = qb._rows_to_nchw(slot.rows(1, B * H * W, C2, dev), B, H, W)
+    slot.buf.copy_(torch.arange(slot.buf.numel(), dtype=torch.float32).view_as(slot.buf))
+    v = qb.cat_channels(a, b)
+    assert v.data_ptr() == a.data_ptr() and torch.equal(v, torch.cat([a, b], dim=1))
+    assert torch.equal(qb._nhwc_rows(v), slot.buf) and qb._nhwc_rows(v).data_ptr() == slot.buf.data_ptr()
+    assert torch.equal(qb._nhwc_rows(b), slot.buf[:, C1:]) and qb._nhwc_rows(b).stride() == (C1 + C2, 1)
+    # near misses: wrong order, a gap, different buffers, a clone of one half, mismatching shapes / dtypes
+    assert qb._adjacent(b, a, 1, 1) is None
+    wide = engine.CatSlot(C1, C2 + 4)
+    wa = qb._rows_to_nchw(wide.rows(0, B * H * W, C1, dev), B, H, W)
+    wb = qb._rows_to_nchw(wide.buf[:, C1 + 4:], B, H, W)                     # same row stride, but a 4-channel gap
+    assert qb._adjacent(wa, wb, 1, 1) is None
+    other = engine.CatSlot(C1, C2)
+    ob = qb._rows_to_nchw(other.rows(1, B * H * W, C2, dev), B, H, W)
+    other.rows(0, B * H * W, C1, dev)
+    assert qb._adjacent(a, ob, 1, 1) is None
+    assert qb._adjacent(a, b.clone(), 1, 1) is None
+    assert qb._adjacent(a[:1], b, 1, 1) is None and qb._adjacent(a, b.double(), 1, 1) is None
+    # two plain contiguous NCHW tensors that happen to be neighbours in one allocation are NOT a channel concatenation
+    flat = torch.arange(2 * B * C1 * H * W, dtype=torch.float32)
+    p, q = flat[:B * C1 * H * W].view(B, C1, H, W), flat[B * C1 * H * W:].view(B, C1, H, W)
+    assert qb._adjacent(p, q, 1, 1) is None
+    for bad in ((b, a), (a, ob), (p, q)):
+        assert torch.equal(qb.cat_channels(*bad), torch.cat(list(bad), dim=1))
+    # a slot refuses producers of the wrong width / row count instead of mis-placing them
+    assert slot.rows(0, B * H * W, C1 + 1, dev) is None and slot.rows(1, B * H * W + 1, C2, dev) is None
