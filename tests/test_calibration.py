@@ -250,3 +250,24 @@ def test_calibration_runs_on_the_gpu(cuda, tmp_path):
     assert torch.isfinite(got).all()
     cos = torch.nn.functional.cosine_similarity(got.flatten(), sim.flatten(), dim=0).item()
     assert (got - sim).abs().max().item() <= 0.15 * sim.abs().max().item() and cos >= 0.99, cos
+
+
+@pytest.mark.parametrize("n_bits,shape", [(4, (48, 32, 3, 3)), (8, (40, 96)), (4, (16, 8, 1, 1))])
+def test_vectorised_mse_range_search_matches_the_per_channel_loop(n_bits, shape):
+    """UniformAffineQuantizer._init_mse_channelwise (all channels at once) vs the reference's per-channel loop
+    (quant_layer.py:138-140,162-177, reproduced by init_quantization_scale on the host): the same (delta, zero_point) for
+    every channel — except that a channel whose two best shrink factors score within fp32 summation noise may take the
+    neighbouring factor (allowed on <= 2 % of the channels, and then by exactly one 1 % step)."""
+    from qdiff import quant_layer as ql
+    g = torch.Generator().manual_seed(17)
+    w = torch.randn(shape, generator=g) * torch.rand(shape[0], *([1] * (len(shape) - 1)), generator=g)
+    q = ql.UniformAffineQuantizer(n_bits=n_bits, symmetric=False, channel_wise=True, scale_method="mse")
+    d_loop, z_loop = q.init_quantization_scale(w, channel_wise=True)
+    d_vec, z_vec = q._init_mse_channelwise(w)
+    assert d_loop.shape == d_vec.shape and z_loop.shape == z_vec.shape
+    same = (d_loop == d_vec).flatten() & (z_loop == z_vec).flatten()
+    assert same.float().mean().item() >= 0.98, same.float().mean().item()
+    off = ~same
+    if off.any():
+        ratio = (d_vec.flatten()[off] / d_loop.flatten()[off])
+        assert ((ratio - 1).abs() <= 0.015).all(), ratio
