@@ -57,19 +57,22 @@ def _to_dev(qnn, *ts):
 
 def calibrate_model(qnn, cali_data, cond=False, quant_act=True, cali_batch_size=32, cali_iters=20000, cali_iters_a=5000,
                     cali_lr=4e-4, cali_p=2.4, running_stat=False, rs_sm_only=False, init_batch=8, act_init_batch=16,
-                    resume_w=False, is_sm=False, on_unit=None):
+                    resume_w=False, is_sm=False, on_unit=None, multi_gpu=False):
     """The scripts' calibration sequence; returns the reference-format state dict (what `torch.save(qnn.state_dict())`
-    writes there after the Parameter wrapping of delta / zero_point).  cali_data = (xs, ts[, conds])."""
+    writes there after the Parameter wrapping of delta / zero_point).  cali_data = (xs, ts[, conds]).
+    multi_gpu: data-parallel calibration, one process per GPU (torch.distributed initialised by the caller, backend "nccl" =
+    RCCL): every rank passes ITS shard of the calibration samples and the same seed; gradients are averaged by an
+    all-reduce every iteration, so all ranks end with identical parameters (tests/test_calibration.py, 2 ranks over gloo)."""
     from . import engine
     from .utils import export_cali_state_dict
     with engine.simulation():           # quantiser initialisation and range tracking see the reference's fp32 arithmetic
         _calibrate(qnn, cali_data, cond, quant_act, cali_batch_size, cali_iters, cali_iters_a, cali_lr, cali_p, running_stat,
-                   rs_sm_only, init_batch, act_init_batch, resume_w, is_sm, on_unit)
+                   rs_sm_only, init_batch, act_init_batch, resume_w, is_sm, on_unit, multi_gpu)
     return export_cali_state_dict(qnn)
 
 
 def _calibrate(qnn, cali_data, cond, quant_act, cali_batch_size, cali_iters, cali_iters_a, cali_lr, cali_p, running_stat,
-               rs_sm_only, init_batch, act_init_batch, resume_w, is_sm, on_unit):
+               rs_sm_only, init_batch, act_init_batch, resume_w, is_sm, on_unit, multi_gpu=False):
     xs, ts = cali_data[0], cali_data[1]
     cs = cali_data[2] if cond else None
 
@@ -83,7 +86,7 @@ def _calibrate(qnn, cali_data, cond, quant_act, cali_batch_size, cali_iters, cal
         with torch.no_grad():
             run(slice(0, init_batch))
         kwargs = dict(cali_data=cali_data, batch_size=cali_batch_size, iters=cali_iters, weight=0.01, asym=True,
-                      b_range=(20, 2), warmup=0.2, act_quant=False, opt_mode='mse', cond=cond, is_sm=is_sm)
+                      b_range=(20, 2), warmup=0.2, act_quant=False, opt_mode='mse', cond=cond, is_sm=is_sm, multi_gpu=multi_gpu)
         logger.info("Doing weight calibration")
         recon_model(qnn, on_unit=on_unit, **kwargs)
         qnn.set_quant_state(weight_quant=True, act_quant=False)
@@ -102,6 +105,6 @@ def _calibrate(qnn, cali_data, cond, quant_act, cali_batch_size, cali_iters, cal
                     run(torch.as_tensor(order[i * act_init_batch:(i + 1) * act_init_batch]))
                 qnn.set_running_stat(False, rs_sm_only)
         kwargs = dict(cali_data=cali_data, batch_size=cali_batch_size, iters=cali_iters_a, act_quant=True, opt_mode='mse',
-                      lr=cali_lr, p=cali_p, cond=cond, is_sm=is_sm)
+                      lr=cali_lr, p=cali_p, cond=cond, is_sm=is_sm, multi_gpu=multi_gpu)
         recon_model(qnn, on_unit=on_unit, **kwargs)
         qnn.set_quant_state(weight_quant=True, act_quant=True)
