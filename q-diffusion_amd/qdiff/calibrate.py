@@ -50,6 +50,36 @@ def recon_model(qnn, module=None, on_unit=None, **kwargs):
             on_unit(name, child)
 
 
+def sync_quantisers(qnn, src=0):
+    """Data-parallel calibration: every rank initialised its quantisers from ITS shard; adopt rank `src`'s ranges (delta,
+    zero_point, the EMA range trackers) everywhere so that the averaged-gradient trajectories start from one point."""
+    import torch.distributed as dist
+    from .adaptive_rounding import AdaRoundQuantizer
+    from .quant_layer import UniformAffineQuantizer
+    quants = [m for m in qnn.modules() if isinstance(m, (UniformAffineQuantizer, AdaRoundQuantizer))]
+    names = ("delta", "zero_point", "x_min", "x_max", "inited")
+    payload = [None]
+    if dist.get_rank() == src:
+        cpu = lambda v: v.detach().cpu() if torch.is_tensor(v) else v
+        payload = [[{n: cpu(getattr(q, n, None)) for n in names} for q in quants]]
+    dist.broadcast_object_list(payload, src=src)
+    if dist.get_rank() != src:
+        dev = next(qnn.parameters()).device
+        for q, st in zip(quants, payload[0]):
+            for n in names:
+                if not hasattr(q, n) and st[n] is None:
+                    continue
+                v = st[n].to(dev) if torch.is_tensor(st[n]) else st[n]
+                if n == "delta" and torch.is_tensor(v) and getattr(q, "leaf_param", False):
+                    v = torch.nn.Parameter(v)                  # activation step sizes are trainable leaves
+                q._parameters.pop(n, None)
+                q.__dict__.pop(n, None)
+                setattr(q, n, v)
+    for m in qnn.modules():
+        if isinstance(m, QuantModule):
+            m.invalidate()
+
+
 def _to_dev(qnn, *ts):
     dev = next(qnn.parameters()).device
     return tuple(t.to(dev) for t in ts)
@@ -85,6 +115,8 @@ def _calibrate(qnn, cali_data, cond, quant_act, cali_batch_size, cali_iters, cal
         qnn.set_quant_state(True, False)
         with torch.no_grad():
             run(slice(0, init_batch))
+        if multi_gpu:
+            sync_quantisers(qnn)
         kwargs = dict(cali_data=cali_data, batch_size=cali_batch_size, iters=cali_iters, weight=0.01, asym=True,
                       b_range=(20, 2), warmup=0.2, act_quant=False, opt_mode='mse', cond=cond, is_sm=is_sm, multi_gpu=multi_gpu)
         logger.info("Doing weight calibration")
@@ -104,6 +136,8 @@ def _calibrate(qnn, cali_data, cond, quant_act, cali_batch_size, cali_iters, cal
                 for i in range(int(xs.size(0) / act_init_batch)):
                     run(torch.as_tensor(order[i * act_init_batch:(i + 1) * act_init_batch]))
                 qnn.set_running_stat(False, rs_sm_only)
+        if multi_gpu:
+            sync_quantisers(qnn)
         kwargs = dict(cali_data=cali_data, batch_size=cali_batch_size, iters=cali_iters_a, act_quant=True, opt_mode='mse',
                       lr=cali_lr, p=cali_p, cond=cond, is_sm=is_sm, multi_gpu=multi_gpu)
         recon_model(qnn, on_unit=on_unit, **kwargs)

@@ -198,6 +198,17 @@ def _dp_worker(rank, world, port, out_dir):
                                act_quant=False, opt_mode='mse', multi_gpu=True)
     alphas = {k: m.alpha.detach().clone() for k, m in blk.named_modules() if isinstance(m, AdaRoundQuantizer)}
     torch.save(alphas, os.path.join(out_dir, f"alphas_{rank}.pt"))
+    # the whole sequence, every rank on ITS shard from the very first (initialisation) batch on: the quantiser ranges of rank 0
+    # are adopted everywhere (calibrate.sync_quantisers), the gradients averaged -> one checkpoint on all ranks
+    from qdiff.calibrate import calibrate_model
+    q2 = qdiff.QuantModel(build_engine_model(spec), wq, aq, sm_abit=spec["sm_abit"]).eval()
+    torch.manual_seed(5)
+    np.random.seed(5)
+    sel4 = slice(rank * 8, rank * 8 + 8)
+    torch.set_num_threads(2)
+    sd = calibrate_model(q2, (xs[sel4], ts[sel4]), cond=False, quant_act=True, cali_batch_size=4, cali_iters=1, cali_iters_a=1,
+                         init_batch=4, act_init_batch=4, multi_gpu=True)
+    torch.save(sd, os.path.join(out_dir, f"sd_{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -216,6 +227,10 @@ def test_data_parallel_calibration_two_ranks_gloo(tmp_path):
     assert len(a0) >= 2 and set(a0) == set(a1)
     for k in a0:
         assert torch.equal(a0[k], a1[k]), k               # averaged gradients -> identical Adam trajectories
+    s0, s1 = torch.load(os.path.join(tmp_path, "sd_0.pt")), torch.load(os.path.join(tmp_path, "sd_1.pt"))
+    assert set(s0) == set(s1) and len(s0) > 100
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
 
 
 @pytest.mark.gpu
