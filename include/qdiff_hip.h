@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 12
+#define QD_ABI_VERSION 13
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -170,6 +170,12 @@ typedef struct {
 } qd_conv_desc;
 
 int qd_conv2d_i8(const qd_conv_desc* d, void* stream);
+
+/* EXPERIMENTAL, not used unless the host sets QDIFF_HALO=1: the same convolution for 3x3 / stride 1 / pad 1 layers with the
+ * activation patch of a block resident in LDS across the nine taps (csrc/igemm_halo.hip).  qd_conv3x3_halo_ok tells whether
+ * the descriptor is covered; results are bit-identical to qd_conv2d_i8's. */
+int qd_conv3x3_halo_ok(const qd_conv_desc* d);
+int qd_conv3x3_halo_i8(const qd_conv_desc* d, void* stream);
 
 /* Scratch bytes qd_conv2d_i8 would use for a split-K contraction of this descriptor (shape fields only are
  * read); 0 when the layer is launched unsplit. */

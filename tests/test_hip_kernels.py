@@ -841,3 +841,42 @@ def test_fused_fakequant_forward_backward_matches_autograd(cuda, sym, shape):
     assert abs(gd_f - truth) <= 1e-5 * scale, (gd_f, gd_c, truth, scale)
     assert abs(gd_c - truth) <= 1e-5 * scale, (gd_f, gd_c, truth, scale)
     assert bool(((codes < lo) | (codes > hi)).any()), "the test tensor never clamps"
+
+
+HALO_CASES = [
+    # name,          B, Cin, H,  W, Cout
+    ("w64_c320",     2, 320, 64, 64, 320),
+    ("w32_c640",     2, 640, 32, 32, 640),
+    ("w16_ktail",    3, 96, 16, 16, 320),     # 96 channels: the second 64-channel slab has a 32-channel K tail
+    ("w32_c64",      1, 64, 32, 32, 320),     # a single slab (no slab prefetch at all)
+]
+
+
+@pytest.mark.skipif(os.environ.get("QDIFF_HALO") != "1", reason="experimental kernel: run with QDIFF_HALO=1")
+@pytest.mark.parametrize("case", HALO_CASES, ids=[c[0] for c in HALO_CASES])
+def test_halo_conv_equals_gather_kernel(cuda, case):
+    """csrc/igemm_halo.hip (activation patch resident in LDS across the nine taps) against qd_conv2d_i8's gather kernel on
+    the same descriptor: fp32 outputs (bias + time-embedding row bias + residual) and GroupNorm statistics bit for bit."""
+    from qdiff import engine, hip
+    _, B, Cin, H, W, Cout = case
+    g = torch.Generator().manual_seed(29)
+    x = F.silu(torch.randn(B, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    q = _weight_quantizer(w, 4, True, g)
+    d, z = R.uaq_init_scale(x, 8, False, False, "max")
+    plan = engine.build_conv_plan(engine.pack_module_weights(w.to(cuda), [q], 0), [_aq(d, z)], 3, 3, 1, 1,
+                                  torch.randn(Cout, generator=g).to(cuda))
+    xq = engine.quantize_rows(x.to(cuda), plan, B, Cin, H * W, (Cin * H * W, H * W, 1))
+    rowbias = torch.randn(B, Cout, generator=g).to(cuda)
+    residual = torch.randn(B * H * W, Cout, generator=g).to(cuda)
+    outs = {}
+    for halo in (False, True):
+        hip.HALO = halo
+        try:
+            o = engine.conv_forward(plan, xq, B, H, W, rowbias=rowbias, residual=residual, gn_stats=True, splitk=False)
+            torch.cuda.synchronize()
+        finally:
+            hip.HALO = False
+        outs[halo] = (o.clone(), o.qd_gn_part.clone())
+    assert torch.equal(outs[True][0], outs[False][0]), (outs[True][0] - outs[False][0]).abs().max().item()
+    assert torch.equal(outs[True][1], outs[False][1])
