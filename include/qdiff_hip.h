@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 13
+#define QD_ABI_VERSION 14
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -167,6 +167,10 @@ typedef struct {
      * then costs no copy at all. */
     float*         gn_part;
     int64_t        gn_ld;
+    /* qd_conv3x3_halo_i8 only (qd_conv2d_i8 rejects a non-zero value): x holds the HALF-resolution map [B][H/2][W/2][ldx] and the
+     * convolution runs on its nearest-neighbour 2x up-sampling (Upsample: openaimodel.py:105-120) — H, W are the up-sampled sizes. */
+    int32_t        upsample2x;
+    int32_t        _pad3;
 } qd_conv_desc;
 
 int qd_conv2d_i8(const qd_conv_desc* d, void* stream);

@@ -1009,6 +1009,7 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
     QD_REQUIRE(d->x && d->w && (d->out || iout), "qd_conv2d_i8: null tensor pointer");
     QD_REQUIRE(d->w_tiled, "qd_conv2d_i8: weights must be in the tile order of qd_pack_weights_t4 / _t8 (w_tiled = 1)");
     QD_REQUIRE(d->wbits == 4 || d->wbits == 8, "qd_conv2d_i8: wbits must be 4 or 8 (got %d)", d->wbits);
+    QD_REQUIRE(!d->upsample2x, "qd_conv2d_i8: upsample2x is a qd_conv3x3_halo_i8 feature");
     QD_REQUIRE(d->out_dtype == QD_F32 || d->out_dtype == QD_F16, "qd_conv2d_i8: out_dtype must be f32/f16");
     QD_REQUIRE(d->nseg == 1 || d->nseg == 2, "qd_conv2d_i8: nseg must be 1 or 2");
     QD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, "qd_conv2d_i8: bad shape");

@@ -36,6 +36,7 @@ struct HaloD {
     const float*   residual;
     long ldx, ldo, ldr, ldrb;
     int B, H, W, lw, Cout, M;
+    int ups;                            // 1: x is the HALF-resolution map [B][H/2][W/2]; input pixel (iy, ix) reads (iy >> 1, ix >> 1)
     int c0, clen, kstep0, nst;          // single segment: first channel, channels, first K-step of the packed operand, 64-channel slabs
     int ntiles, nblk_n;
     const float*  scale;
@@ -126,7 +127,10 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const HaloD p) {
         const bool inimg = inslab && iy >= 0 && iy < p.H && ix >= 0 && ix < W;
         const int c = (slot ^ ((pix >> 2) & 3)) * 16;
         s_chunk[j] = c;
-        s_src[j] = inimg ? p.x + ((long)b * HW + (long)iy * W + ix) * p.ldx + p.c0 + c : (inslab ? fill : zero16);
+        // nearest-neighbour 2x up-sampling folded into the gather (openaimodel.py:116 F.interpolate -> conv): the patch is read
+        // from the small map, the in-image test runs on the up-sampled coordinates
+        const long spix = p.ups ? (long)b * (HW >> 2) + (long)(iy >> 1) * (W >> 1) + (ix >> 1) : (long)b * HW + (long)iy * W + ix;
+        s_src[j] = inimg ? p.x + spix * p.ldx + p.c0 + c : (inslab ? fill : zero16);
         s_inc[j] = inimg ? 64 : 0;
         s_dst[j] = q * 1024;
     }
@@ -378,6 +382,7 @@ extern "C" int qd_conv3x3_halo_ok(const qd_conv_desc* d) {
     if (d->rowbias && (d->ld_rowbias % 4 != 0 || !qd_aligned(d->rowbias, 16))) return 0;
     if (d->gn_part && (d->Ho * d->Wo) % 128 != 0) return 0;
     if ((long)9 * d->seg[0].clen >= 32768) return 0;         // 24-bit zero-point multiply, as qd_conv2d_i8
+    if (d->upsample2x && (d->H % 2 || d->W % 2)) return 0;
     return 1;
 }
 
@@ -390,6 +395,7 @@ extern "C" int qd_conv3x3_halo_i8(const qd_conv_desc* d, void* stream) {
     k.x = d->x; k.wt = d->w; k.out = reinterpret_cast<float*>(d->out);
     k.bias = d->bias; k.rowbias = d->rowbias; k.residual = reinterpret_cast<const float*>(d->residual);
     k.ldx = d->ldx; k.ldo = d->ldo; k.ldr = d->ldr; k.ldrb = d->ld_rowbias;
+    k.ups = d->upsample2x ? 1 : 0;
     k.B = d->B; k.H = d->H; k.W = d->W; k.lw = d->W == 16 ? 4 : (d->W == 32 ? 5 : 6); k.Cout = d->Cout;
     k.M = d->B * d->H * d->W;
     k.c0 = g.c0; k.clen = g.clen; k.kstep0 = g.kstep0; k.nst = (g.clen + 63) / 64;

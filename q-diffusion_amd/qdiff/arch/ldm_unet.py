@@ -252,6 +252,10 @@ class Upsample(nn.Module):
                 rows = qb._nhwc_rows(x)
                 plan = conv.conv_plan()
                 xq = engine.quantize_rows(rows, plan, 1, c, b * h * w, (0, 1, rows.stride(0)))
+                if engine.halo_upsample_ok(plan, 2 * h, 2 * w):
+                    # experimental (QDIFF_HALO=1): the up-sampling is folded into the convolution's patch gather
+                    out = conv.forward_codes(xq, b, 2 * h, 2 * w, gn_stats=True, slot=out_slot, upsample2x=True)
+                    return qb._rows_to_nchw(out, b, 2 * h, 2 * w)
                 up = xq.view(b, h, 1, w, 1, -1).expand(b, h, 2, w, 2, xq.shape[1]).reshape(b * 4 * h * w, xq.shape[1])
                 out = conv.forward_codes(up, b, 2 * h, 2 * w, gn_stats=True, slot=out_slot)
                 return qb._rows_to_nchw(out, b, 2 * h, 2 * w)

@@ -321,8 +321,16 @@ class _SlotSide:
         return self.slot.part(self.i, B, nchunk, C, device)
 
 
+def halo_upsample_ok(plan, H, W):
+    """The experimental halo kernel (QDIFF_HALO=1) can run `plan` on the nearest-2x up-sampling of a half-resolution map
+    whose up-sampled size is H x W (mirrors qd_conv3x3_halo_ok)."""
+    return bool(hip.HALO and plan.kh == 3 and plan.kw == 3 and plan.stride == 1 and plan.pad == 1 and len(plan.segs) == 1
+                and plan.pack.tiled and plan.pack.wbits == 4 and W in (16, 32, 64) and (H * W) % 128 == 0
+                and H % (128 // W) == 0 and H % 2 == 0 and plan.Cout % 320 == 0 and plan.segs[0]["clen"] % 16 == 0)
+
+
 def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, residual=None, acc_out=None,
-                 out_dtype=torch.float32, pad_tl=None, splitk=None, gn_stats=False, slot=None):
+                 out_dtype=torch.float32, pad_tl=None, splitk=None, gn_stats=False, slot=None, upsample2x=False):
     """Run K3/K4 on quantised rows xq [B*H*W][ldx].  Returns out [B*Ho*Wo][Cout] (row-major).
     splitk=False forbids the split-K schedule (tests compare it with the default, which lets the library decide).
     gn_stats=True: when the layer is eligible (tile-ordered int4, fp32 out, Ho*Wo % 128 == 0, not a split-K layer) the
@@ -348,10 +356,10 @@ def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, re
                         ld_rowbias=(rowbias.stride(0) if rowbias is not None else 0),
                         B=B, H=H, W=W, Ho=Ho, Wo=Wo, Cout=plan.Cout, kh=plan.kh, kw=plan.kw, stride=plan.stride,
                         pad_t=pad, pad_l=pad, wbits=plan.pack.wbits, w_tiled=plan.pack.tiled, segs=plan.segs,
-                        splitk=splitk)
+                        splitk=splitk, upsample2x=upsample2x)
     part = None
     if (gn_stats and acc_out is None and plan.pack.tiled and out.dtype == torch.float32 and (Ho * Wo) % 128 == 0
-            and out.stride(1) == 1 and (splitk is False or hip.splitk_ws_bytes(call) == 0)):
+            and out.stride(1) == 1 and (upsample2x or splitk is False or hip.splitk_ws_bytes(call) == 0)):
         if slot is not None:
             part = slot.part(B, Ho * Wo // 128, plan.Cout, xq.device)
         if part is None:

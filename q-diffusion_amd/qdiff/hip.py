@@ -44,7 +44,7 @@ class ConvDesc(ctypes.Structure):
                 ("splitk_ws", ctypes.c_void_p), ("splitk_ws_bytes", ctypes.c_int64),
                 ("hd_H", ctypes.c_int32), ("hd_d", ctypes.c_int32), ("hd_T", ctypes.c_int32), ("hd_Tpad", ctypes.c_int32),
                 ("hd_dpad", ctypes.c_int32), ("oq_prescale", ctypes.c_float), ("hd_sum", ctypes.c_void_p),
-                ("gn_part", ctypes.c_void_p), ("gn_ld", ctypes.c_int64)]
+                ("gn_part", ctypes.c_void_p), ("gn_ld", ctypes.c_int64), ("upsample2x", ctypes.c_int32), ("_pad3", ctypes.c_int32)]
 
 
 class RawSeg(ctypes.Structure):
@@ -111,7 +111,7 @@ def load():
     lib.qd_fakequant_bwd.argtypes = [vp, vp, i64, vp, vp, i32, i32, vp, vp, vp]
     lib.qd_conv3x3_halo_ok.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.qd_conv3x3_halo_i8.argtypes = [ctypes.POINTER(ConvDesc), vp]
-    if lib.qd_abi_version() != 13:
+    if lib.qd_abi_version() != 14:
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -214,7 +214,7 @@ class ConvCall:
     """Python-side description of one qd_conv2d_i8 launch (tensors, not pointers)."""
     __slots__ = ("x", "w", "out", "bias", "rowbias", "residual", "ldx", "ldk", "ldo", "ldr", "ld_rowbias",
                  "B", "H", "W", "Ho", "Wo", "Cout", "kh", "kw", "stride", "pad_t", "pad_l", "wbits", "w_tiled", "segs",
-                 "epilogue", "oq_params", "oq_grid", "splitk", "heads", "gn_part")
+                 "epilogue", "oq_params", "oq_grid", "splitk", "heads", "gn_part", "upsample2x")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -242,9 +242,16 @@ def splitk_ws_bytes(c):
 HALO = os.environ.get("QDIFF_HALO", "0") == "1"       # EXPERIMENTAL 3x3 kernel with the activation patch resident in LDS
 
 
+def halo_covers(c):
+    """The experimental 3x3 kernel (QDIFF_HALO=1) would take ConvCall `c` (shape fields and pointers only are looked at)."""
+    return bool(HALO and load().qd_conv3x3_halo_ok(ctypes.byref(_conv_desc(c))))
+
+
 def conv2d_i8(c, acc_out=None):
     """c: ConvCall.  segs: list of dicts {c0, clen, kofs, wzp, scale, zc, zw, zfill} (tensors or None)."""
     d = _conv_desc(c)
+    if c.upsample2x and not (HALO and acc_out is None and load().qd_conv3x3_halo_ok(ctypes.byref(d))):
+        raise HipEngineError("upsample2x needs the experimental halo kernel (QDIFF_HALO=1) and a shape it covers")
     if HALO and acc_out is None and load().qd_conv3x3_halo_ok(ctypes.byref(d)):
         _check(load().qd_conv3x3_halo_i8(ctypes.byref(d), _stream()), "qd_conv3x3_halo_i8")
         return
@@ -286,6 +293,7 @@ def _conv_desc(c):
     d.gn_part = _ptr(c.gn_part, "gn_part")
     if c.gn_part is not None:
         d.gn_ld = part_ld(c.gn_part)
+    d.upsample2x = 1 if c.upsample2x else 0
     d.nseg = len(c.segs)
     for i, s in enumerate(c.segs):
         g = d.seg[i]

@@ -880,3 +880,29 @@ def test_halo_conv_equals_gather_kernel(cuda, case):
         outs[halo] = (o.clone(), o.qd_gn_part.clone())
     assert torch.equal(outs[True][0], outs[False][0]), (outs[True][0] - outs[False][0]).abs().max().item()
     assert torch.equal(outs[True][1], outs[False][1])
+
+
+@pytest.mark.skipif(os.environ.get("QDIFF_HALO") != "1", reason="experimental kernel: run with QDIFF_HALO=1")
+@pytest.mark.parametrize("B,C,h,Cout", [(2, 640, 16, 640), (1, 96, 8, 320), (2, 320, 32, 320)])
+def test_halo_conv_folds_nearest_upsampling(cuda, B, C, h, Cout):
+    """upsample2x: the halo kernel reads the half-resolution int8 map and convolves its nearest-neighbour 2x up-sampling —
+    bit-identical to replicating the int8 rows first (arch/ldm_unet.py Upsample.forward) and running the gather kernel."""
+    from qdiff import engine, hip
+    g = torch.Generator().manual_seed(31)
+    x = F.silu(torch.randn(B, C, h, h, generator=g))
+    w = torch.randn(Cout, C, 3, 3, generator=g) * 0.05
+    q = _weight_quantizer(w, 4, True, g)
+    d, z = R.uaq_init_scale(x, 8, False, False, "max")
+    plan = engine.build_conv_plan(engine.pack_module_weights(w.to(cuda), [q], 0), [_aq(d, z)], 3, 3, 1, 1,
+                                  torch.randn(Cout, generator=g).to(cuda))
+    xq = engine.quantize_rows(x.to(cuda), plan, B, C, h * h, (C * h * h, h * h, 1))
+    up = xq.view(B, h, 1, h, 1, -1).expand(B, h, 2, h, 2, xq.shape[1]).reshape(B * 4 * h * h, xq.shape[1])
+    want = engine.conv_forward(plan, up, B, 2 * h, 2 * h, gn_stats=True, splitk=False)
+    hip.HALO = True
+    try:
+        assert engine.halo_upsample_ok(plan, 2 * h, 2 * h)
+        got = engine.conv_forward(plan, xq, B, 2 * h, 2 * h, gn_stats=True, upsample2x=True)
+        torch.cuda.synchronize()
+    finally:
+        hip.HALO = False
+    assert torch.equal(got, want) and torch.equal(got.qd_gn_part, want.qd_gn_part)

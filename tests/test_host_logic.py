@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     from qdiff import hip
     assert sorted(hip.EXPORTS) == declared
     lib.qd_abi_version.restype = ctypes.c_int
-    assert lib.qd_abi_version() == 13
+    assert lib.qd_abi_version() == 14
     assert lib.qd_device_ok() in (0, 1)                  # no compute calls without a GPU
 
 
@@ -41,7 +41,7 @@ def test_conv_desc_layout_matches_header():
     """ctypes mirror of qd_conv_desc / qd_conv_seg has the C layout (sizes from the header's field list)."""
     from qdiff import hip
     assert ctypes.sizeof(hip.ConvSeg) == 4 * 4 + 6 * 8
-    assert ctypes.sizeof(hip.ConvDesc) == 6 * 8 + 5 * 8 + 16 * 4 + 2 * ctypes.sizeof(hip.ConvSeg) + 8 + 4 * 4 + 16 + 5 * 4 + 4 + 8 + 8 + 8
+    assert ctypes.sizeof(hip.ConvDesc) == 6 * 8 + 5 * 8 + 16 * 4 + 2 * ctypes.sizeof(hip.ConvSeg) + 8 + 4 * 4 + 16 + 5 * 4 + 4 + 8 + 8 + 8 + 8
     assert ctypes.sizeof(hip.RawSeg) == 6 * 4 + 8 and ctypes.sizeof(hip.RawQuant) == 8 + 8 + 4 + 4 + 2 * ctypes.sizeof(hip.RawSeg)
 
 

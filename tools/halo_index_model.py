@@ -8,9 +8,11 @@ import sys
 import numpy as np
 
 
-def check(B, H, W, C, c0, clen, ldx, seed=0):
+def check(B, H, W, C, c0, clen, ldx, seed=0, ups=False):
     rng = np.random.default_rng(seed)
-    x = rng.integers(-128, 128, size=(B * H * W, ldx), dtype=np.int8)
+    xs = rng.integers(-128, 128, size=(B * H * W // (4 if ups else 1), ldx), dtype=np.int8)
+    # `x` below is the LOGICAL input the definition uses; with ups the kernel reads the half-resolution map xs instead
+    x = (xs.reshape(B, H // 2, W // 2, ldx).repeat(2, axis=1).repeat(2, axis=2).reshape(B * H * W, ldx) if ups else xs)
     fill = np.full(16, 7, dtype=np.int8)                      # the "true zero" byte of out-of-image taps
     lw = {16: 4, 32: 5, 64: 6}[W]
     Wp, R = W + 2, 128 >> lw
@@ -36,7 +38,8 @@ def check(B, H, W, C, c0, clen, ldx, seed=0):
                         src = np.zeros(16, dtype=np.int8)
                     elif inimg:
                         a = c0 + cs * 64 + c
-                        src = x[(b * H + iy) * W + ix, a:a + 16]
+                        spix = (b * (H * W >> 2) + (iy >> 1) * (W >> 1) + (ix >> 1)) if ups else ((b * H + iy) * W + ix)
+                        src = xs[spix, a:a + 16]
                     else:
                         src = fill if inslab else np.zeros(16, dtype=np.int8)
                     lds[q * 1024 + lane * 16: q * 1024 + lane * 16 + 16] = src
@@ -66,7 +69,8 @@ def check(B, H, W, C, c0, clen, ldx, seed=0):
 if __name__ == "__main__":
     ok = True
     for cfg in [(1, 16, 16, 96, 0, 96, 96), (2, 32, 32, 64, 16, 48, 80), (1, 4, 64, 128, 0, 128, 128), (1, 8, 16, 80, 0, 80, 80)]:
-        r = check(*cfg)
-        print(cfg, "ok" if r else "FAILED")
-        ok &= r
+        for ups in (False, True):
+            r = check(*cfg, ups=ups)
+            print(cfg, "ups" if ups else "   ", "ok" if r else "FAILED")
+            ok &= r
     sys.exit(0 if ok else 1)
