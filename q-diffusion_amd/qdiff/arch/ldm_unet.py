@@ -252,7 +252,7 @@ class Upsample(nn.Module):
                 rows = qb._nhwc_rows(x)
                 plan = conv.conv_plan()
                 xq = engine.quantize_rows(rows, plan, 1, c, b * h * w, (0, 1, rows.stride(0)))
-                if engine.halo_upsample_ok(plan, 2 * h, 2 * w):
+                if engine.halo_upsample_ok(plan, b, 2 * h, 2 * w):
                     # experimental (QDIFF_HALO=1): the up-sampling is folded into the convolution's patch gather
                     out = conv.forward_codes(xq, b, 2 * h, 2 * w, gn_stats=True, slot=out_slot, upsample2x=True)
                     return qb._rows_to_nchw(out, b, 2 * h, 2 * w)

@@ -321,10 +321,10 @@ class _SlotSide:
         return self.slot.part(self.i, B, nchunk, C, device)
 
 
-def halo_upsample_ok(plan, H, W):
+def halo_upsample_ok(plan, B, H, W):
     """The experimental halo kernel (QDIFF_HALO=1) can run `plan` on the nearest-2x up-sampling of a half-resolution map
-    whose up-sampled size is H x W (mirrors qd_conv3x3_halo_ok)."""
-    return bool(hip.HALO and plan.kh == 3 and plan.kw == 3 and plan.stride == 1 and plan.pad == 1 and len(plan.segs) == 1
+    whose up-sampled size is H x W (mirrors qd_conv3x3_halo_ok) and its blocks would fill the chip."""
+    return bool(hip.HALO and hip.halo_blocks(B, H, W, plan.Cout) >= hip.HALO_MINBLK and plan.kh == 3 and plan.kw == 3 and plan.stride == 1 and plan.pad == 1 and len(plan.segs) == 1
                 and plan.pack.tiled and plan.pack.wbits == 4 and W in (16, 32, 64) and (H * W) % 128 == 0
                 and H % (128 // W) == 0 and H % 2 == 0 and plan.Cout % 320 == 0 and plan.segs[0]["clen"] % 16 == 0)
 

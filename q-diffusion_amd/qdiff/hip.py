@@ -240,6 +240,11 @@ def splitk_ws_bytes(c):
 
 
 HALO = os.environ.get("QDIFF_HALO", "0") == "1"       # EXPERIMENTAL 3x3 kernel with the activation patch resident in LDS
+HALO_MINBLK = int(os.environ.get("QDIFF_HALO_MINBLK", "200"))   # ... only where its 128 x 320 blocks fill the chip (else split-K)
+
+
+def halo_blocks(B, H, W, Cout):
+    return (B * H * W // 128) * (Cout // 320)
 
 
 def halo_covers(c):
@@ -252,7 +257,8 @@ def conv2d_i8(c, acc_out=None):
     d = _conv_desc(c)
     if c.upsample2x and not (HALO and acc_out is None and load().qd_conv3x3_halo_ok(ctypes.byref(d))):
         raise HipEngineError("upsample2x needs the experimental halo kernel (QDIFF_HALO=1) and a shape it covers")
-    if HALO and acc_out is None and load().qd_conv3x3_halo_ok(ctypes.byref(d)):
+    if (HALO and acc_out is None and (c.upsample2x or halo_blocks(c.B, c.H, c.W, c.Cout) >= HALO_MINBLK)
+            and load().qd_conv3x3_halo_ok(ctypes.byref(d))):
         _check(load().qd_conv3x3_halo_i8(ctypes.byref(d), _stream()), "qd_conv3x3_halo_i8")
         return
     if acc_out is None:

@@ -870,13 +870,14 @@ def test_halo_conv_equals_gather_kernel(cuda, case):
     rowbias = torch.randn(B, Cout, generator=g).to(cuda)
     residual = torch.randn(B * H * W, Cout, generator=g).to(cuda)
     outs = {}
+    minblk = hip.HALO_MINBLK
     for halo in (False, True):
-        hip.HALO = halo
+        hip.HALO, hip.HALO_MINBLK = halo, 1
         try:
             o = engine.conv_forward(plan, xq, B, H, W, rowbias=rowbias, residual=residual, gn_stats=True, splitk=False)
             torch.cuda.synchronize()
         finally:
-            hip.HALO = False
+            hip.HALO, hip.HALO_MINBLK = False, minblk
         outs[halo] = (o.clone(), o.qd_gn_part.clone())
     assert torch.equal(outs[True][0], outs[False][0]), (outs[True][0] - outs[False][0]).abs().max().item()
     assert torch.equal(outs[True][1], outs[False][1])
@@ -898,11 +899,11 @@ def test_halo_conv_folds_nearest_upsampling(cuda, B, C, h, Cout):
     xq = engine.quantize_rows(x.to(cuda), plan, B, C, h * h, (C * h * h, h * h, 1))
     up = xq.view(B, h, 1, h, 1, -1).expand(B, h, 2, h, 2, xq.shape[1]).reshape(B * 4 * h * h, xq.shape[1])
     want = engine.conv_forward(plan, up, B, 2 * h, 2 * h, gn_stats=True, splitk=False)
-    hip.HALO = True
+    hip.HALO, minblk, hip.HALO_MINBLK = True, hip.HALO_MINBLK, 1
     try:
-        assert engine.halo_upsample_ok(plan, 2 * h, 2 * h)
+        assert engine.halo_upsample_ok(plan, B, 2 * h, 2 * h)
         got = engine.conv_forward(plan, xq, B, 2 * h, 2 * h, gn_stats=True, upsample2x=True)
         torch.cuda.synchronize()
     finally:
-        hip.HALO = False
+        hip.HALO, hip.HALO_MINBLK = False, minblk
     assert torch.equal(got, want) and torch.equal(got.qd_gn_part, want.qd_gn_part)

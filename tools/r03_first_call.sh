@@ -1,0 +1,13 @@
+#!/bin/bash
+# First GPU call of the next round: parity of everything this round could not verify on a GPU (the experimental 3x3 halo
+# kernel and its up-sampling fold, GPU calibration), then the A/B numbers that decide whether the halo kernel becomes default.
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/r03_first; mkdir -p $out
+QDIFF_HALO=1 timeout 300 python -m pytest tests/test_hip_kernels.py -m gpu -q -k "halo" > $out/pytest_halo.log 2>&1; echo "halo parity rc=$?"; tail -4 $out/pytest_halo.log
+timeout 300 python -m pytest tests/test_calibration.py -m gpu -q > $out/pytest_cal.log 2>&1; echo "gpu calibration rc=$?"; tail -3 $out/pytest_cal.log
+timeout 120 python tools/bench_fakequant.py 2>&1 | tail -2 | tee $out/fakequant.txt
+SH="16,320,64,320,3,1;16,640,64,320,3,1;16,960,64,320,3,1;16,640,32,640,3,1;16,1280,32,640,3,1;16,1280,16,1280,3,1"
+for e in "QDIFF_HALO=0" "QDIFF_HALO=1"; do
+  echo "== igemm $e"; env $e IGEMM_SHAPES="$SH" timeout 200 python tools/bench_igemm.py 4 20 2>&1 | tail -7
+done | tee $out/igemm_halo_ab.txt
+tools/r02_ab.sh "QDIFF_HALO=0" "QDIFF_HALO=1" "QDIFF_HALO=0" "QDIFF_HALO=1" 2>&1 | tee $out/sd_halo_ab.txt
