@@ -308,7 +308,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const HaloD p) {
             for (int r = 0; r < 16; ++r) {
                 const int rl = hcrow(r) + 4 * fhalf;
                 const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rbase + rl] - kz);
-                tb[rl * 32 + frow] = __float_as_uint((float)I * sc + bias_n);
+                const float v = (float)I * sc;                  // (same statement structure as igemm_dma.hip: identical contraction)
+                tb[rl * 32 + frow] = __float_as_uint(v + bias_n);
             }
             v4f rb, rs[4];
             if (has_rb) rb = *reinterpret_cast<const v4f*>(p.rowbias + (long)b * p.ldrb + n4);
