@@ -327,7 +327,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const HaloD p) {
                 *reinterpret_cast<v4f*>(p.out + (long)(m0 + rbase + rl) * p.ldo + n4) = v;
                 if (gn) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
+                    // separate multiply and add (as the gather kernel's epilogue is compiled): the statistics are bit-identical
+                    for (int e = 0; e < 4; ++e) { gs[e] += v[e]; gq[e] += __fmul_rn(v[e], v[e]); }
                 }
             }
         }
