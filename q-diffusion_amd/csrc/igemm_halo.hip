@@ -73,6 +73,14 @@ __device__ __forceinline__ int hbytesum16(const v4i& v) {
 
 __device__ __forceinline__ constexpr int hcrow(int r) { return (r & 3) + 8 * (r >> 2); }
 
+// a product that is rounded on its own (never fused into a following add)
+__device__ __forceinline__ float hmul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    float r = a * b;
+    asm volatile("" : "+v"(r));          // the value is opaque to the optimiser from here on: nothing to contract it with
+    return r;
+}
+
 constexpr int H_MT = 2, H_NT = 5, H_WM = 2, H_WN = 2;
 constexpr int H_BM = 32 * H_MT * H_WM, H_BN = 32 * H_NT * H_WN, H_NTB = H_NT * H_WN;      // 128 x 320, 10 n-tiles
 constexpr int H_TB = 1024;                                   // bytes of one (K-step, 32-channel) int4 weight tile
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const HaloD p) {
                 if (gn) {
 #pragma unroll
                     // separate multiply and add (as the gather kernel's epilogue is compiled): the statistics are bit-identical
-                    for (int e = 0; e < 4; ++e) { gs[e] += v[e]; gq[e] += __fmul_rn(v[e], v[e]); }
+                    for (int e = 0; e < 4; ++e) { gs[e] += v[e]; gq[e] += hmul_rn(v[e], v[e]); }
                 }
             }
         }
