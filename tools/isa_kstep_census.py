@@ -48,15 +48,16 @@ def main():
             if mm and mm.group(1) in labels and labels[mm.group(1)] < i:          # backward branch
                 lo, hi = labels[mm.group(1)], i
                 inside = [k for k in mf if lo <= k <= hi]
-                if len(inside) == len(mf) and (best is None or hi - lo < best[1] - best[0]):
-                    best = (lo, hi)
+                # the loop with the most MFMAs wins (a peeled first iteration leaves a copy outside), then the tightest one
+                if inside and (best is None or (len(inside), -(hi - lo)) > (best[2], -(best[1] - best[0]))):
+                    best = (lo, hi, len(inside))
         if best is None:
             continue
         ops = [l.split()[0] for l in lines[best[0]:best[1] + 1] if l and not l.startswith((".", ";")) and not l.endswith(":")]
         c = collections.Counter(klass(o) for o in ops)
         scr = sum(1 for l in lines[best[0]:best[1] + 1] if l.startswith("scratch_"))
         targs = re.search(r"igemm_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELi(\d)ELi(\d)E", name)
-        tag = "<MT=%s,NT=%s,WM=%s,WN=%s,SPLIT=%s,OUT=%s,WB=%s>" % targs.groups() if targs else name[:60]
+        tag = "<MT=%s,NT=%s,WM=%s,WN=%s,SPLIT=%s,OUT=%s,WB=%s>" % targs.groups() if targs else name[18:60]
         others = c["VALU"] + c["SALU"] + c["LDS"] + c["VMEM"] + c["WAIT"] + c["BARRIER"] + c["BRANCH"]
         print(f"| {tag} | {c['MFMA']} | {c['VALU']} | {c['SALU']} | {c['LDS']} | {c['VMEM']} | {c['WAIT']} | {others / c['MFMA']:.1f} | {scr} |")
 
