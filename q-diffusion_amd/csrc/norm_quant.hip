@@ -140,6 +140,64 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+// EXPERIMENTAL (QD_GN_ROWS=2|4, off by default): the same apply pass with U rows per thread — the U 16-byte loads of a thread
+// are issued back to back before any of them is used (more bytes in flight per wave: the one-row kernel streams at
+// 3.8 TB/s of the ~5.5 the HBM sustains), the per-(sample, channel) affine is fetched once per U rows.  fp32 input, 16-byte
+// aligned rows, no float output; U consecutive rows always belong to one sample (S % U == 0).  Same arithmetic per element.
+template <int U>
+__global__ __launch_bounds__(256) void gn_apply_rows_kernel(const float* __restrict__ x, long rows, long S, int C, long ldx,
+                                                            const float* __restrict__ ab, int apply_silu,
+                                                            const float* __restrict__ qp, float qmin, float qmax, int off,
+                                                            int8_t* __restrict__ out, long ldo, const RawQ raw) {
+    const int chunks = C >> 2;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (rows / U) * chunks) return;
+    const long rg = gid / chunks;
+    const int c = (int)(gid - rg * chunks) * 4;
+    const long row0 = rg * U;
+    const long b = row0 / S;
+    float4 xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const float4*>(x + (row0 + u) * ldx + c);
+    const float4 ab0 = *reinterpret_cast<const float4*>(ab + (b * C + c) * 2);
+    const float4 ab1 = *reinterpret_cast<const float4*>(ab + (b * C + c) * 2 + 4);
+    const float a4[4] = {ab0.x, ab0.z, ab1.x, ab1.z}, s4[4] = {ab0.y, ab0.w, ab1.y, ab1.w};
+    const QP q = qd_load_qp(qp);
+    const bool s1 = raw.out && raw.nseg > 1 && c >= raw.c0[1];
+    const int rc0 = s1 ? raw.c0[1] : raw.c0[0], rlen = s1 ? raw.clen[1] : raw.clen[0], roc0 = s1 ? raw.oc0[1] : raw.oc0[0];
+    const bool rawhere = raw.out && c >= rc0 && c < rc0 + rlen;
+    QP rq{1.f, 0.f, 1.f, false};
+    if (rawhere) rq = qd_load_qp(s1 ? raw.qp[1] : raw.qp[0]);
+    const float rmin = s1 ? raw.qmin[1] : raw.qmin[0], rmax = s1 ? raw.qmax[1] : raw.qmax[0];
+    const int roff = s1 ? raw.off[1] : raw.off[0];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const float v[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+        const long row = row0 + u;
+        unsigned w0 = 0;
+        auto body = [&](auto ft) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float y = v[j] * a4[j] + s4[j];
+                if (apply_silu) y = y * (1.0f / (1.0f + expf(-y)));
+                w0 |= (unsigned)((qd_code_t<decltype(ft)::value>(y, q, qmin, qmax) - off) & 0xff) << (8 * j);
+            }
+        };
+        QD_FAST_DISPATCH(q.fast, body);
+        *reinterpret_cast<unsigned*>(out + row * ldo + c) = w0;
+        if (rawhere) {
+            unsigned w = 0;
+            auto rbody = [&](auto ft) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    w |= (unsigned)((qd_code_t<decltype(ft)::value>(v[j], rq, rmin, rmax) - roff) & 0xff) << (8 * j);
+            };
+            QD_FAST_DISPATCH(rq.fast, rbody);
+            *reinterpret_cast<unsigned*>(raw.out + row * raw.ldo + roc0 + (c - rc0)) = w;
+        }
+    }
+}
+
 // LayerNorm: one wave per row, row held in registers (C <= 64*4*MAXV).
 constexpr int LN_MAXV = 6;  // up to 1536 channels
 // NV = float4 chunks per lane (ceil(C/256)), RPW = rows per wave: the loads of RPW rows are issued back to
@@ -310,6 +368,17 @@ extern "C" int qd_groupnorm_silu_quant(const void* x, int x_dtype, int64_t B, in
     }
     long rows = B * S;
     long total = rows * (C / 4);
+    static const int gn_rows_knob = getenv("QD_GN_ROWS") ? atoi(getenv("QD_GN_ROWS")) : 0;       // experimental, see gn_apply_rows_kernel
+    if ((gn_rows_knob == 2 || gn_rows_knob == 4) && x_dtype == QD_F32 && vec && out && !yout && S % gn_rows_knob == 0) {
+        const long tot = (rows / gn_rows_knob) * (C / 4);
+        dim3 g2((unsigned)((tot + 255) / 256));
+        if (gn_rows_knob == 2)
+            hipLaunchKernelGGL(gn_apply_rows_kernel<2>, g2, dim3(256), 0, st, (const float*)x, rows, (long)S, C, (long)ldx, ab, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, rq);
+        else
+            hipLaunchKernelGGL(gn_apply_rows_kernel<4>, g2, dim3(256), 0, st, (const float*)x, rows, (long)S, C, (long)ldx, ab, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, rq);
+        QD_LAUNCH_CHECK("qd_groupnorm_silu_quant");
+        return 0;
+    }
     dim3 grid((unsigned)((total + 255) / 256));
     if (x_dtype == QD_F32)
         hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, rows, (long)S, C, (long)ldx, ab, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, yout, (long)ldy, vec, rq);

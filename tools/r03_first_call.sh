@@ -11,3 +11,8 @@ for e in "QDIFF_HALO=0" "QDIFF_HALO=1"; do
   echo "== igemm $e"; env $e IGEMM_SHAPES="$SH" timeout 200 python tools/bench_igemm.py 4 20 2>&1 | tail -7
 done | tee $out/igemm_halo_ab.txt
 tools/r02_ab.sh "QDIFF_HALO=0" "QDIFF_HALO=1" "QDIFF_HALO=0" "QDIFF_HALO=1" 2>&1 | tee $out/sd_halo_ab.txt
+# experimental multi-row GroupNorm apply pass (csrc/norm_quant.hip gn_apply_rows_kernel): parity through the existing tests, then A/B
+for u in 2 4; do
+  QD_GN_ROWS=$u timeout 300 python -m pytest tests/test_hip_kernels.py -m gpu -q -k "groupnorm or concatenation" > $out/pytest_gnrows$u.log 2>&1; echo "gn rows=$u parity rc=$?"; tail -2 $out/pytest_gnrows$u.log
+done
+tools/r02_ab.sh "QD_GN_ROWS=0" "QD_GN_ROWS=2" "QD_GN_ROWS=4" "QD_GN_ROWS=0" 2>&1 | tee $out/sd_gnrows_ab.txt
