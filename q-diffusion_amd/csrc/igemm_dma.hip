@@ -912,6 +912,41 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const int32_t* __r
     }
 }
 
+// EXPERIMENTAL (QD_FIN_VEC=1, off by default): the same second pass with four consecutive output channels per thread —
+// 16-byte loads of every slice, of the residual and the row bias, one 16-byte store (the scalar version moves 4 bytes per lane
+// per access).  fp32 only, Cout % 4 == 0, 16-byte aligned rows.  Same float sequence per element.
+__global__ __launch_bounds__(256) void splitk_finalize4_kernel(const int32_t* __restrict__ part, int nsplit, long MN, int Cout, int HoWo,
+                                                               const float* __restrict__ scale, const int* __restrict__ zc,
+                                                               const int* __restrict__ zw, const int* __restrict__ zfill,
+                                                               const float* __restrict__ bias, const float* __restrict__ rowbias, long ldrb,
+                                                               const float* __restrict__ residual, long ldr, float* __restrict__ out, long ldo) {
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= MN) return;
+    const long m = e / Cout;
+    const int  n = (int)(e - m * Cout);
+    v4i I = {0, 0, 0, 0};
+    for (int s = 0; s < nsplit; ++s) I += *reinterpret_cast<const v4i*>(part + (long)s * MN + e);
+    const int kz = zfill ? zfill[1] : 0;
+    v4f v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int Ij = I[j] - (zc ? zc[n + j] : 0) + (zw ? zw[n + j] : 0) * kz;
+        v[j] = (float)Ij * scale[n + j];
+        v[j] += bias ? bias[n + j] : 0.f;
+    }
+    if (rowbias) {
+        const v4f rb = *reinterpret_cast<const v4f*>(rowbias + (m / HoWo) * ldrb + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += rb[j];
+    }
+    if (residual) {
+        const v4f rs = *reinterpret_cast<const v4f*>(residual + m * ldr + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += rs[j];
+    }
+    *reinterpret_cast<v4f*>(out + m * ldo + n) = v;
+}
+
 // tile-ordered s8 packer: thread = one 16-byte unit (row n, 16 consecutive K), stored byte = W - 128
 __global__ __launch_bounds__(256) void pack_t8_kernel(const float* __restrict__ w, const float* __restrict__ alpha,
                                                       const float* __restrict__ delta, const float* __restrict__ zp,
@@ -1104,6 +1139,16 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
         const SegD& sg = k.seg[0];
         const long MN = M * N;
         dim3 grid((unsigned)((MN + 255) / 256)), block(256);
+        static const bool fin_vec = getenv("QD_FIN_VEC") && atoi(getenv("QD_FIN_VEC")) == 1;     // experimental, see splitk_finalize4_kernel
+        if (fin_vec && d->out_dtype == QD_F32 && N % 4 == 0 && d->ldo % 4 == 0 && qd_aligned(d->out, 16) &&
+            (!d->residual || (d->ldr % 4 == 0 && qd_aligned(d->residual, 16))) &&
+            (!d->rowbias || (d->ld_rowbias % 4 == 0 && qd_aligned(d->rowbias, 16)))) {
+            dim3 g4((unsigned)((MN / 4 + 255) / 256));
+            hipLaunchKernelGGL(splitk_finalize4_kernel, g4, block, 0, st, k.iout, nsplit, MN, N, d->Ho * d->Wo, sg.scale, sg.zc, sg.zw,
+                               sg.zfill, k.bias, k.rowbias, k.ldrb, (const float*)k.residual, k.ldr, (float*)k.out, k.ldo);
+            QD_LAUNCH_CHECK("qd_conv2d_i8 (split-K)");
+            return 0;
+        }
         if (d->out_dtype == QD_F16)
             hipLaunchKernelGGL(splitk_finalize_kernel<__half>, grid, block, 0, st, k.iout, nsplit, MN, N, d->Ho * d->Wo, sg.scale, sg.zc, sg.zw,
                                sg.zfill, k.bias, k.rowbias, k.ldrb, (const __half*)k.residual, k.ldr, (__half*)k.out, k.ldo);

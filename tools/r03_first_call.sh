@@ -16,3 +16,6 @@ for u in 2 4; do
   QD_GN_ROWS=$u timeout 300 python -m pytest tests/test_hip_kernels.py -m gpu -q -k "groupnorm or concatenation" > $out/pytest_gnrows$u.log 2>&1; echo "gn rows=$u parity rc=$?"; tail -2 $out/pytest_gnrows$u.log
 done
 tools/r02_ab.sh "QD_GN_ROWS=0" "QD_GN_ROWS=2" "QD_GN_ROWS=4" "QD_GN_ROWS=0" 2>&1 | tee $out/sd_gnrows_ab.txt
+# experimental vectorised split-K second pass (csrc/igemm_dma.hip splitk_finalize4_kernel): parity (bit-identical to unsplit), then A/B
+QD_FIN_VEC=1 timeout 300 python -m pytest tests/test_hip_kernels.py -m gpu -q -k "splitk" > $out/pytest_finvec.log 2>&1; echo "fin vec parity rc=$?"; tail -2 $out/pytest_finvec.log
+tools/r02_ab.sh "QD_FIN_VEC=0" "QD_FIN_VEC=1" "QD_FIN_VEC=0" "QD_FIN_VEC=1" 2>&1 | tee $out/sd_finvec_ab.txt
