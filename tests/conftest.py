@@ -11,6 +11,14 @@ for p in (ROOT, os.path.join(ROOT, "q-diffusion_amd")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "late: collected last (end-to-end jobs whose failure must not hide the kernel parity "
+                                       "tests behind `-x`)")
+
+
+def pytest_collection_modifyitems(config, items):
+    late = [it for it in items if it.get_closest_marker("late")]
+    if late:
+        items[:] = [it for it in items if not it.get_closest_marker("late")] + late
 
 
 @pytest.fixture(scope="session")
