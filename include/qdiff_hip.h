@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 14
+#define QD_ABI_VERSION 15
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -265,6 +265,17 @@ int qd_groupnorm_silu_quant(const void* x, int x_dtype, int64_t B, int64_t S, in
                             int8_t* out, int64_t ldo, float* yout, int64_t ldy,
                             void* ws, const float* part_in, int nchunk_in, int64_t part_ld, const qd_raw_quant* raw,
                             void* stream);
+/* The same for the second norm of a `use_scale_shift_norm` residual block (qdiff/quant_block.py:99-103, openaimodel.py:
+ * 266-272: `h = out_norm(h) * (1 + scale) + shift`, then SiLU -> Dropout -> conv): mod holds one fp32 row per sample,
+ * [B][mod_ld >= 2 C] = scale | shift, the two halves of the block's embedding projection (th.chunk(emb_out, 2, dim=1)).
+ * The modulation is folded into the per-(sample, channel) affine of the normalisation; no raw second output.            */
+int qd_groupnorm_mod_silu_quant(const void* x, int x_dtype, int64_t B, int64_t S, int C, int64_t ldx,
+                                int groups, float eps, const float* gamma, const float* beta,
+                                int apply_silu,
+                                const float* qparams, int qmin, int qmax, int off,
+                                int8_t* out, int64_t ldo, float* yout, int64_t ldy,
+                                void* ws, const float* part_in, int nchunk_in, int64_t part_ld,
+                                const float* mod, int64_t mod_ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K9a LayerNorm -> quantise (up to 3 consumers).  Replaces nn.LayerNorm (attention.py:229-231)

@@ -193,15 +193,28 @@ def cifar_forward(Q, cfg, x, t, split_shortcut=True):
 # =================================================================================================
 # LDM / SD UNet  (openaimodel.py:447-782, attention.py, quant_block.py:44-282)
 # =================================================================================================
-def _ldm_resblock(Q, p, x, emb, cin, cout, split=0):
-    """QuantResBlock._forward (quant_block.py:83-111), no up/down, no scale-shift."""
-    h = Q.conv(p + ".in_layers.2", F.silu(Q.gn(p + ".in_layers.0", x, 1e-5)), 1, 1)
-    e = Q.linear(p + ".emb_layers.1", F.silu(emb)).type(h.dtype)
-    h = h + e[..., None, None]
-    h = Q.conv(p + ".out_layers.3", F.silu(Q.gn(p + ".out_layers.0", h, 1e-5)), 1, 1)
+def _ldm_resblock(Q, p, x, emb, cin, cout, split=0, updown=None, scale_shift=False):
+    """QuantResBlock._forward (quant_block.py:83-111).  updown: None | "up" | "down" — the resblock_updown variant resamples
+    h (after norm + SiLU) and x before the first convolution (:84-90; Upsample / Downsample without convolution,
+    openaimodel.py:108-119,139-160); scale_shift: use_scale_shift_norm (:99-103)."""
+    x_in = x
+    h = F.silu(Q.gn(p + ".in_layers.0", x, 1e-5))
+    if updown == "up":
+        h, x = F.interpolate(h, scale_factor=2, mode="nearest"), F.interpolate(x, scale_factor=2, mode="nearest")
+    elif updown == "down":
+        h, x = F.avg_pool2d(h, kernel_size=2, stride=2), F.avg_pool2d(x, kernel_size=2, stride=2)
+    h = Q.conv(p + ".in_layers.2", h, 1, 1)
+    e = Q.linear(p + ".emb_layers.1", F.silu(emb)).type(h.dtype)[..., None, None]
+    if scale_shift:
+        scale, shift = torch.chunk(e, 2, dim=1)
+        h = Q.gn(p + ".out_layers.0", h, 1e-5) * (1 + scale) + shift
+        h = Q.conv(p + ".out_layers.3", F.silu(h), 1, 1)
+    else:
+        h = h + e
+        h = Q.conv(p + ".out_layers.3", F.silu(Q.gn(p + ".out_layers.0", h, 1e-5)), 1, 1)
     if cin == cout:
-        return Q.block("ldm_res", p, x + h, x=x, emb=emb, split=0)
-    return Q.block("ldm_res", p, Q.conv(p + ".skip_connection", x, 1, 0, split=split) + h, x=x, emb=emb, split=split)
+        return Q.block("ldm_res", p, x + h, x=x_in, emb=emb, split=0)
+    return Q.block("ldm_res", p, Q.conv(p + ".skip_connection", x, 1, 0, split=split) + h, x=x_in, emb=emb, split=split)
 
 
 def _cross_attn(Q, p, x, context, heads):
@@ -277,6 +290,10 @@ def ldm_forward(Q, cfg, x, t, context=None, split=True):
     num_heads | num_head_channels, use_spatial_transformer, legacy)."""
     mc, mult, nrb = cfg["model_channels"], list(cfg["channel_mult"]), cfg["num_res_blocks"]
     st = bool(cfg.get("use_spatial_transformer", False))
+    ss, rud = bool(cfg.get("use_scale_shift_norm", False)), bool(cfg.get("resblock_updown", False))
+    if rud and split:
+        raise AttributeError("resblock_updown with the split shortcut: the reference raises here (quant_block.py:75, the "
+                             "resampling ResBlock's skip connection is an Identity without `.split`)")
     nhc, nh = cfg.get("num_head_channels", -1), cfg.get("num_heads", -1)
 
     def heads_at(ch):
@@ -297,7 +314,7 @@ def ldm_forward(Q, cfg, x, t, context=None, split=True):
     chans = [mc]
     for level, m in enumerate(mult):
         for _ in range(nrb):
-            h = _ldm_resblock(Q, f"input_blocks.{idx}.0", h, emb, ch, m * mc)
+            h = _ldm_resblock(Q, f"input_blocks.{idx}.0", h, emb, ch, m * mc, scale_shift=ss)
             ch = m * mc
             if ds in cfg["attention_resolutions"]:
                 Q.note(f"input_blocks.{idx}.0", h)
@@ -307,27 +324,33 @@ def ldm_forward(Q, cfg, x, t, context=None, split=True):
             chans.append(ch)
             idx += 1
         if level != len(mult) - 1:
-            h = Q.note(f"input_blocks.{idx}", Q.block("conv", f"input_blocks.{idx}.0.op", Q.conv(f"input_blocks.{idx}.0.op", h, 2, 1), x=h))
+            if rud:
+                h = Q.note(f"input_blocks.{idx}", _ldm_resblock(Q, f"input_blocks.{idx}.0", h, emb, ch, ch, updown="down", scale_shift=ss))
+            else:
+                h = Q.note(f"input_blocks.{idx}", Q.block("conv", f"input_blocks.{idx}.0.op", Q.conv(f"input_blocks.{idx}.0.op", h, 2, 1), x=h))
             hs.append(h)
             chans.append(ch)
             idx += 1
             ds *= 2
-    h = Q.note("middle_block.0", _ldm_resblock(Q, "middle_block.0", h, emb, ch, ch))
+    h = Q.note("middle_block.0", _ldm_resblock(Q, "middle_block.0", h, emb, ch, ch, scale_shift=ss))
     h = Q.note("middle_block.1", attn("middle_block.1", h, ch))
-    h = Q.note("middle_block", _ldm_resblock(Q, "middle_block.2", h, emb, ch, ch))
+    h = Q.note("middle_block", _ldm_resblock(Q, "middle_block.2", h, emb, ch, ch, scale_shift=ss))
     idx = 0
     for level, m in list(enumerate(mult))[::-1]:
         for i in range(nrb + 1):
             skip = hs.pop()
             sp = h.shape[1] if split else 0
             cin = h.shape[1] + skip.shape[1]
-            h = _ldm_resblock(Q, f"output_blocks.{idx}.0", torch.cat([h, skip], dim=1), emb, cin, mc * m, split=sp)
+            h = _ldm_resblock(Q, f"output_blocks.{idx}.0", torch.cat([h, skip], dim=1), emb, cin, mc * m, split=sp, scale_shift=ss)
             ch = mc * m
             j = 1
             if ds in cfg["attention_resolutions"]:
                 h = attn(f"output_blocks.{idx}.{j}", h, ch)
                 j += 1
-            if level and i == nrb:
+            if level and i == nrb and rud:
+                h = _ldm_resblock(Q, f"output_blocks.{idx}.{j}", h, emb, ch, ch, updown="up", scale_shift=ss)
+                ds //= 2
+            elif level and i == nrb:
                 h = Q.block("ldm_upsample", f"output_blocks.{idx}.{j}", Q.conv(f"output_blocks.{idx}.{j}.conv", F.interpolate(h, scale_factor=2, mode="nearest"), 1, 1), x=h)
                 ds //= 2
             Q.note(f"output_blocks.{idx}", h)

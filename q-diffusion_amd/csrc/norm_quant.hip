@@ -75,6 +75,22 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     }
 }
 
+// use_scale_shift_norm residual blocks (reference quant_block.py:99-103: `out_norm(h) * (1 + scale) + shift`, scale | shift =
+// the two halves of the block's embedding projection, one row per sample): the modulation is folded into the per-(sample,
+// channel) affine the apply pass already uses — a' = a (1 + scale), sh' = sh (1 + scale) + shift — so the apply pass and its
+// one read of the tensor stay as they are.  mod: [B][>= 2C] fp32 rows.
+__global__ __launch_bounds__(256) void gn_modulate_kernel(float* __restrict__ ab, const float* __restrict__ mod, long ldm, int C,
+                                                          long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / C;
+    const int c = (int)(i - b * C);
+    const float sc = 1.0f + mod[b * ldm + c], sf = mod[b * ldm + C + c];
+    const float a = ab[2 * i], sh = ab[2 * i + 1];
+    ab[2 * i] = a * sc;
+    ab[2 * i + 1] = sh * sc + sf;
+}
+
 // second, optional output of the apply pass: the RAW input quantised for another consumer of the same tensor — the 1x1
 // skip connection of a residual block (reference quant_block.py:108-111: `skip_connection(x, split)` reads the very
 // tensor `in_layers` normalises; up to two channel segments with their own activation quantisers, quant_layer.py:257-269).
@@ -326,10 +342,11 @@ extern "C" int64_t qd_groupnorm_ws_bytes(int64_t B, int64_t C, int64_t S) {
     return (B * nchunk * C * 2 + B * C * 2) * (int64_t)sizeof(float);
 }
 
-extern "C" int qd_groupnorm_silu_quant(const void* x, int x_dtype, int64_t B, int64_t S, int C, int64_t ldx, int groups,
-                                       float eps, const float* gamma, const float* beta, int apply_silu,
-                                       const float* qparams, int qmin, int qmax, int off, int8_t* out, int64_t ldo,
-                                       float* yout, int64_t ldy, void* ws, const float* part_in, int nchunk_in, int64_t part_ld, const qd_raw_quant* raw, void* stream) {
+static int groupnorm_impl(const void* x, int x_dtype, int64_t B, int64_t S, int C, int64_t ldx, int groups,
+                          float eps, const float* gamma, const float* beta, int apply_silu,
+                          const float* qparams, int qmin, int qmax, int off, int8_t* out, int64_t ldo,
+                          float* yout, int64_t ldy, void* ws, const float* part_in, int nchunk_in, int64_t part_ld, const qd_raw_quant* raw,
+                          const float* mod, int64_t mod_ld, void* stream) {
     QD_REQUIRE(x && ws && (out || yout), "qd_groupnorm_silu_quant: null pointer");
     QD_REQUIRE(!out || qparams, "qd_groupnorm_silu_quant: quantised output needs qparams");
     QD_REQUIRE(x_dtype == QD_F32 || x_dtype == QD_F16, "qd_groupnorm_silu_quant: dtype must be f32/f16");
@@ -351,6 +368,11 @@ extern "C" int qd_groupnorm_silu_quant(const void* x, int x_dtype, int64_t B, in
     else
         hipLaunchKernelGGL(gn_partial_kernel<__half>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, (const __half*)x, (long)S, C, (long)ldx, part, nchunk, vec);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, (unsigned)B), dim3(64), 0, st, part_in ? part_in : part, nchunk, ldp, (long)S, C, groups, eps, gamma, beta, ab);
+    if (mod) {
+        QD_REQUIRE(mod_ld >= 2 * (int64_t)C, "qd_groupnorm_mod_silu_quant: modulation rows hold scale | shift: mod_ld >= 2 C");
+        const long tot = (long)B * C;
+        hipLaunchKernelGGL(gn_modulate_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ab, mod, (long)mod_ld, C, tot);
+    }
     RawQ rq{};
     if (raw && raw->out) {
         QD_REQUIRE(raw->nseg == 1 || raw->nseg == 2, "qd_groupnorm_silu_quant: raw output takes 1 or 2 segments");
@@ -386,6 +408,24 @@ extern "C" int qd_groupnorm_silu_quant(const void* x, int x_dtype, int64_t B, in
         hipLaunchKernelGGL(gn_apply_kernel<__half>, grid, dim3(256), 0, st, (const __half*)x, rows, (long)S, C, (long)ldx, ab, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, yout, (long)ldy, vec, rq);
     QD_LAUNCH_CHECK("qd_groupnorm_silu_quant");
     return 0;
+}
+
+extern "C" int qd_groupnorm_silu_quant(const void* x, int x_dtype, int64_t B, int64_t S, int C, int64_t ldx, int groups,
+                                       float eps, const float* gamma, const float* beta, int apply_silu,
+                                       const float* qparams, int qmin, int qmax, int off, int8_t* out, int64_t ldo,
+                                       float* yout, int64_t ldy, void* ws, const float* part_in, int nchunk_in, int64_t part_ld, const qd_raw_quant* raw, void* stream) {
+    return groupnorm_impl(x, x_dtype, B, S, C, ldx, groups, eps, gamma, beta, apply_silu, qparams, qmin, qmax, off, out, ldo, yout, ldy, ws,
+                          part_in, nchunk_in, part_ld, raw, nullptr, 0, stream);
+}
+
+extern "C" int qd_groupnorm_mod_silu_quant(const void* x, int x_dtype, int64_t B, int64_t S, int C, int64_t ldx, int groups,
+                                           float eps, const float* gamma, const float* beta, int apply_silu,
+                                           const float* qparams, int qmin, int qmax, int off, int8_t* out, int64_t ldo,
+                                           float* yout, int64_t ldy, void* ws, const float* part_in, int nchunk_in, int64_t part_ld,
+                                           const float* mod, int64_t mod_ld, void* stream) {
+    QD_REQUIRE(mod, "qd_groupnorm_mod_silu_quant: null modulation rows");
+    return groupnorm_impl(x, x_dtype, B, S, C, ldx, groups, eps, gamma, beta, apply_silu, qparams, qmin, qmax, off, out, ldo, yout, ldy, ws,
+                          part_in, nchunk_in, part_ld, nullptr, mod, mod_ld, stream);
 }
 
 extern "C" int qd_layernorm_quant(const void* x, int x_dtype, int64_t M, int C, int64_t ldx, float eps,

@@ -425,11 +425,13 @@ def raw_quant_segs(plan, C):
     return segs if pos == C and 1 <= len(segs) <= 2 else None
 
 
-def groupnorm_silu_quant(x_rows, B, S, C, gn, silu, plan=None, want_float=False, part=None, raw_plan=None):
+def groupnorm_silu_quant(x_rows, B, S, C, gn, silu, plan=None, want_float=False, part=None, raw_plan=None, mod=None):
     """x_rows: channels-last rows [B*S][>=C] (fp32/fp16).  Returns (int8 rows for `plan`, float rows) — and, with
     raw_plan (the ConvPlan of a 1x1 consumer of the SAME un-normalised tensor: a residual block's skip connection), a
     third value: that consumer's int8 input rows, quantised in the same pass over x.
-    part: first-level statistics that came with x_rows from its producer (conv_forward(gn_stats=True))."""
+    part: first-level statistics that came with x_rows from its producer (conv_forward(gn_stats=True)).
+    mod: [B][2C] fp32 rows scale | shift — GroupNorm(x) * (1 + scale) + shift of a use_scale_shift_norm residual block
+    (reference quant_block.py:99-103), folded into the normalisation's affine."""
     part = _part_view(part, B, S, C)
     dev = x_rows.device
     ws = _workspace(hip.groupnorm_ws_bytes(B, C, S), dev)
@@ -446,7 +448,7 @@ def groupnorm_silu_quant(x_rows, B, S, C, gn, silu, plan=None, want_float=False,
         raw = dict(out=raw_out, segs=segs)
     hip.groupnorm_silu_quant(x_rows, B, S, C, x_rows.stride(0), gn.num_groups, gn.eps, gn.weight, gn.bias, silu,
                              plan.qparams[0] if plan is not None else None, plan.grids[0] if plan is not None else None,
-                             out, plan.ldx if plan is not None else 0, ws, yout=y, ldy=C, part=part, raw=raw)
+                             out, plan.ldx if plan is not None else 0, ws, yout=y, ldy=C, part=part, raw=raw, mod=mod)
     if raw_plan is not None:
         return out, y, raw_out
     return out, y

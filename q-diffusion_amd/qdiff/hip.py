@@ -63,7 +63,7 @@ EPI_LINEAR, EPI_GEGLU_I8, EPI_HEADS_I8, EPI_HEADS_T_I8 = 0, 1, 2, 3
 EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_make_qparams", "qd_quantize_act", "qd_pack_weights", "qd_pack_weights_t4",
            "qd_pack_weights_t8",
            "qd_conv2d_i8", "qd_conv2d_i8_splitk_ws_bytes",
-           "qd_conv2d_i8_acc", "qd_groupnorm_ws_bytes", "qd_groupnorm_silu_quant", "qd_layernorm_quant",
+           "qd_conv2d_i8_acc", "qd_groupnorm_ws_bytes", "qd_groupnorm_silu_quant", "qd_groupnorm_mod_silu_quant", "qd_layernorm_quant",
            "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8", "qd_bmm_qk_i8", "qd_bmm_pv_i8", "qd_temb_mlp",
            "qd_fakequant_blocks", "qd_fakequant_fwd", "qd_fakequant_bwd", "qd_conv3x3_halo_ok", "qd_conv3x3_halo_i8"]
 
@@ -94,6 +94,8 @@ def load():
     lib.qd_conv2d_i8_splitk_ws_bytes.restype = ctypes.c_int64
     lib.qd_groupnorm_silu_quant.argtypes = [vp, i32, i64, i64, i32, i64, i32, f32, vp, vp, i32, vp, i32, i32, i32, vp,
                                             i64, vp, i64, vp, vp, i32, i64, ctypes.POINTER(RawQuant), vp]
+    lib.qd_groupnorm_mod_silu_quant.argtypes = [vp, i32, i64, i64, i32, i64, i32, f32, vp, vp, i32, vp, i32, i32, i32, vp,
+                                                i64, vp, i64, vp, vp, i32, i64, vp, i64, vp]
     lib.qd_layernorm_quant.argtypes = [vp, i32, i64, i32, i64, f32, vp, vp, i32, ctypes.POINTER(vp),
                                        ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32),
                                        ctypes.POINTER(vp), i64, vp]
@@ -111,7 +113,7 @@ def load():
     lib.qd_fakequant_bwd.argtypes = [vp, vp, i64, vp, vp, i32, i32, vp, vp, vp]
     lib.qd_conv3x3_halo_ok.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.qd_conv3x3_halo_i8.argtypes = [ctypes.POINTER(ConvDesc), vp]
-    if lib.qd_abi_version() != 14:
+    if lib.qd_abi_version() != 15:
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -342,11 +344,23 @@ def raw_quant_desc(raw):
 
 
 def groupnorm_silu_quant(x, B, S, C, ldx, groups, eps, gamma, beta, silu, qparams, grid, out, ldo, ws, yout=None, ldy=0,
-                         part=None, raw=None):
+                         part=None, raw=None, mod=None):
     """part: optional [B][nchunk][C][2] fp32 first-level statistics written by the producer of x (ConvCall.gn_part);
     raw: optional second output, the un-normalised input quantised for the residual block's 1x1 skip connection
-    (include/qdiff_hip.h qd_raw_quant)."""
+    (include/qdiff_hip.h qd_raw_quant);
+    mod: optional [B][>= 2C] fp32 rows scale | shift of a use_scale_shift_norm block (qd_groupnorm_mod_silu_quant)."""
     g = grid or Grid(0, 0, 0)
+    if mod is not None:
+        if raw is not None:
+            raise HipEngineError("groupnorm_silu_quant: a modulated norm has no raw second output")
+        if mod.dtype != torch.float32 or mod.dim() != 2 or mod.shape[0] != B or mod.shape[1] < 2 * C or mod.stride(1) != 1:
+            raise HipEngineError("groupnorm_silu_quant: mod must be fp32 rows [B][>= 2C]")
+        _check(load().qd_groupnorm_mod_silu_quant(_ptr(x), _dtype(x), B, S, C, ldx, groups, float(eps), _ptr(gamma), _ptr(beta),
+                                                  1 if silu else 0, _ptr(_qp(qparams)), g.qmin, g.qmax, g.off, _ptr(out), ldo,
+                                                  _ptr(yout), ldy, _ptr(ws), _ptr(part), part.shape[1] if part is not None else 0,
+                                                  part_ld(part) if part is not None else 0, _ptr(mod), mod.stride(0), _stream()),
+               "qd_groupnorm_mod_silu_quant")
+        return
     rq, keep = raw_quant_desc(raw)
     _check(load().qd_groupnorm_silu_quant(_ptr(x), _dtype(x), B, S, C, ldx, groups, float(eps), _ptr(gamma), _ptr(beta),
                                           1 if silu else 0, _ptr(_qp(qparams)), g.qmin, g.qmax, g.off, _ptr(out), ldo,

@@ -116,15 +116,17 @@ def _aq_ready(*quantizers):
     return all(q.inited and not q.running_stat for q in quantizers)
 
 
-def _gn_silu_to(conv, rows, B, S, C, gn, silu=True, raw_plan=None):
+def _gn_silu_to(conv, rows, B, S, C, gn, silu=True, raw_plan=None, mod=None):
     """GroupNorm(+SiLU) -> int8 rows for `conv`; initialises conv's act quantiser on first use.
     raw_plan: also return the int8 rows of a 1x1 consumer of the un-normalised `rows` (the skip connection), quantised
-    in the same pass."""
+    in the same pass.  mod: [B][2C] scale | shift rows of a use_scale_shift_norm block (reference :99-103)."""
     if not conv.act_quantizer.inited:
         y = F.group_norm(rows.view(B, S, C).permute(0, 2, 1).float(), gn.num_groups, gn.weight, gn.bias, gn.eps)
+        if mod is not None:
+            y = y * (1 + mod[:, :C, None]) + mod[:, C:2 * C, None]
         conv._init_act_quantizers(F.silu(y) if silu else y)
     res = engine.groupnorm_silu_quant(rows, B, S, C, gn, silu, plan=conv.conv_plan(), part=getattr(rows, "qd_gn_part", None),
-                                      raw_plan=raw_plan)
+                                      raw_plan=raw_plan, mod=mod)
     return (res[0], res[2]) if raw_plan is not None else res[0]
 
 
@@ -397,9 +399,10 @@ class QuantResBlock(BaseQuantBlock, ldm_unet.TimestepBlock):
         if emb is None:
             x, emb = x
         assert x.shape[2] == x.shape[3]
+        H_ = x.shape[2]
         conv1, conv2 = self.in_layers[-1], self.out_layers[-1]
-        if (not self.updown and not self.use_scale_shift_norm and _int_mode(conv1, conv2, self.emb_layers[-1])
-                and conv1.split == 0 and conv2.split == 0):
+        if (_int_mode(conv1, conv2, self.emb_layers[-1]) and conv1.split == 0 and conv2.split == 0
+                and (not self.updown or (H_ % 2 == 0 and not getattr(self.h_upd, "use_conv", False)))):
             return self._forward_int(x, emb, split, conv1, conv2, out_slot)
         return self._forward_sim(x, emb, split)
 
@@ -436,21 +439,55 @@ class QuantResBlock(BaseQuantBlock, ldm_unet.TimestepBlock):
         return plan if engine.raw_quant_segs(plan, C) is not None else None
 
     def _forward_int(self, x, emb, split, conv1, conv2, out_slot=None):
+        """Reference :83-111 on the integer engine.  Plain blocks: GN.SiLU -> int8 (one pass; the skip connection's rows in
+        the same pass), conv1 with the embedding as a row bias and the next norm's statistics in its epilogue, GN.SiLU ->
+        int8, conv2 with the residual in its epilogue.  `updown` blocks (:84-90) resample between the first norm and the
+        first convolution: nearest-2x commutes with the quantiser, so the SMALL map is quantised and its int8 rows are
+        replicated; the 2x2 average does not, so the norm writes fp32 rows, torch averages them (F.avg_pool2d, as the
+        reference) and the small map is quantised.  `use_scale_shift_norm` blocks (:99-103) hand the two halves of the
+        embedding projection to the second norm as a per-sample modulation (qd_groupnorm_mod_silu_quant) instead of
+        adding the projection to h."""
         B, C, H, W = x.shape
         S = H * W
         rows = _nhwc_rows(x)
-        skp = None if isinstance(self.skip_connection, nn.Identity) else self._skip_plan(split, C)
-        if skp is not None:
+        ident = isinstance(self.skip_connection, nn.Identity)
+        up = self.updown and not hasattr(self.h_upd, "op")            # Upsample has .conv / nothing, Downsample has .op
+        down = self.updown and not up
+        skp = None if (ident or self.updown) else self._skip_plan(split, C)
+        if down:
+            y = engine.groupnorm_silu_quant(rows, B, S, C, self.in_layers[0], True, want_float=True,
+                                            part=getattr(rows, "qd_gn_part", None))[1]
+            hp = self.h_upd(_rows_to_nchw(y, B, H, W))
+            x = self.x_upd(x)
+            H, W = H // 2, W // 2
+            S = H * W
+            conv1._init_act_quantizers(hp)
+            hp = _nhwc_rows(hp)
+            xq = engine.quantize_rows(hp, conv1.conv_plan(), 1, C, B * S, (0, 1, hp.stride(0)))
+            rows = _nhwc_rows(x)
+        elif skp is not None:
             xq, skq = _gn_silu_to(conv1, rows, B, S, C, self.in_layers[0], raw_plan=skp)
         else:
             xq = _gn_silu_to(conv1, rows, B, S, C, self.in_layers[0])
+        if up:
+            xq = xq.view(B, H, 1, W, 1, -1).expand(B, H, 2, W, 2, xq.shape[1]).reshape(B * 4 * S, xq.shape[1])
+            x = self.x_upd(x)
+            H, W = 2 * H, 2 * W
+            S = H * W
+            rows = _nhwc_rows(x)
         grp = self.__dict__.get("_emb_group")
         e = grp.get(self, emb) if grp is not None else None           # all blocks' projections in one launch (K6)
         if e is None:
-            e = self.emb_layers(emb).float().contiguous()             # SiLU + integer linear -> [B, Cout]
-        h = conv1.forward_codes(xq, B, H, W, rowbias=e, gn_stats=True)
-        hq = _gn_silu_to(conv2, h, B, S, self.out_channels, self.out_layers[0])
-        if isinstance(self.skip_connection, nn.Identity):
+            e = self.emb_layers(emb).float().contiguous()             # SiLU + integer linear -> [B, Cout] (2 Cout: scale | shift)
+        if self.use_scale_shift_norm:
+            h = conv1.forward_codes(xq, B, H, W, gn_stats=True)
+            if e.stride(1) != 1:
+                e = e.contiguous()
+            hq = _gn_silu_to(conv2, h, B, S, self.out_channels, self.out_layers[0], mod=e)
+        else:
+            h = conv1.forward_codes(xq, B, H, W, rowbias=e, gn_stats=True)
+            hq = _gn_silu_to(conv2, h, B, S, self.out_channels, self.out_layers[0])
+        if ident:
             res = rows
         elif skp is not None:
             res = self.skip_connection.forward_codes(skq, B, H, W)

@@ -206,8 +206,12 @@ def groupnorm_ws_bytes(B, C, S):
 
 
 def groupnorm_silu_quant(x, B, S, C, ldx, groups, eps, gamma, beta, silu, qparams, grid, out, ldo, ws, yout=None, ldy=0,
-                         part=None, raw=None):
+                         part=None, raw=None, mod=None):
     v = x[:, :C].float().reshape(B, S, C).permute(0, 2, 1)
+    if mod is not None:
+        # qd_groupnorm_mod_silu_quant: scale | shift rows of a use_scale_shift_norm block
+        assert raw is None and mod.dtype == torch.float32 and mod.shape[0] == B and mod.shape[1] >= 2 * C
+        sc, sf = 1.0 + mod[:, :C].reshape(B, C, 1), mod[:, C:2 * C].reshape(B, C, 1)
     if raw is not None:
         # qd_raw_quant: the un-normalised input quantised per channel segment for the 1x1 skip connection
         for sg in raw["segs"]:
@@ -222,9 +226,14 @@ def groupnorm_silu_quant(x, B, S, C, ldx, groups, eps, gamma, beta, silu, qparam
         rstd = (1.0 / torch.sqrt(var + eps)).float().repeat_interleave(C // groups, dim=1).view(B, C, 1)
         fmean = mean.float().repeat_interleave(C // groups, dim=1).view(B, C, 1)
         a = rstd * gamma.view(1, C, 1)
-        y = v * a + (beta.view(1, C, 1) - fmean * a)
+        sh = beta.view(1, C, 1) - fmean * a
+        if mod is not None:                                   # the kernel folds the modulation into the affine
+            a, sh = a * sc, sh * sc + sf
+        y = v * a + sh
     else:
         y = F.group_norm(v, groups, gamma, beta, eps)
+        if mod is not None:
+            y = y * sc + sf
     if silu:
         y = y * torch.sigmoid(y)
     rows = y.permute(0, 2, 1).reshape(B * S, C)

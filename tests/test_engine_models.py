@@ -75,7 +75,12 @@ def _metrics(y, ref):
     return d, cos, ref.abs().max().item()
 
 
-@pytest.mark.parametrize("name", TINY + FULL)
+# ldm_updown_tiny: resblock_updown + use_scale_shift_norm (the LSUN-Churches LDM-8 block variants); collected late: added
+# after the round's last GPU run
+LATE = [pytest.param("ldm_updown_tiny", marks=pytest.mark.late)]
+
+
+@pytest.mark.parametrize("name", TINY + FULL + LATE)
 def test_quantised_unet_matches_reference(cuda, name):
     fx = load_fixture(f"model_{name}.pt")
     qnn = _resume(fx, cuda)
@@ -98,7 +103,7 @@ def test_quantised_unet_matches_reference(cuda, name):
     assert d64 <= 1.25 * dself + 1e-3 * mx, f"{name}: engine is {d64 / mx:.3e} of range from the fp64 evaluation, the reference {dself / mx:.3e}"
     assert d <= 1.5 * dself + 1e-3 * mx, f"{name}: {d / mx:.3e} of range vs envelope {dself / mx:.3e}"
     assert cos >= 0.995 and cos64 >= cosself - 1e-3
-    if name in TINY + ["cifar_full"]:
+    if name in TINY + ["cifar_full", "ldm_updown_tiny"]:
         qnn.set_quant_state(True, False)
         d, cos, mx = _metrics(_run(qnn, fx, cuda), fx["out_w"])
         print(f"[{name}] W-only: max|diff|={d:.3e}")

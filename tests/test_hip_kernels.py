@@ -420,6 +420,46 @@ def test_groupnorm_silu_quant(cuda, silu, C, S):
     assert mx <= 1 and frac <= 1e-3
 
 
+@pytest.mark.late
+@pytest.mark.parametrize("silu", [True, False])
+@pytest.mark.parametrize("C,S,from_part", [(64, 100, False), (384, 256, False), (768, 64, True)])
+def test_groupnorm_modulated_silu_quant(cuda, silu, C, S, from_part):
+    """qd_groupnorm_mod_silu_quant: `GroupNorm(h) * (1 + scale) + shift` of a use_scale_shift_norm residual block
+    (reference quant_block.py:99-103) -> SiLU -> codes, the modulation folded into the normalisation's per-(sample, channel)
+    affine.  Same criterion as the plain kernel: fp32 output within rounding of the torch composition, codes off by at most
+    one on <= 0.1 % of the elements.  from_part: statistics from first-level partial sums (the producer-epilogue route)."""
+    from qdiff import engine, hip
+    g = torch.Generator().manual_seed(9)
+    B = 3
+    x = torch.randn(B, C, 1, S, generator=g) * 2 + 0.3
+    mod = torch.randn(B, 2 * C + 8, generator=g) * 0.7                     # rows wider than 2C: mod_ld is honoured
+    gn = torch.nn.GroupNorm(32, C, eps=1e-5)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C, generator=g))
+        gn.bias.copy_(torch.randn(C, generator=g))
+        y = gn(x) * (1 + mod[:, :C, None, None]) + mod[:, C:2 * C, None, None]
+        y = R.silu(y) if silu else y
+    d, z = R.uaq_init_scale(y, 8, False, False, "max")
+    want = R.uaq_codes(y, d, z, 8, False) - 128
+    rows = x.to(cuda).permute(0, 2, 3, 1).reshape(B * S, C).contiguous()
+    part = None
+    if from_part:
+        nchunk = 4
+        r = rows.view(B, nchunk, S // nchunk, C).double()
+        part = torch.stack([r.sum(2), (r * r).sum(2)], dim=-1).float().contiguous()      # [B][nchunk][C][2]
+    ws = torch.empty(hip.groupnorm_ws_bytes(B, C, S), dtype=torch.uint8, device=cuda)
+    out = torch.empty((B * S, C), dtype=torch.int8, device=cuda)
+    yo = torch.empty((B * S, C), dtype=torch.float32, device=cuda)
+    hip.groupnorm_silu_quant(rows, B, S, C, C, 32, 1e-5, gn.weight.data.to(cuda), gn.bias.data.to(cuda), silu,
+                             torch.tensor([float(d), float(z)], device=cuda), engine.act_grid(8, False), out, C, ws, yout=yo, ldy=C,
+                             part=part, mod=mod.to(cuda))
+    torch.cuda.synchronize()
+    yref = y.permute(0, 2, 3, 1).reshape(B * S, C)
+    assert (yo.cpu() - yref).abs().max().item() <= 1e-5 * max(1.0, yref.abs().max().item())
+    mx, frac = _code_mismatch(out.cpu(), want.permute(0, 2, 3, 1).reshape(B * S, C))
+    assert mx <= 1 and frac <= 1e-3
+
+
 def test_layernorm_quant_three_consumers(cuda):
     from qdiff import engine, hip
     g = torch.Generator().manual_seed(8)

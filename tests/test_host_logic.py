@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     from qdiff import hip
     assert sorted(hip.EXPORTS) == declared
     lib.qd_abi_version.restype = ctypes.c_int
-    assert lib.qd_abi_version() == 14
+    assert lib.qd_abi_version() == 15
     assert lib.qd_device_ok() in (0, 1)                  # no compute calls without a GPU
 
 
@@ -158,7 +158,7 @@ def test_quant_module_kinds_on_emulator(emu):
         assert (y - c["y"]).abs().max() <= 2e-5 * c["y"].abs().max(), (c["kind"], c["w_bits"], c["a_sym"], c["split"])
 
 
-@pytest.mark.parametrize("name", ["cifar_tiny", "ldm_tiny", "sd_tiny"])
+@pytest.mark.parametrize("name", ["cifar_tiny", "ldm_tiny", "sd_tiny", "ldm_updown_tiny"])
 def test_tiny_unets_on_emulator(emu, name):
     """resume_cali_model + fused integer blocks end to end on CPU.  Bound: the reference's own
     fp32-vs-fp64 envelope — max|diff| <= 0.1 * range and cosine >= 0.998."""
@@ -183,7 +183,7 @@ def test_tiny_unets_on_emulator(emu, name):
         assert (y - fx[key]).abs().max() <= 1e-4 * fx[key].abs().max()
 
 
-@pytest.mark.parametrize("name", ["cifar_tiny", "ldm_tiny", "sd_tiny"])
+@pytest.mark.parametrize("name", ["cifar_tiny", "ldm_tiny", "sd_tiny", "ldm_updown_tiny"])
 def test_checkpoint_schema_and_resume_types(emu, name):
     from qdiff.adaptive_rounding import AdaRoundQuantizer
     from qdiff.quant_layer import UniformAffineQuantizer
@@ -203,7 +203,7 @@ def test_checkpoint_schema_and_resume_types(emu, name):
             assert isinstance(m.zero_point, int) and isinstance(m.delta, torch.nn.Parameter)
         if getattr(m, "split", 0):
             n_split += 1
-    assert n_split > 0, "split shortcut never engaged"
+    assert (n_split > 0) == bool(fx["spec"]["split"]), "split shortcut engaged / not engaged against the spec"
 
 
 def test_plan_cache_tracks_quantiser_changes(emu):
@@ -333,7 +333,7 @@ def test_packed_checkpoint_round_trip(emu, name, tmp_path):
     assert mods and all(m.weight.numel() == 0 for m in mods)
 
 
-@pytest.mark.parametrize("name", ["cifar_tiny", "ldm_tiny", "sd_tiny"])
+@pytest.mark.parametrize("name", ["cifar_tiny", "ldm_tiny", "sd_tiny", "ldm_updown_tiny"])
 def test_blocks_teacher_forced_on_emulator(emu, name):
     """The teacher-forced per-block harness of tests/test_block_parity.py (GPU, full shapes) on the CPU ABI emulator:
     every fused block wiring of qdiff/quant_block.py fed with the oracle's block inputs reproduces the oracle's block

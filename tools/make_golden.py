@@ -67,6 +67,14 @@ MODELS = {
     "ldm_tiny": dict(family="ldm", w_bits=4, a_bits=8, a_sym=True, sm_abit=8, split=True, x=(3, 16, 16), ctx=None,
                      unet=dict(image_size=16, in_channels=3, out_channels=3, model_channels=32, attention_resolutions=[2, 1],
                                num_res_blocks=1, channel_mult=[1, 2], num_head_channels=16)),
+    # ResBlocks that resample inside the block (resblock_updown) and modulate the second norm (use_scale_shift_norm):
+    # reference quant_block.py:83-107, the branches no BASELINE config takes.  split=False: with the split shortcut the
+    # reference hands `split` to the up-sampling ResBlock too, whose skip connection is an Identity without that
+    # attribute (quant_block.py:75 raises AttributeError)
+    "ldm_updown_tiny": dict(family="ldm", w_bits=4, a_bits=8, a_sym=True, sm_abit=8, split=False, x=(3, 16, 16), ctx=None,
+                            unet=dict(image_size=16, in_channels=3, out_channels=3, model_channels=32, attention_resolutions=[2],
+                                      num_res_blocks=1, channel_mult=[1, 2], num_head_channels=16, resblock_updown=True,
+                                      use_scale_shift_norm=True)),
     "sd_tiny": dict(family="ldm", w_bits=4, a_bits=8, a_sym=False, sm_abit=16, split=True, x=(4, 16, 16), ctx=(7, 48),
                     unet=dict(image_size=16, in_channels=4, out_channels=4, model_channels=64, attention_resolutions=[2, 1],
                               num_res_blocks=1, channel_mult=[1, 2], num_heads=4, use_spatial_transformer=True,
