@@ -56,6 +56,14 @@ def build_quantised_unet(kind, device, seed=0):
         wq = dict(n_bits=4, channel_wise=True, scale_method="max")
         aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True, symmetric=True)
         sm_abit = 8
+    elif kind == "churches":
+        # LSUN-Churches LDM-8 (README.md:53-55): resampling ResBlocks with scale-shift norms; no split shortcut (the
+        # reference cannot combine it with resblock_updown, tools/make_golden.py)
+        model = ldm_unet.UNetModel(**ldm_unet.lsun_churches_config())
+        model.split = False
+        wq = dict(n_bits=4, channel_wise=True, scale_method="max")
+        aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True, symmetric=True)
+        sm_abit = 8
     else:
         model = ddim_unet.Model(ddim_unet.cifar10_config(split_shortcut=True))
         wq = dict(n_bits=8, channel_wise=True, scale_method="max")
@@ -86,15 +94,16 @@ def build_skeleton(kind, device, seed=777):
     if kind == "sd":
         model, sm_abit = ldm_unet.UNetModel(**ldm_unet.sd_v1_config()), 16
         wq, aq = dict(n_bits=4, channel_wise=True, scale_method="max"), dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True)
-    elif kind == "ldm":
-        model, sm_abit = ldm_unet.UNetModel(**ldm_unet.lsun_beds_config()), 8
+    elif kind in ("ldm", "churches"):
+        cfg = ldm_unet.lsun_beds_config() if kind == "ldm" else ldm_unet.lsun_churches_config()
+        model, sm_abit = ldm_unet.UNetModel(**cfg), 8
         wq = dict(n_bits=4, channel_wise=True, scale_method="max")
         aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True, symmetric=True)
     else:
         model, sm_abit = ddim_unet.Model(ddim_unet.cifar10_config(split_shortcut=True)), 8
         wq = dict(n_bits=8, channel_wise=True, scale_method="max")
         aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True, symmetric=True)
-    if kind != "cifar":
+    if kind in ("sd", "ldm"):
         model.split = True
     synthetic.load_synthetic_weights(model, seed=seed)
     qnn = qdiff.QuantModel(model.to(device).eval(), wq, aq, sm_abit=sm_abit).to(device).eval()
@@ -195,7 +204,7 @@ def cpu_baseline(qnn, qspec, kind, cfg, k=2):
             if kind == "cifar":
                 U.cifar_forward(Q, cfg, x, t, split_shortcut=True)
             else:
-                U.ldm_forward(Q, cfg, x, t, c, split=True)
+                U.ldm_forward(Q, cfg, x, t, c, split=kind != "churches")
     one()
     t0 = time.time()
     for _ in range(k):
@@ -232,7 +241,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--images-per-gpu", type=int, default=8, help="n images per GPU (UNet batch 2n with CFG)")
-    ap.add_argument("--model", default="sd", choices=["sd", "ldm", "cifar"])
+    ap.add_argument("--model", default="sd", choices=["sd", "ldm", "cifar", "churches"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-denominators", action="store_true", help="skip the fp32 / fake-quant GPU denominators")
@@ -268,11 +277,15 @@ def main():
         shape, ctx_shape, guide, evals = (3, 64, 64), None, 1.0, 200
         betas = sampling.ldm_betas(0.0015, 0.0195)
         ocfg = ldm_unet.lsun_beds_config()
+    elif kind == "churches":
+        shape, ctx_shape, guide, evals = (4, 32, 32), None, 1.0, 400          # README.md:53-55: -c 400 -e 0.0
+        betas = sampling.ldm_betas(0.0015, 0.0155)                            # models/ldm/lsun_churches256/config.yaml:5-6
+        ocfg = ldm_unet.lsun_churches_config()
     else:
         shape, ctx_shape, guide, evals = (3, 32, 32), None, 1.0, 100
         betas = sampling.ddpm_betas()
         ocfg = dict(ch=128, ch_mult=[1, 2, 2, 2], num_res_blocks=2, attn_resolutions=[16], resolution=32)
-    table = sampling.StepTable(betas, 50 if kind == "sd" else (200 if kind == "ldm" else 100), eta=0.0)
+    table = sampling.StepTable(betas, {"sd": 50, "ldm": 200, "churches": 400}.get(kind, 100), eta=0.0)
     gb = n * world
     x = sampling.sharded_noise((gb,) + shape, seed=0, world_size=world, rank=rank, device=dev)
     cond = uncond = None
@@ -357,7 +370,7 @@ def main():
             break
         # whole-step view: every integer op of the evaluation (contractions + attention, SURVEY.md §8d per-sample figures)
         # against the wall clock of the timed sampler step
-        per_sample_gop = {"sd": 803.0, "ldm": 202.0, "cifar": 12.5}[kind]
+        per_sample_gop = {"sd": 803.0, "ldm": 202.0, "cifar": 12.5, "churches": 41.8}[kind]
         step_top = per_sample_gop * 1e9 * (xb.shape[0] * (2 if guide != 1.0 else 1)) / (ms_per_step * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
                            "frac": round(ach / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,

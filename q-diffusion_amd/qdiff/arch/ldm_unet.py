@@ -551,6 +551,12 @@ def sd_v1_config():
                 transformer_depth=1, context_dim=768, use_checkpoint=True, legacy=False)
 
 
+def lsun_churches_config():
+    """models/ldm/lsun_churches256/config.yaml:32-53 (unet_config.params): LDM-8 on 4 x 32 x 32 latents."""
+    return dict(image_size=32, in_channels=4, out_channels=4, model_channels=192, attention_resolutions=[1, 2, 4, 8],
+                num_res_blocks=2, channel_mult=[1, 2, 2, 4, 4], num_heads=8, use_scale_shift_norm=True, resblock_updown=True)
+
+
 def lsun_beds_config():
     """models/ldm/lsun_beds256/config.yaml:17-34 (unet_config.params)."""
     return dict(image_size=64, in_channels=3, out_channels=3, model_channels=224, attention_resolutions=[8, 4, 2],

@@ -58,12 +58,14 @@ def load_synthetic_weights(model, seed=0):
 
 
 def synthetic_inputs(kind, batch, seed=0):
-    """(x, t, context) for 'cifar' | 'ldm' | 'sd' at the BASELINE shapes."""
+    """(x, t, context) for 'cifar' | 'ldm' | 'sd' at the BASELINE shapes ('churches': LSUN-Churches LDM-8 latents)."""
     g = torch.Generator().manual_seed(1000 + seed)
     if kind == "cifar":
         return torch.randn(batch, 3, 32, 32, generator=g), torch.randint(0, 1000, (batch,), generator=g).float(), None
     if kind == "ldm":
         return torch.randn(batch, 3, 64, 64, generator=g), torch.randint(0, 1000, (batch,), generator=g), None
+    if kind == "churches":
+        return torch.randn(batch, 4, 32, 32, generator=g), torch.randint(0, 1000, (batch,), generator=g), None
     if kind == "sd":
         return (torch.randn(batch, 4, 64, 64, generator=g), torch.randint(0, 1000, (batch,), generator=g),
                 torch.randn(batch, 77, 768, generator=g))

@@ -75,9 +75,9 @@ def _metrics(y, ref):
     return d, cos, ref.abs().max().item()
 
 
-# ldm_updown_tiny: resblock_updown + use_scale_shift_norm (the LSUN-Churches LDM-8 block variants); collected late: added
-# after the round's last GPU run
-LATE = [pytest.param("ldm_updown_tiny", marks=pytest.mark.late)]
+# ldm_updown_tiny / churches_full: resblock_updown + use_scale_shift_norm (LSUN-Churches LDM-8, models/ldm/lsun_churches256);
+# collected late: added after the round's last GPU run
+LATE = [pytest.param("ldm_updown_tiny", marks=pytest.mark.late), pytest.param("churches_full", marks=pytest.mark.late)]
 
 
 @pytest.mark.parametrize("name", TINY + FULL + LATE)

@@ -347,6 +347,31 @@ def test_blocks_teacher_forced_on_emulator(emu, name):
     assert not failures, "\n".join(failures)
 
 
+def test_churches_unet_on_emulator(emu):
+    """LSUN-Churches LDM-8 at its real shapes (models/ldm/lsun_churches256/config.yaml: 4 x 32 x 32 latents, 35 residual
+    blocks that all modulate their second norm, 4 + 4 of them resampling, 21 eight-head attention blocks with head dims
+    24 / 48 / 96 on 1024 .. 4 tokens) through the host logic and the ABI emulator: the whole evaluation inside the reference's
+    own fp32-vs-fp64 envelope, and every block teacher-forced with the oracle's inputs within the per-kind bounds."""
+    import qdiff
+    from block_parity_util import run_block_parity
+    fx = load_fixture("model_churches_full.pt")
+    qnn = _resume_cpu(fx)
+    mods = [m for m in qnn.modules() if isinstance(m, qdiff.QuantModule)]
+    assert len(mods) == fx["n_quant_modules"] and all(m.int_ready() for m in mods)
+    x, t, _ = fixture_inputs(fx, "test")
+    with torch.no_grad():
+        y = qnn(x, t)
+    assert all(m._plan is not None for m in mods)
+    ref = fx["out_wa"]
+    d = (y - ref).abs().max().item() / ref.abs().max().item()
+    cos = torch.nn.functional.cosine_similarity(y.flatten(), ref.flatten(), dim=0).item()
+    assert d <= 0.1 and cos >= 0.998, (d, cos)
+    lines, failures = run_block_parity(qnn, fx, torch.device("cpu"))
+    print("\n" + "\n".join(lines))
+    assert lines[0].endswith("0.00e+00 of range"), "oracle trace run is not the reference run"
+    assert not failures, "\n".join(failures)
+
+
 @pytest.mark.parametrize("name", ["sd_tiny", "cifar_tiny"])
 def test_running_stat_updates_match_the_simulation_path(emu, name):
     """QuantModel.set_running_stat(True) (the reference's calibration loop, txt2img.py:457-468) in (True, True) state:

@@ -82,6 +82,12 @@ MODELS = {
     "ldm_full": dict(family="ldm", w_bits=4, a_bits=8, a_sym=True, sm_abit=8, split=True, x=(3, 64, 64), ctx=None,
                      unet=dict(image_size=64, in_channels=3, out_channels=3, model_channels=224, attention_resolutions=[8, 4, 2],
                                num_res_blocks=2, channel_mult=[1, 2, 3, 4], num_head_channels=32)),
+    # LSUN-Churches LDM-8 (models/ldm/lsun_churches256/config.yaml:32-53; README.md:53-55,77): 4 x 32 x 32 latents,
+    # resampling ResBlocks with scale-shift norms, 8-head legacy attention at 32^2 .. 4^2 tokens (head dims 24 / 48 / 96)
+    "churches_full": dict(family="ldm", w_bits=4, a_bits=8, a_sym=True, sm_abit=8, split=False, x=(4, 32, 32), ctx=None,
+                          unet=dict(image_size=32, in_channels=4, out_channels=4, model_channels=192,
+                                    attention_resolutions=[1, 2, 4, 8], num_res_blocks=2, channel_mult=[1, 2, 2, 4, 4],
+                                    num_heads=8, use_scale_shift_norm=True, resblock_updown=True)),
     "sd_full": dict(family="ldm", w_bits=4, a_bits=8, a_sym=False, sm_abit=16, split=True, x=(4, 64, 64), ctx=(77, 768),
                     unet=dict(image_size=32, in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1],
                               num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
