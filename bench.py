@@ -62,7 +62,7 @@ def build_quantised_unet(kind, device, seed=0):
         model = ldm_unet.UNetModel(**ldm_unet.lsun_churches_config())
         model.split = False
         wq = dict(n_bits=4, channel_wise=True, scale_method="max")
-        aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True, symmetric=True)
+        aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True)     # README.md:55: no --a_sym
         sm_abit = 8
     else:
         model = ddim_unet.Model(ddim_unet.cifar10_config(split_shortcut=True))
@@ -98,7 +98,9 @@ def build_skeleton(kind, device, seed=777):
         cfg = ldm_unet.lsun_beds_config() if kind == "ldm" else ldm_unet.lsun_churches_config()
         model, sm_abit = ldm_unet.UNetModel(**cfg), 8
         wq = dict(n_bits=4, channel_wise=True, scale_method="max")
-        aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True, symmetric=True)
+        aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True)
+        if kind == "ldm":
+            aq["symmetric"] = True
     else:
         model, sm_abit = ddim_unet.Model(ddim_unet.cifar10_config(split_shortcut=True)), 8
         wq = dict(n_bits=8, channel_wise=True, scale_method="max")

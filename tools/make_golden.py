@@ -84,7 +84,8 @@ MODELS = {
                                num_res_blocks=2, channel_mult=[1, 2, 3, 4], num_head_channels=32)),
     # LSUN-Churches LDM-8 (models/ldm/lsun_churches256/config.yaml:32-53; README.md:53-55,77): 4 x 32 x 32 latents,
     # resampling ResBlocks with scale-shift norms, 8-head legacy attention at 32^2 .. 4^2 tokens (head dims 24 / 48 / 96)
-    "churches_full": dict(family="ldm", w_bits=4, a_bits=8, a_sym=True, sm_abit=8, split=False, x=(4, 32, 32), ctx=None,
+    # activations asymmetric: README.md:55,77 pass --quant_act --act_bit 8 without --a_sym for this model
+    "churches_full": dict(family="ldm", w_bits=4, a_bits=8, a_sym=False, sm_abit=8, split=False, x=(4, 32, 32), ctx=None,
                           unet=dict(image_size=32, in_channels=4, out_channels=4, model_channels=192,
                                     attention_resolutions=[1, 2, 4, 8], num_res_blocks=2, channel_mult=[1, 2, 2, 4, 4],
                                     num_heads=8, use_scale_shift_norm=True, resblock_updown=True)),
