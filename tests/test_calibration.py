@@ -27,7 +27,7 @@ def _summary(t):
     return dict(numel=f.numel(), n_up=int((f >= 0).sum()), sum=float(f.sum()), l2=float(f.norm()), sample=f[::step][:64].float())
 
 
-@pytest.mark.parametrize("name", ["cifar_tiny", "sd_tiny", "ldm_tiny"])
+@pytest.mark.parametrize("name", ["cifar_tiny", "sd_tiny", "ldm_tiny", "ldm_updown_tiny"])
 def test_calibration_matches_the_reference(name):
     import qdiff
     from qdiff.adaptive_rounding import AdaRoundQuantizer
