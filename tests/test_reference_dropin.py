@@ -69,7 +69,7 @@ def _wrap_and_resume(fx):
     return qnn
 
 
-@pytest.mark.parametrize("name", ["sd_tiny", "ldm_tiny", "cifar_tiny"])
+@pytest.mark.parametrize("name", ["sd_tiny", "ldm_tiny", "cifar_tiny", "ldm_updown_tiny"])
 def test_reference_classes_wrapped_by_this_qdiff(monkeypatch, name):
     import qdiff
     from qdiff import hip, quant_block
@@ -148,7 +148,7 @@ def test_groupnorm_statistics_survive_the_reference_cat(monkeypatch):
     assert cat_inputs and any(part for _, part in cat_inputs), cat_inputs
 
 
-@pytest.mark.parametrize("name", ["sd_tiny", "ldm_tiny", "cifar_tiny"])
+@pytest.mark.parametrize("name", ["sd_tiny", "ldm_tiny", "cifar_tiny", "ldm_updown_tiny"])
 def test_reference_unet_takes_the_planned_concatenation_walk(monkeypatch, name):
     """On the REFERENCE's UNetModel the integer state runs this repo's walk (QuantModel._adopt_reference_walk): from the
     second evaluation on every skip concatenation is a view (no `cat` copy of activations), and the output equals the one
