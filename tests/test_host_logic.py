@@ -300,7 +300,7 @@ def test_standalone_qk_smv_matmuls_on_emulator(emu):
     assert (a - c["out"]).abs().max() <= 2e-5 * c["out"].abs().max()
 
 
-@pytest.mark.parametrize("name", ["cifar_tiny", "ldm_tiny", "sd_tiny"])
+@pytest.mark.parametrize("name", ["cifar_tiny", "ldm_tiny", "sd_tiny", "ldm_updown_tiny"])
 def test_packed_checkpoint_round_trip(emu, name, tmp_path):
     """export_packed_ckpt -> load_packed_ckpt into a model with DIFFERENT fp32 weights reproduces the original
     integer-path output bit for bit, the fp32 weights of the quantised layers are released, and the file is several
@@ -420,7 +420,7 @@ def test_running_stat_updates_match_the_simulation_path(emu, name):
     assert moved > 20
 
 
-@pytest.mark.parametrize("name", ["cifar_tiny", "ldm_tiny", "sd_tiny"])
+@pytest.mark.parametrize("name", ["cifar_tiny", "ldm_tiny", "sd_tiny", "ldm_updown_tiny"])
 def test_planned_concatenation_is_a_view_and_changes_nothing(emu, name, monkeypatch):
     """Skip concatenations (openaimodel.py:776, ddim diffusion.py:340) planned through engine.CatSlot + the skip
     connection's int8 rows taken from the GroupNorm pass (qd_raw_quant): from the second evaluation on no `cat` copy runs
