@@ -346,7 +346,7 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int8xint4->int32 (fp32 residual stream)", "data": "synthetic",
         "config": {"workload": f"{kind} UNet eval batch {2 * n if guide != 1.0 else n} per GPU, {evals} evals per image batch, "
-                               f"W{qspec['w_bits']}A8 sm_abit={qspec['sm_abit']} split, hip-graph={'off' if a.no_graph else 'on'}",
+                               f"W{qspec['w_bits']}A8 sm_abit={qspec['sm_abit']}{'' if kind == 'churches' else ' split'}, hip-graph={'off' if a.no_graph else 'on'}",
                    "images_per_gpu": n, "global_batch": gb, "single_unet_step_ms": round(ms_per_step, 4),
                    "parallelism": f"batch-sharded x{world}, quant-state broadcast {nbytes} B"},
     }
