@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# Some tests import the reference's `ldm` / `ddim` packages from /root/reference, which is read-only for this project:
+# no byte-code caches next to its sources — in this process and in every process it spawns (gloo workers, script runs).
+sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "q-diffusion_amd")):
     if p not in sys.path:

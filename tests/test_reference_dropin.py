@@ -20,6 +20,7 @@ import abi_emulator
 from golden_util import build_ckpt, fixture_inputs, load_fixture, quant_params
 
 REF = "/root/reference"
+sys.dont_write_bytecode = True          # the reference tree is read-only for this project: no __pycache__ next to its sources
 if not os.path.isdir(os.path.join(REF, "ldm")):
     pytest.skip("reference tree not present (GPU box)", allow_module_level=True)
 

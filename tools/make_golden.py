@@ -27,6 +27,7 @@ import torch.nn as nn
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 OUT = os.path.join(ROOT, "tests", "golden")
+sys.dont_write_bytecode = True          # /root/reference is read-only for this project: no __pycache__ next to its sources
 sys.path.insert(0, REF)
 
 # --- shims (test side only; reference files untouched) -------------------------------------------
