@@ -111,6 +111,18 @@ def _int_mode(*modules):
             and not any(_tracking(m) for m in modules))
 
 
+def _dropout_live(block):
+    """The block is in train mode and holds a Dropout with p > 0: the reference then drops activations (its calibration
+    helpers leave the model in train mode, utils.py:249, so the scripts initialise activation ranges under dropout), which
+    only the simulation composition reproduces — the integer path is the eval-mode path."""
+    if not block.training:
+        return False
+    live = block.__dict__.get("_qd_has_dropout")
+    if live is None:
+        live = block.__dict__["_qd_has_dropout"] = any(isinstance(m, nn.Dropout) and m.p > 0 for m in block.modules())
+    return live
+
+
 def _aq_ready(*quantizers):
     """Initialised and not in EMA range-tracking mode (a tracking quantiser must see its float input: simulation path)."""
     return all(q.inited and not q.running_stat for q in quantizers)
@@ -401,7 +413,7 @@ class QuantResBlock(BaseQuantBlock, ldm_unet.TimestepBlock):
         assert x.shape[2] == x.shape[3]
         H_ = x.shape[2]
         conv1, conv2 = self.in_layers[-1], self.out_layers[-1]
-        if (_int_mode(conv1, conv2, self.emb_layers[-1]) and conv1.split == 0 and conv2.split == 0
+        if (_int_mode(conv1, conv2, self.emb_layers[-1]) and conv1.split == 0 and conv2.split == 0 and not _dropout_live(self)
                 and (not self.updown or (H_ % 2 == 0 and not getattr(self.h_upd, "use_conv", False)))):
             return self._forward_int(x, emb, split, conv1, conv2, out_slot)
         return self._forward_sim(x, emb, split)
@@ -416,11 +428,13 @@ class QuantResBlock(BaseQuantBlock, ldm_unet.TimestepBlock):
         e = self.emb_layers(emb).type(h.dtype)
         while e.dim() < h.dim():
             e = e[..., None]
+        live = _dropout_live(self)      # the dropout mask follows MEMORY order: NCHW, as the reference's tensors are laid out
         if self.use_scale_shift_norm:
             scale, shift = th.chunk(e, 2, dim=1)
-            h = self.out_layers[1:](self.out_layers[0](h) * (1 + scale) + shift)
+            h = self.out_layers[0](h) * (1 + scale) + shift
+            h = self.out_layers[1:](h.contiguous() if live else h)
         else:
-            h = self.out_layers(h + e)
+            h = self.out_layers((h + e).contiguous() if live else h + e)
         if split != 0:
             return self.skip_connection(x, split=split) + h
         return self.skip_connection(x) + h
@@ -693,7 +707,7 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
         a1, a2 = self.attn1, self.attn2
         mods = [a1.to_q, a1.to_k, a1.to_v, a1.to_out[0], a2.to_q, a2.to_k, a2.to_v, a2.to_out[0], self.ff.net[-1]]
         glu = isinstance(self.ff.net[0], ldm_unet.GEGLU) or type(self.ff.net[0]).__name__ == "GEGLU"
-        if (glu and a1.use_act_quant and a2.use_act_quant and _int_mode(*mods, self.ff.net[0].proj)
+        if (glu and a1.use_act_quant and a2.use_act_quant and not _dropout_live(self) and _int_mode(*mods, self.ff.net[0].proj)
                 and self._attn_inited(a1) and self._attn_inited(a2)):
             return self._forward_int(x, context, out_plan)
         x = self.attn1(self.norm1(x)) + x
@@ -798,11 +812,14 @@ class QuantResnetBlock(BaseQuantBlock):
     def forward(self, x, temb=None, split=0, out_slot=None):
         if temb is None:
             x, temb = x
-        if _int_mode(self.conv1, self.conv2, self.temb_proj):
+        if _int_mode(self.conv1, self.conv2, self.temb_proj) and not _dropout_live(self):
             return self._forward_int(x, temb, split, out_slot)
         h = self.conv1(ddim_unet.nonlinearity(self.norm1(x)))
         h = h + self.temb_proj(ddim_unet.nonlinearity(temb))[:, :, None, None]
-        h = self.conv2(self.dropout(ddim_unet.nonlinearity(self.norm2(h))))
+        h = ddim_unet.nonlinearity(self.norm2(h))
+        if _dropout_live(self):
+            h = h.contiguous()          # the dropout mask follows MEMORY order: NCHW, as the reference's tensors are laid out
+        h = self.conv2(self.dropout(h))
         if self.in_channels != self.out_channels:
             x = self.conv_shortcut(x) if self.use_conv_shortcut else self.nin_shortcut(x, split=split)
         return x + h

@@ -492,6 +492,8 @@ def test_cat_channels_only_takes_the_view_when_it_is_one():
     other = engine.CatSlot(C1, C2)
     ob = qb._rows_to_nchw(other.rows(1, B * H * W, C2, dev), B, H, W)
     other.rows(0, B * H * W, C1, dev)
+    other.buf.fill_(3.0)                   # slot buffers are torch.empty: garbage (possibly NaN) would defeat torch.equal below
+    wide.buf.fill_(5.0)
     assert qb._adjacent(a, ob, 1, 1) is None
     assert qb._adjacent(a, b.clone(), 1, 1) is None
     assert qb._adjacent(a[:1], b, 1, 1) is None and qb._adjacent(a, b.double(), 1, 1) is None
