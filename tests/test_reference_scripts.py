@@ -28,20 +28,30 @@ if not os.path.isfile(os.path.join(REF, "scripts", "sample_diffusion_ddim.py")):
     pytest.skip("reference tree not present (GPU box)", allow_module_level=True)
 
 
-def _run(qdiff_root, fp_ckpt, out, logdir, extra, emulator=False):
+def _run(qdiff_root, fp_ckpt, out, logdir, extra, emulator=False, job=False):
     cmd = [sys.executable, os.path.join(ROOT, "tests", "run_reference_script.py"), qdiff_root, "ddim", fp_ckpt, out]
     cmd += ["--emulator"] if emulator else []
     cmd += ["--", "--config", os.path.join(os.path.dirname(fp_ckpt), "cifar10_batch2.yml"), "--timesteps", "4", "--eta", "0", "--skip_type", "quad", "--max_images", "2",
             "--ptq", "--quant_mode", "qdiff", "--split", "--resume", "-l", logdir, "--seed", "1234"] + extra
-    return _launch(cmd, out)
+    return (cmd, out) if job else _launch(cmd, out)
 
 
 def _launch(cmd, out):
-    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="8")
+    return _launch_all([(cmd, out)])[0]
+
+
+def _launch_all(jobs):
+    """Start every (cmd, out) at once — the reference-side and this-package-side runs of a comparison are independent
+    processes — and collect their stored results."""
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS=str(max(2, (os.cpu_count() or 8) // len(jobs))))
     env.pop("PYTHONPATH", None)
-    r = subprocess.run(cmd, cwd=REF, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    return torch.load(out, weights_only=False)
+    procs = [subprocess.Popen(cmd, cwd=REF, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for cmd, _ in jobs]
+    res = []
+    for p, (cmd, out) in zip(procs, jobs):
+        so, se = p.communicate(timeout=900)
+        assert p.returncode == 0, so[-2000:] + se[-4000:]
+        res.append(torch.load(out, weights_only=False))
+    return res
 
 
 @pytest.fixture(scope="module")
@@ -68,8 +78,8 @@ def ckpts(tmp_path_factory):
 def test_ddim_script_weights_only_is_bit_identical(ckpts):
     d, fp_path, cali_path = ckpts
     args = ["--weight_bit", "8", "--cali_ckpt", cali_path]
-    ref = _run(REF, fp_path, str(d / "ref_w.pt"), str(d / "log_ref_w"), args)
-    ours = _run(os.path.join(ROOT, "q-diffusion_amd"), fp_path, str(d / "our_w.pt"), str(d / "log_our_w"), args)
+    ref, ours = _launch_all([_run(REF, fp_path, str(d / "ref_w.pt"), str(d / "log_ref_w"), args, job=True),
+                             _run(os.path.join(ROOT, "q-diffusion_amd"), fp_path, str(d / "our_w.pt"), str(d / "log_our_w"), args, job=True)])
     assert "/root/reference/qdiff" in ref["qdiff"] and "q-diffusion_amd/qdiff" in ours["qdiff"]
     assert ref["names"] == ours["names"] == ["0.png", "1.png"]
     assert torch.isfinite(ref["images"]).all() and ref["images"].std() > 0
@@ -79,8 +89,8 @@ def test_ddim_script_weights_only_is_bit_identical(ckpts):
 def test_ddim_script_w8a8_runs_on_the_integer_engine(ckpts):
     d, fp_path, cali_path = ckpts
     args = ["--weight_bit", "8", "--quant_act", "--act_bit", "8", "--a_sym", "--cali_ckpt", cali_path]
-    ref = _run(REF, fp_path, str(d / "ref_wa.pt"), str(d / "log_ref_wa"), args)
-    ours = _run(os.path.join(ROOT, "q-diffusion_amd"), fp_path, str(d / "our_wa.pt"), str(d / "log_our_wa"), args, emulator=True)
+    ref, ours = _launch_all([_run(REF, fp_path, str(d / "ref_wa.pt"), str(d / "log_ref_wa"), args, job=True),
+                             _run(os.path.join(ROOT, "q-diffusion_amd"), fp_path, str(d / "our_wa.pt"), str(d / "log_our_wa"), args, emulator=True, job=True)])
     a, b = ref["images"].double(), ours["images"].double()
     assert a.shape == b.shape and torch.isfinite(b).all()
     cos = torch.nn.functional.cosine_similarity((a - a.mean()).flatten(), (b - b.mean()).flatten(), dim=0).item()
@@ -130,21 +140,21 @@ def ldm_run_dir(tmp_path_factory):
     return d
 
 
-def _run_ldm(qdiff_root, d, tag, extra, emulator=False):
+def _run_ldm(qdiff_root, d, tag, extra, emulator=False, job=False):
     out = str(d / f"{tag}.pt")
     cmd = [sys.executable, os.path.join(ROOT, "tests", "run_reference_script.py"), qdiff_root, "ldm", "-", out]
     cmd += ["--emulator"] if emulator else []
     cmd += ["--", "-r", str(d / "model.ckpt"), "-n", "2", "--batch_size", "2", "-c", "4", "-e", "1.0", "--seed", "41",
             "--ptq", "--resume", "-l", str(d / f"log_{tag}"), "--cali_ckpt", str(d / "cali.pth")] + extra
-    return _launch(cmd, out)
+    return (cmd, out) if job else _launch(cmd, out)
 
 
 def test_ldm_script_weights_only_is_bit_identical(ldm_run_dir):
     """README.md:47,53 (`--ptq --weight_bit 4 --resume`): LatentDiffusion + DDIMSampler + first-stage decode of the script,
     the UNet wrapped by either `qdiff`: the uint8 images of the script's own .npz are identical."""
     d = ldm_run_dir
-    ref = _run_ldm(REF, d, "ref_w", ["--weight_bit", "4"])
-    ours = _run_ldm(os.path.join(ROOT, "q-diffusion_amd"), d, "our_w", ["--weight_bit", "4"])
+    ref, ours = _launch_all([_run_ldm(REF, d, "ref_w", ["--weight_bit", "4"], job=True),
+                             _run_ldm(os.path.join(ROOT, "q-diffusion_amd"), d, "our_w", ["--weight_bit", "4"], job=True)])
     assert "/root/reference/qdiff" in ref["qdiff"] and "q-diffusion_amd/qdiff" in ours["qdiff"]
     assert len(ref["names"]) == len(ours["names"]) == 2 and ref["images"].shape == (2, 64, 64, 3)
     assert ref["images"].float().std() > 0
@@ -157,8 +167,8 @@ def test_ldm_script_w4a8_runs_on_the_integer_engine(ldm_run_dir):
     the comparison is about the picture (see test_ddim_script_w8a8_runs_on_the_integer_engine)."""
     d = ldm_run_dir
     args = ["--weight_bit", "4", "--quant_act", "--act_bit", "8", "--a_sym"]
-    ref = _run_ldm(REF, d, "ref_wa", args)
-    ours = _run_ldm(os.path.join(ROOT, "q-diffusion_amd"), d, "our_wa", args, emulator=True)
+    ref, ours = _launch_all([_run_ldm(REF, d, "ref_wa", args, job=True),
+                             _run_ldm(os.path.join(ROOT, "q-diffusion_amd"), d, "our_wa", args, emulator=True, job=True)])
     a, b = ref["images"].double() / 255, ours["images"].double() / 255
     assert a.shape == b.shape
     cos = torch.nn.functional.cosine_similarity((a - a.mean()).flatten(), (b - b.mean()).flatten(), dim=0).item()
@@ -214,22 +224,22 @@ def sd_run_dir(tmp_path_factory):
     return d
 
 
-def _run_txt2img(qdiff_root, d, tag, extra, emulator=False):
+def _run_txt2img(qdiff_root, d, tag, extra, emulator=False, job=False):
     out = str(d / f"{tag}.pt")
     cmd = [sys.executable, os.path.join(ROOT, "tests", "run_reference_script.py"), qdiff_root, "txt2img", "-", out]
     cmd += ["--emulator"] if emulator else []
     cmd += ["--", "--prompt", "a puppy wearing a hat", "--plms", "--cond", "--ptq", "--quant_mode", "qdiff", "--no_grad_ckpt", "--split",
             "--n_samples", "1", "--n_iter", "1", "--ddim_steps", "4", "--resume", "--skip_grid", "--outdir", str(d / f"out_{tag}"),
             "--config", str(d / "v1-inference-small.yaml"), "--ckpt", str(d / "model.ckpt"), "--cali_ckpt", str(d / "cali.pth")] + extra
-    return _launch(cmd, out)
+    return (cmd, out) if job else _launch(cmd, out)
 
 
 def test_txt2img_script_weights_only_is_bit_identical(sd_run_dir):
     """README.md:59 (`--plms --cond --ptq --weight_bit 4 --quant_mode qdiff --no_grad_ckpt --split --resume`): PLMSSampler
     with classifier-free guidance, the split shortcut, the first-stage decode — the PNG the script writes is identical."""
     d = sd_run_dir
-    ref = _run_txt2img(REF, d, "ref_w", ["--weight_bit", "4"])
-    ours = _run_txt2img(os.path.join(ROOT, "q-diffusion_amd"), d, "our_w", ["--weight_bit", "4"])
+    ref, ours = _launch_all([_run_txt2img(REF, d, "ref_w", ["--weight_bit", "4"], job=True),
+                             _run_txt2img(os.path.join(ROOT, "q-diffusion_amd"), d, "our_w", ["--weight_bit", "4"], job=True)])
     assert "/root/reference/qdiff" in ref["qdiff"] and "q-diffusion_amd/qdiff" in ours["qdiff"]
     assert ref["names"] == ours["names"] == ["00000.png"] and ref["images"].shape == (1, 512, 512, 3)
     assert ref["images"].float().std() > 0
@@ -240,8 +250,8 @@ def test_txt2img_script_w4a8_runs_on_the_integer_engine(sd_run_dir):
     """README.md:61 (`--quant_act --act_bit 8 --sm_abit 16`): this package's side on the integer engine (C-ABI emulator)."""
     d = sd_run_dir
     args = ["--weight_bit", "4", "--quant_act", "--act_bit", "8", "--sm_abit", "16"]
-    ref = _run_txt2img(REF, d, "ref_wa", args)
-    ours = _run_txt2img(os.path.join(ROOT, "q-diffusion_amd"), d, "our_wa", args, emulator=True)
+    ref, ours = _launch_all([_run_txt2img(REF, d, "ref_wa", args, job=True),
+                             _run_txt2img(os.path.join(ROOT, "q-diffusion_amd"), d, "our_wa", args, emulator=True, job=True)])
     a, b = ref["images"].double() / 255, ours["images"].double() / 255
     assert a.shape == b.shape
     cos = torch.nn.functional.cosine_similarity((a - a.mean()).flatten(), (b - b.mean()).flatten(), dim=0).item()
@@ -288,13 +298,15 @@ def test_ddim_script_calibrates_with_this_packages_reconstruction(tmp_path):
         cmd += ["--emulator"] if emulator else []
         cmd += ["--", "--config", str(d / "cifar10_batch2.yml"), "--timesteps", "4", "--eta", "0", "--skip_type", "quad", "--max_images", "2",
                 "--ptq", "--quant_mode", "qdiff", "--split", "-l", str(d / f"log_{tag}"), "--seed", "1234"] + args
-        res = _launch(cmd, str(d / f"{tag}.pt"))
+        return cmd, str(d / f"{tag}.pt")
+
+    def ckpt_of(tag):
         ck = glob.glob(str(d / f"log_{tag}" / "samples" / "*" / "ckpt.pth"))
         assert len(ck) == 1
-        return res, ck[0]
+        return ck[0]
 
-    ref, ck_ref = run(REF, "ref", False)
-    ours, ck_ours = run(os.path.join(ROOT, "q-diffusion_amd"), "ours", True)
+    ref, ours = _launch_all([run(REF, "ref", False), run(os.path.join(ROOT, "q-diffusion_amd"), "ours", True)])
+    ck_ref, ck_ours = ckpt_of("ref"), ckpt_of("ours")
     a, b = torch.load(ck_ref, map_location="cpu"), torch.load(ck_ours, map_location="cpu")
     assert {k: tuple(v.shape) for k, v in a.items()} == {k: tuple(v.shape) for k, v in b.items()}
     n_alpha = n_delta = 0
@@ -317,3 +329,58 @@ def test_ddim_script_calibrates_with_this_packages_reconstruction(tmp_path):
            "--ptq", "--quant_mode", "qdiff", "--split", "-l", str(d / "log_ref_resumed"), "--seed", "1234", "--weight_bit", "8",
            "--quant_act", "--act_bit", "8", "--a_sym", "--resume", "--cali_ckpt", ck_ours]
     _launch(cmd, str(d / "ref_resumed.pt"))
+
+
+def test_txt2img_script_calibrates_with_this_packages_reconstruction(sd_run_dir, tmp_path):
+    """README.md:80 without --resume: the script's own calibration of the conditional model — `get_train_samples` with
+    conditional + unconditional contexts, channel-wise 'mse' weight ranges, its inline `recon_model` walk (temporary
+    checkpoints on the way: `torch.save(qnn.state_dict())` mid-calibration), EMA range tracking (`--running_stat`,
+    `set_running_stat(True, rs_sm_only)`), the activation phase, the final checkpoint, then PLMS sampling with guidance
+    (txt2img.py:395-490) — on each `qdiff`, 3 + 3 iterations per unit on 16 x 16 latents.  Same checkpoint keys and shapes;
+    AdaRound alphas and activation step sizes within the reach of their own Adam steps."""
+    import glob
+    d = sd_run_dir
+    g = torch.Generator().manual_seed(21)
+    n, steps = 8, 4
+    data = {"xs": [torch.randn(n, 4, 16, 16, generator=g) for _ in range(steps)],
+            "ts": [torch.full((n,), t, dtype=torch.long) for t in (951, 701, 451, 201)],
+            "cs": [torch.randn(n, 77, 768, generator=g) for _ in range(steps)],
+            "ucs": [torch.randn(1, 77, 768, generator=g).expand(n, 77, 768).clone() for _ in range(steps)]}
+    torch.save(data, tmp_path / "cali_data.pt")
+
+    def run(root, tag, emulator):
+        out = str(tmp_path / f"{tag}.pt")
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "run_reference_script.py"), root, "txt2img", "-", out]
+        cmd += ["--emulator"] if emulator else []
+        cmd += ["--", "--prompt", "a photograph of an astronaut riding a horse", "--plms", "--cond", "--ptq", "--weight_bit", "4",
+                "--quant_mode", "qdiff", "--quant_act", "--act_bit", "8", "--cali_st", "2", "--cali_batch_size", "8", "--cali_n", str(n),
+                "--cali_iters", "3", "--cali_iters_a", "3", "--no_grad_ckpt", "--split", "--running_stat", "--sm_abit", "16",
+                "--cali_data_path", str(tmp_path / "cali_data.pt"), "--outdir", str(tmp_path / f"out_{tag}"), "--ddim_steps", str(steps),
+                "--n_samples", "1", "--n_iter", "1", "--H", "128", "--W", "128", "--skip_grid",
+                "--config", str(d / "v1-inference-small.yaml"), "--ckpt", str(d / "model.ckpt")]
+        return cmd, out
+
+    def ckpt_of(tag):
+        ck = glob.glob(str(tmp_path / f"out_{tag}" / "*" / "ckpt.pth"))
+        assert len(ck) == 1
+        return torch.load(ck[0], map_location="cpu")
+
+    ref, ours = _launch_all([run(REF, "ref", False), run(os.path.join(ROOT, "q-diffusion_amd"), "ours", True)])
+    a, b = ckpt_of("ref"), ckpt_of("ours")
+    assert {k: tuple(v.shape) for k, v in a.items()} == {k: tuple(v.shape) for k, v in b.items()}
+    n_alpha = n_delta = 0
+    for k, va in a.items():
+        vb, leaf = b[k], k.rsplit(".", 1)[-1]
+        if leaf == "alpha":
+            assert (va - vb).abs().max().item() <= 2 * 1e-3 * 3 + 1e-5, k
+            assert ((va >= 0) != (vb >= 0)).float().mean().item() <= 1e-3, k
+            n_alpha += 1
+        elif leaf == "delta" and "act_quantizer" in k:
+            assert torch.allclose(va, vb, rtol=1e-2, atol=2 * 4e-4 * 3), (k, va, vb)
+            n_delta += 1
+        elif leaf == "delta":                             # channel-wise 'mse' weight ranges: the same search, the same winner
+            assert torch.equal(va, vb), k
+        elif leaf != "zero_point":
+            assert torch.equal(va, vb), k
+    assert n_alpha > 20 and n_delta > 40
+    assert ref["images"].shape == ours["images"].shape == (1, 128, 128, 3)
