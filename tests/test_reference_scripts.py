@@ -384,3 +384,58 @@ def test_txt2img_script_calibrates_with_this_packages_reconstruction(sd_run_dir,
             assert torch.equal(va, vb), k
     assert n_alpha > 20 and n_delta > 40
     assert ref["images"].shape == ours["images"].shape == (1, 128, 128, 3)
+
+
+def test_ldm_script_two_stage_calibration(ldm_run_dir, tmp_path):
+    """The LDM flow of the reference: weights are calibrated in a weights-only run (README.md:74 without --quant_act; with
+    quantised activations the weight phase of the reference stops at the weight-free attention-matmul blocks), then a
+    second run resumes them (`--resume_w --cali_ckpt`) and calibrates the activation step sizes (`--quant_act --a_sym
+    --a_min_max --running_stat`, sample_diffusion_ldm.py:480-566).  Both runs on both packages, each resuming its own
+    first-stage checkpoint; checkpoints compared as in the other calibration tests.  UNet with resampling ResBlocks,
+    scale-shift norms and legacy attention blocks (QuantQKMatMul / QuantSMVMatMul units in the second stage)."""
+    import glob
+    d = ldm_run_dir
+    g = torch.Generator().manual_seed(31)
+    n, steps = 16, 4
+    torch.save({"xs": [torch.randn(n, 3, 16, 16, generator=g) for _ in range(steps)],
+                "ts": [torch.full((n,), t, dtype=torch.long) for t in (751, 501, 251, 1)]}, tmp_path / "cali_data.pt")
+    ours_root = os.path.join(ROOT, "q-diffusion_amd")
+
+    def job(root, tag, extra, emulator):
+        out = str(tmp_path / f"{tag}.pt")
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "run_reference_script.py"), root, "ldm", "-", out]
+        cmd += ["--emulator"] if emulator else []
+        cmd += ["--", "-r", str(d / "model.ckpt"), "-n", "2", "--batch_size", "2", "-c", str(steps), "-e", "1.0", "--seed", "40", "--ptq",
+                "--weight_bit", "4", "--quant_mode", "qdiff", "--cali_st", "2", "--cali_batch_size", "8", "--cali_n", str(n),
+                "--cali_data_path", str(tmp_path / "cali_data.pt"), "-l", str(tmp_path / f"log_{tag}")] + extra
+        return cmd, out
+
+    def ckpt_of(tag):
+        ck = glob.glob(str(tmp_path / f"log_{tag}" / "**" / "ckpt.pth"), recursive=True)
+        assert len(ck) == 1, ck
+        return ck[0]
+
+    _launch_all([job(REF, "ref1", ["--cali_iters", "3"], False), job(ours_root, "our1", ["--cali_iters", "3"], False)])
+    a, b = torch.load(ckpt_of("ref1"), map_location="cpu"), torch.load(ckpt_of("our1"), map_location="cpu")
+    assert {k: tuple(v.shape) for k, v in a.items()} == {k: tuple(v.shape) for k, v in b.items()}
+    n_alpha = 0
+    for k, va in a.items():
+        if k.endswith(".alpha"):
+            assert (va - b[k]).abs().max().item() <= 2 * 1e-3 * 3 + 1e-5, k
+            assert ((va >= 0) != (b[k] >= 0)).float().mean().item() <= 1e-3, k
+            n_alpha += 1
+        else:
+            assert torch.equal(va, b[k]), k                 # fp weights, channel-wise 'mse' weight ranges
+    assert n_alpha > 20
+    stage2 = ["--quant_act", "--act_bit", "8", "--a_sym", "--a_min_max", "--running_stat", "--resume_w", "--cali_iters_a", "3"]
+    ref, ours = _launch_all([job(REF, "ref2", stage2 + ["--cali_ckpt", ckpt_of("ref1")], False),
+                             job(ours_root, "our2", stage2 + ["--cali_ckpt", ckpt_of("our1")], True)])
+    a, b = torch.load(ckpt_of("ref2"), map_location="cpu"), torch.load(ckpt_of("our2"), map_location="cpu")
+    assert {k: tuple(v.shape) for k, v in a.items()} == {k: tuple(v.shape) for k, v in b.items()}
+    n_delta = 0
+    for k, va in a.items():
+        if k.endswith(".delta") and "act_quantizer" in k:
+            assert torch.allclose(va, b[k], rtol=1e-2, atol=2 * 4e-4 * 3), (k, va, b[k])
+            n_delta += 1
+    assert n_delta > 40 and any("act_quantizer_w" in k for k in a)           # the matmul units were calibrated too
+    assert ref["images"].shape == ours["images"].shape == (2, 64, 64, 3)
