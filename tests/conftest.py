@@ -23,6 +23,11 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
     late = [it for it in items if it.get_closest_marker("late")]
     if late:
+        # among themselves: single kernels first, then the (independent) calibration job, then the whole models that need
+        # those kernels — `-x` stops at the first failure, and a failing kernel test says more than the model tests it
+        # would take down with it
+        rank = {"test_hip_kernels.py": 0, "test_calibration.py": 1, "test_engine_models.py": 2, "test_block_parity.py": 3}
+        late.sort(key=lambda it: rank.get(os.path.basename(str(it.fspath)), 4))
         items[:] = [it for it in items if not it.get_closest_marker("late")] + late
 
 
