@@ -83,6 +83,19 @@ def test_conv_desc_offsets_match_the_compiled_header(tmp_path):
         assert int(got[f"raw.{name}"]) == getattr(hip.RawQuant, name).offset, name
 
 
+def test_modulated_groupnorm_entry_validates_its_arguments_on_the_host():
+    """qd_groupnorm_mod_silu_quant (ABI v15): the argument checks that precede any device work are reachable without a GPU and
+    tell that `mod` / `mod_ld` arrive in the positions the ctypes binding puts them (fake non-null pointers are never
+    dereferenced on this path)."""
+    from qdiff import hip
+    lib = hip.load()
+    args = [1, 0, 1, 8, 16, 16, 4, 1e-5, None, None, 1, None, 0, 0, 0, None, 0, 8, 16, 16, None, 0, 0]
+    assert lib.qd_groupnorm_mod_silu_quant(*args, 24, 5, None) != 0
+    assert "mod_ld >= 2 C" in lib.qd_last_error().decode()
+    assert lib.qd_groupnorm_mod_silu_quant(*args, None, 64, None) != 0
+    assert "null modulation rows" in lib.qd_last_error().decode()
+
+
 def test_integer_path_refuses_to_run_on_the_host():
     """No silent fallback: with (True, True) quantisation and CPU tensors the engine raises."""
     import qdiff
