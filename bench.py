@@ -219,10 +219,10 @@ def first_stage_decode_ms(kind, n, dev, k=3):
     reported so that the end-to-end cost of an image is visible next to the 51 / 200 UNet evaluations it follows)."""
     from qdiff import synthetic
     from qdiff.arch import first_stage as fs
-    m, scale = fs.sd_v1_first_stage() if kind == "sd" else fs.lsun_beds_first_stage()
+    m, scale = {"sd": fs.sd_v1_first_stage, "ldm": fs.lsun_beds_first_stage, "churches": fs.lsun_churches_first_stage}[kind]()
     synthetic.load_synthetic_weights(m, seed=0)
     m = m.to(dev).eval()
-    z = torch.randn((n, 4, 64, 64) if kind == "sd" else (n, 3, 64, 64), device=dev)
+    z = torch.randn({"sd": (n, 4, 64, 64), "ldm": (n, 3, 64, 64), "churches": (n, 4, 32, 32)}[kind], device=dev)
     res = {}
     for name, dt in (("fp32", None), ("bf16_autocast", torch.bfloat16)):
         fs.decode_first_stage(m, z, scale, autocast_dtype=dt, to_uint8=True)
@@ -247,7 +247,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-denominators", action="store_true", help="skip the fp32 / fake-quant GPU denominators")
-    ap.add_argument("--decode", action="store_true", help="also time the first-stage decode of the image batch (sd / ldm; extra field)")
+    ap.add_argument("--decode", action="store_true", help="also time the first-stage decode of the image batch (sd / ldm / churches; extra field)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -400,7 +400,7 @@ def main():
             out["cpu_baseline"] = {"value": round(1.0 / per_image, 6), "unit": "images/s", "cores": torch.get_num_threads(),
                                    "kind": "port", "sample": f"UNet evaluations of one sample on the host cores: 1 warm-up + 2 timed, {dt:.1f} s "
                                                              f"each; extrapolated to {evals} evaluations x {2 if guide != 1.0 else 1} samples per image"}
-        if a.decode and kind in ("sd", "ldm"):
+        if a.decode and kind in ("sd", "ldm", "churches"):
             out["first_stage_decode"] = first_stage_decode_ms(kind, n, dev)
         print(json.dumps(out))
     if world > 1:

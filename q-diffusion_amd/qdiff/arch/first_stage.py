@@ -242,6 +242,14 @@ def sd_v1_first_stage():
     return AutoencoderKLDecoder(dd, embed_dim=4), 0.18215
 
 
+def lsun_churches_first_stage(scale_factor=1.0):
+    """models/ldm/lsun_churches256/config.yaml:32-53 (KL-f8, the same decoder shape as SD's).  `scale_by_std: true` (:17): the
+    checkpoint carries `scale_factor` as a buffer (ddpm.py:460-463) — pass its value."""
+    dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    return AutoencoderKLDecoder(dd, embed_dim=4), scale_factor
+
+
 def lsun_beds_first_stage():
     """models/ldm/lsun_beds256/config.yaml:35-55 (VQ-f4); scale_factor 1.0."""
     dd = dict(double_z=False, z_channels=3, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4],
