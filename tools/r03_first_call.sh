@@ -7,7 +7,7 @@ QDIFF_HALO=1 timeout 300 python -m pytest tests/test_hip_kernels.py -m gpu -q -k
 # everything marked `late` (collected after the parity tests of the round's last GPU run): GPU calibration, the modulated
 # GroupNorm (qd_groupnorm_mod_silu_quant), the LSUN-Churches attention shapes, ldm_updown_tiny / churches_full whole-UNet and
 # teacher-forced blocks — WITHOUT -x, so that one failure does not hide the others
-timeout 900 python -m pytest tests -m "gpu and late" -q > $out/pytest_late.log 2>&1; echo "late tests rc=$?"; tail -8 $out/pytest_late.log
+QDIFF_RUN_LATE=1 timeout 900 python -m pytest tests -m "gpu and late" -q > $out/pytest_late.log 2>&1; echo "late tests rc=$?"; tail -8 $out/pytest_late.log
 timeout 300 python bench.py --model churches --steps 10 --warmup 2 > $out/bench_churches.json 2> $out/bench_churches.err; echo "churches bench rc=$?"; tail -c 1500 $out/bench_churches.json
 timeout 120 python tools/bench_fakequant.py 2>&1 | tail -2 | tee $out/fakequant.txt
 SH="16,320,64,320,3,1;16,640,64,320,3,1;16,960,64,320,3,1;16,640,32,640,3,1;16,1280,32,640,3,1;16,1280,16,1280,3,1"
