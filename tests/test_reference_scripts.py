@@ -339,7 +339,20 @@ def test_txt2img_script_calibrates_with_this_packages_reconstruction(sd_run_dir,
     (txt2img.py:395-490) — on each `qdiff`, 3 + 3 iterations per unit on 16 x 16 latents.  Same checkpoint keys and shapes;
     AdaRound alphas and activation step sizes within the reach of their own Adam steps."""
     import glob
-    d = sd_run_dir
+    import yaml
+    from qdiff import synthetic
+    from qdiff.arch import ldm_unet
+    d = tmp_path
+    # a one-level UNet for this test: the reference's per-channel 'mse' range search (80 candidates per output channel,
+    # quant_layer.py:138-177) is what a from-scratch calibration spends its start-up on
+    unet_kw = dict(SD_SCRIPT_UNET, channel_mult=[1], attention_resolutions=[1])
+    cfg = yaml.safe_load(open(sd_run_dir / "v1-inference-small.yaml"))
+    cfg["model"]["params"]["unet_config"]["params"] = dict(unet_kw)
+    yaml.safe_dump(cfg, open(d / "v1-inference-small.yaml", "w"))
+    unet = ldm_unet.UNetModel(**unet_kw)
+    synthetic.load_synthetic_weights(unet, seed=0)
+    torch.save({"global_step": 0, "state_dict": {"model.diffusion_model." + k: v.clone() for k, v in unet.state_dict().items()}},
+               d / "model.ckpt")
     g = torch.Generator().manual_seed(21)
     n, steps = 8, 4
     data = {"xs": [torch.randn(n, 4, 16, 16, generator=g) for _ in range(steps)],
@@ -382,7 +395,7 @@ def test_txt2img_script_calibrates_with_this_packages_reconstruction(sd_run_dir,
             assert torch.equal(va, vb), k
         elif leaf != "zero_point":
             assert torch.equal(va, vb), k
-    assert n_alpha > 20 and n_delta > 40
+    assert n_alpha > 15 and n_delta > 25
     assert ref["images"].shape == ours["images"].shape == (1, 128, 128, 3)
 
 
