@@ -83,6 +83,40 @@ def test_conv_desc_offsets_match_the_compiled_header(tmp_path):
         assert int(got[f"raw.{name}"]) == getattr(hip.RawQuant, name).offset, name
 
 
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every `argtypes` list of qdiff/hip.py against the prototype include/qdiff_hip.h declares for that symbol: the same number
+    of parameters, each of the same kind (pointer / 32-bit int / 64-bit int / float) in the same position — a shifted argument
+    in a ctypes call corrupts silently, and no CPU test would otherwise see it."""
+    import ctypes
+    import re
+    from qdiff import hip
+    lib = hip.load()
+    h = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "qdiff_hip.h")).read(), flags=re.S)
+    protos = re.findall(r"\b(?:int|int64_t|const char\*|void)\s+(qd_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", h, flags=re.S)
+    assert len(protos) == len(hip.EXPORTS) and {n for n, _ in protos} == set(hip.EXPORTS)
+
+    def header_kind(t):
+        t = t.strip()
+        if t in ("void", ""):
+            return None
+        if "*" in t:
+            return "ptr"
+        return {"int": "i32", "int32_t": "i32", "int64_t": "i64", "float": "f32"}[t.replace("const", "").split()[0]]
+
+    def ctypes_kind(c):
+        if c in (ctypes.c_void_p, ctypes.c_char_p) or (isinstance(c, type) and issubclass(c, ctypes._Pointer)):
+            return "ptr"
+        return {ctypes.c_int: "i32", ctypes.c_int64: "i64", ctypes.c_long: "i64", ctypes.c_float: "f32"}[c]
+
+    for name, args in protos:
+        want = [k for k in (header_kind(a) for a in args.split(",")) if k]
+        at = getattr(lib, name).argtypes
+        if at is None:
+            assert not want, f"{name}: the header declares {len(want)} parameters, hip.py sets no argtypes"
+            continue
+        assert [ctypes_kind(c) for c in at] == want, name
+
+
 def test_modulated_groupnorm_entry_validates_its_arguments_on_the_host():
     """qd_groupnorm_mod_silu_quant (ABI v15): the argument checks that precede any device work are reachable without a GPU and
     tell that `mod` / `mod_ld` arrive in the positions the ctypes binding puts them (fake non-null pointers are never
