@@ -248,9 +248,36 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-denominators", action="store_true", help="skip the fp32 / fake-quant GPU denominators")
     ap.add_argument("--decode", action="store_true", help="also time the first-stage decode of the image batch (sd / ldm / churches; extra field)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only (gloo, no GPU): prove that `python bench.py --gpus N` becomes N ranks; used by tests")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become N ranks of one node, one process per GPU (the driver's own command line,
+        # SURVEY.md §8e); the children see WORLD_SIZE and fall through to the code below
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {a.gpus}")
+    if a.launch_check:
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")
+        t = torch.ones(1)
+        if world > 1:
+            dist.all_reduce(t)
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": int(t.item())}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():

@@ -177,13 +177,22 @@ def export_packed_ckpt(qnn, to_cpu=True):
     from . import engine
     keep = (lambda t: t.detach().cpu().clone()) if to_cpu else (lambda t: t.detach())
     mods, quantizers, skip = {}, {}, set()
+    # the GEGLU projections (`ff.net[0].proj` of every transformer block, reference attention.py:37-44): they run through a
+    # SECOND, value/gate-interleaved pack (QuantModule.geglu_plan) which must travel whether or not an integer forward has
+    # built it on the exporting side yet — a receiver without it silently takes the unfused projection + qd_geglu_quant path
+    geglu_ids = set()
+    for blk in qnn.model.modules():
+        proj = getattr(getattr(getattr(getattr(blk, "ff", None), "net", [None])[0], "proj", None), "geglu_plan", None) \
+            if hasattr(blk, "attn1") and hasattr(blk, "norm3") else None
+        if proj is not None:
+            geglu_ids.add(id(blk.ff.net[0].proj))
     for name, m in qnn.model.named_modules():
         if isinstance(m, QuantModule):
             if not m.int_ready():
                 raise ValueError(f"{name}: export_packed_ckpt needs set_quant_state(True, True) and initialised quantisers")
             entry = dict(pack=engine.pack_to_dict(m.conv_plan().pack, to_cpu), split=int(m.split))
-            if "_geglu_cache" in m.__dict__ or m.__dict__.get("_frozen_geglu_pack") is not None:
-                gp = m.geglu_plan()              # the layer runs as a fused GEGLU projection: refreshed for the CURRENT quantisers
+            if id(m) in geglu_ids or "_geglu_cache" in m.__dict__ or m.__dict__.get("_frozen_geglu_pack") is not None:
+                gp = m.geglu_plan()              # None when the layer does not qualify; always for the CURRENT quantisers
                 if gp is not None:
                     entry["geglu_pack"] = engine.pack_to_dict(gp.pack, to_cpu)
             mods[name] = entry

@@ -128,8 +128,9 @@ def _worker(rank, world, port, gb, out_dir):
     spec = fx["spec"]
     if rank == 0:
         qnn = _resume_cpu(fx)
-        with torch.no_grad():
-            qnn(*fixture_inputs(fx, "cal"))                      # the fused GEGLU packs exist once the path has run
+        if gb == 6:                                              # gb == 7: COLD export — bench.py broadcasts right after
+            with torch.no_grad():                                # convert_adaround, before any integer forward; the GEGLU
+                qnn(*fixture_inputs(fx, "cal"))                  # packs must travel either way (round-2 defect)
     else:
         wq, aq = quant_params(spec)
         skel = synthetic.load_synthetic_weights(build_engine_model(spec), seed=777)      # NOT the calibrated weights
@@ -139,7 +140,9 @@ def _worker(rank, world, port, gb, out_dir):
     with torch.no_grad():
         y = qnn(x, t, c)
     freed = all(m.weight.numel() == 0 for m in qnn.modules() if isinstance(m, qdiff.QuantModule))
-    torch.save(dict(y=y, nbytes=nbytes, freed=freed), os.path.join(out_dir, f"model_{rank}.pt"))
+    blocks = [m for m in qnn.modules() if isinstance(m, qdiff.quant_block.QuantBasicTransformerBlock)]
+    geglu = [b.ff.net[0].proj.geglu_plan() is not None for b in blocks]
+    torch.save(dict(y=y, nbytes=nbytes, freed=freed, geglu=geglu), os.path.join(out_dir, f"model_{rank}.pt"))
     # --- sharded sampling --------------------------------------------------------------------------
     table = sampling.StepTable(sampling.ldm_betas(0.00085, 0.012), 10, eta=0.0)
     shape = (gb, 4, 8, 8)
@@ -152,6 +155,9 @@ def _worker(rank, world, port, gb, out_dir):
         torch.save(full, os.path.join(out_dir, "gathered.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+_ARENA_BYTES = {}
 
 
 @pytest.mark.parametrize("gb", [6, 7])
@@ -175,6 +181,12 @@ def test_sharded_sampling_two_ranks_gloo(tmp_path, gb):
     assert m0["nbytes"] == m1["nbytes"] > 100_000
     assert torch.equal(m0["y"], m1["y"]) and torch.isfinite(m0["y"]).all()
     assert m1["freed"] and not m0["freed"]
+    # every transformer block of the RECEIVER runs the fused GEGLU projection, with or without a prior forward on rank 0,
+    # and the arena has the same size both ways
+    assert len(m1["geglu"]) > 0 and all(m1["geglu"]) and all(m0["geglu"])
+    _ARENA_BYTES[gb] = m0["nbytes"]
+    if len(_ARENA_BYTES) == 2:
+        assert _ARENA_BYTES[6] == _ARENA_BYTES[7], _ARENA_BYTES
     if gb == 6:
         import abi_emulator
         from golden_util import fixture_inputs as fi, load_fixture as lf
@@ -189,3 +201,23 @@ def test_sharded_sampling_two_ranks_gloo(tmp_path, gb):
         finally:
             mp_.undo()
         assert torch.equal(want_y, m0["y"])
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the plain command line) must become two ranks of one node
+    (round-2 defect: the flag was parsed and never read).  --launch-check stops after the rendezvous: no GPU here."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    assert json.loads(line) == {"launch_check": True, "n_gpus": 2, "ranks_seen": 2}
+    # a mismatch between the flag and the launcher's world size is refused, not silently reported as n_gpus = 1
+    env["WORLD_SIZE"], env["RANK"] = "1", "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
