@@ -129,7 +129,20 @@ def measure_igemm(qnn, args):
         e1.record(st)
         k = call.kh * call.kw * sum(s["clen"] for s in call.segs)
         m = call.B * call.Ho * call.Wo
-        records.append((e0, e1, 2.0 * m * k * call.Cout, m, call.Cout, k))
+        epi = getattr(call, "epilogue", 0) or 0
+        if epi == hip.EPI_GEGLU_I8:
+            cls = "geglu_i8_out"
+        elif epi in (hip.EPI_HEADS_I8, hip.EPI_HEADS_T_I8):
+            cls = "heads_i8_out"
+        elif len(call.segs) == 2:
+            cls = "split_shortcut"
+        elif call.splitk is not False and hip.splitk_ws_bytes(call) > 0:
+            cls = "split_k(+finalise)"
+        elif k >= 2880:
+            cls = "long_k_f32_out"
+        else:
+            cls = "short_k_f32_out"
+        records.append((e0, e1, 2.0 * m * k * call.Cout, m, call.Cout, k, cls))
     hip.conv2d_i8 = timed
     try:
         with torch.no_grad():
@@ -152,7 +165,17 @@ def measure_igemm(qnn, args):
     overhead = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
     ms = sum(max(a.elapsed_time(b) - overhead, 0.0) for a, b, *_ in records)
     ops = sum(r[2] for r in records)
-    return dict(launches=len(records), total_ms=ms, ops=ops, event_overhead_us=1000.0 * overhead)
+    classes = {}
+    for a, b, o, *_rest, cls in records:
+        c = classes.setdefault(cls, dict(launches=0, ms=0.0, GOP=0.0))
+        c["launches"] += 1
+        c["ms"] += max(a.elapsed_time(b) - overhead, 0.0)
+        c["GOP"] += o / 1e9
+    for c in classes.values():
+        c["TOPs"] = round(c["GOP"] / max(c["ms"], 1e-9), 1)                 # GOP / ms == TOP/s
+        c["frac"] = round(c["TOPs"] / I8_MFMA_PEAK_TOPS, 4)
+        c["ms"], c["GOP"] = round(c["ms"], 3), round(c["GOP"], 1)
+    return dict(launches=len(records), total_ms=ms, ops=ops, event_overhead_us=1000.0 * overhead, classes=classes)
 
 
 def gpu_denominators(qnn, margs, k=2):
@@ -207,11 +230,27 @@ def cpu_baseline(qnn, qspec, kind, cfg, k=2):
                 U.cifar_forward(Q, cfg, x, t, split_shortcut=True)
             else:
                 U.ldm_forward(Q, cfg, x, t, c, split=kind != "churches")
-    one()
+    # best-effort CPU number: batch 1 on every hardware thread of a 128-thread host is oversubscribed (round 2: 22.4 s on 128
+    # threads against 13.3 s for the unmodified reference on 8 cores), so sweep the intra-op thread count on one evaluation
+    # each, then time k evaluations at the best setting
+    n0 = torch.get_num_threads()
+    cands = sorted({t for t in (8, 16, 32, 64, n0) if t <= n0})
+    torch.set_num_threads(cands[len(cands) // 2])
+    one()                                              # warm-up (allocator, oneDNN primitives)
+    sweep = {}
+    for t in cands:
+        torch.set_num_threads(t)
+        t0 = time.time()
+        one()
+        sweep[t] = time.time() - t0
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
     t0 = time.time()
     for _ in range(k):
         one()
-    return (time.time() - t0) / k
+    dt = (time.time() - t0) / k
+    torch.set_num_threads(n0)
+    return dt, best, {str(t): round(v, 2) for t, v in sweep.items()}
 
 
 def first_stage_decode_ms(kind, n, dev, k=3):
@@ -394,8 +433,9 @@ def main():
         traffic, traffic_src = None, None
         for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(f"_{kind}_igemm_hbm_traffic.json")),
                            reverse=True):
-            traffic = json.load(open(os.path.join(ROOT, "profiles", cand))).get("hbm_bytes_per_call_corrected")
-            traffic_src = "profiles/" + cand
+            tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
+            traffic = tj.get("hbm_bytes_per_call_corrected")
+            traffic_src = "profiles/" + cand + (f" (measured at commit {tj['commit']})" if tj.get("commit") else " (commit of the measurement not recorded)")
             break
         # whole-step view: every integer op of the evaluation (contractions + attention, SURVEY.md §8d per-sample figures)
         # against the wall clock of the timed sampler step
@@ -410,7 +450,8 @@ def main():
                            "launches_per_eval": r["launches"],
                            "avg_launch_us": round(1000.0 * r["total_ms"] / r["launches"], 2),
                            "igemm_ms_per_eval": round(r["total_ms"], 3), "algorithmic_GOP_per_eval": round(r["ops"] / 1e9, 1),
-                           "event_pair_overhead_us": round(r["event_overhead_us"], 2)}
+                           "event_pair_overhead_us": round(r["event_overhead_us"], 2),
+                           "by_launch_class": r["classes"]}
         if world == 1 and not a.no_denominators:
             # same UNet, same batch, same GPU, same run: the denominators of north_star's ">= 4x the reference fp32
             # PyTorch-ROCm UNet" target
@@ -421,12 +462,14 @@ def main():
                            "fp32); fake_quant_sim = the reference's fp32 simulation arithmetic on the GPU (fake-quantised weights cached)")
             out["gpu_denominators"] = den
         if world == 1 and not a.no_cpu_baseline:
-            dt = cpu_baseline(qnn, qspec, kind, ocfg)
+            dt, cpu_threads, cpu_sweep = cpu_baseline(qnn, qspec, kind, ocfg)
             # dt = one sample through one UNet evaluation; an image needs `evals` evaluations of 2 samples (CFG) or 1
             per_image = evals * (2 if guide != 1.0 else 1) * dt
-            out["cpu_baseline"] = {"value": round(1.0 / per_image, 6), "unit": "images/s", "cores": torch.get_num_threads(),
-                                   "kind": "port", "sample": f"UNet evaluations of one sample on the host cores: 1 warm-up + 2 timed, {dt:.1f} s "
-                                                             f"each; extrapolated to {evals} evaluations x {2 if guide != 1.0 else 1} samples per image"}
+            out["cpu_baseline"] = {"value": round(1.0 / per_image, 6), "unit": "images/s", "cores": cpu_threads,
+                                   "kind": "port", "sample": f"UNet evaluations of one sample on the host cores: 1 warm-up, one evaluation per "
+                                                             f"thread count {cpu_sweep} (seconds), then 2 timed at the best ({cpu_threads} of "
+                                                             f"{torch.get_num_threads()} threads): {dt:.1f} s each; extrapolated to {evals} evaluations x "
+                                                             f"{2 if guide != 1.0 else 1} samples per image"}
         if a.decode and kind in ("sd", "ldm", "churches"):
             out["first_stage_decode"] = first_stage_decode_ms(kind, n, dev)
         print(json.dumps(out))

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 15
+#define QD_ABI_VERSION 16
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -167,19 +167,14 @@ typedef struct {
      * then costs no copy at all. */
     float*         gn_part;
     int64_t        gn_ld;
-    /* qd_conv3x3_halo_i8 only (qd_conv2d_i8 rejects a non-zero value): x holds the HALF-resolution map [B][H/2][W/2][ldx] and the
-     * convolution runs on its nearest-neighbour 2x up-sampling (Upsample: openaimodel.py:105-120) — H, W are the up-sampled sizes. */
+    /* non-zero: x holds the HALF-resolution map [B][H/2][W/2][ldx] and the convolution runs on its nearest-neighbour 2x
+     * up-sampling (Upsample: openaimodel.py:105-120, ddim diffusion.py:36-52) — H, W are the up-sampled sizes; the
+     * replication happens in the im2col source address, no up-sampled tensor exists.  Needs stride 1, kh*kw > 1, even H, W. */
     int32_t        upsample2x;
     int32_t        _pad3;
 } qd_conv_desc;
 
 int qd_conv2d_i8(const qd_conv_desc* d, void* stream);
-
-/* EXPERIMENTAL, not used unless the host sets QDIFF_HALO=1: the same convolution for 3x3 / stride 1 / pad 1 layers with the
- * activation patch of a block resident in LDS across the nine taps (csrc/igemm_halo.hip).  qd_conv3x3_halo_ok tells whether
- * the descriptor is covered; results are bit-identical to qd_conv2d_i8's. */
-int qd_conv3x3_halo_ok(const qd_conv_desc* d);
-int qd_conv3x3_halo_i8(const qd_conv_desc* d, void* stream);
 
 /* Scratch bytes qd_conv2d_i8 would use for a split-K contraction of this descriptor (shape fields only are
  * read); 0 when the layer is launched unsplit. */

@@ -13,7 +13,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libqdiff_hip.so")
 ARCH = "gfx950"
-SOURCES = ["errors.cpp", "igemm_dma.hip", "quantize.hip", "norm_quant.hip", "attn_i8.hip", "bmm_i8.hip", "temb_mlp.hip", "fakequant.hip", "igemm_halo.hip"]
+SOURCES = ["errors.cpp", "igemm_dma.hip", "quantize.hip", "norm_quant.hip", "attn_i8.hip", "bmm_i8.hip", "temb_mlp.hip", "fakequant.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "qdiff_hip.h")]
 # correctly-rounded fp32 division / sqrt are hipcc defaults; keep them explicit because the
 # quantisers must reproduce torch's `round(x / delta)` bit for bit.

@@ -75,6 +75,7 @@ struct ConvD {
     int    gn_nchunk;         //   i.e. the first level of GroupNorm's statistics (layout of gn_partial_kernel); S/128
     long   gn_ld;             //   channels per chunk row of gnpart (>= Cout: column range of a wider statistics buffer)
     int    pointwise;         // 1x1 convolution / linear layer without padding or stride: output row m is input pixel m
+    int    ups;               // x is the HALF-resolution map [B][H/2][W/2][ldx]; the convolution runs on its nearest-2x up-sampling
 };
 
 // O_PART: split-K partial.  The block contracts K-steps [y*it_per, (y+1)*it_per) only and stores
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
     const int a_chunk = (slot ^ ((lr16 >> 2) & 3)) * 16;   // source byte offset inside a 64-B K-step landing in this lane's slot
     const int8_t* a_org[NA];                      // pixel (ho*stride - pad_t, wo*stride - pad_l) of this lane's row, + a_chunk
     unsigned a_mask[NA];                          // bit t: tap t of that row lies inside the image
+    int a_hw0[NA];                                // ups only: (ih0 + 8) << 16 | (iw0 + 8) of the row's first tap on the UP-SAMPLED map
     bool a_valid[NA];
     const int HoWo = p.Ho * p.Wo;
     // 1x1 / linear layers (three quarters of the launches of a UNet evaluation, most of them short-K): output row m IS input
@@ -181,6 +183,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
             const int mm = a_valid[i] ? m : 0;
             a_org[i] = p.x + (long)mm * p.ldx + a_chunk;
             a_mask[i] = a_valid[i] ? 1u : 0u;
+            a_hw0[i] = 0;
             if (p.rowbias != nullptr && slot == 0) sRowB[r] = mm / HoWo;
         }
     } else {
@@ -194,7 +197,11 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
         const int rem = mm - b * HoWo;
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
         const int ih0 = ho * p.stride - p.pad_t, iw0 = wo * p.stride - p.pad_l;
-        a_org[i] = p.x + ((long)b * p.H * p.W + (long)ih0 * p.W + iw0) * p.ldx + a_chunk;
+        // nearest-2x folded into the gather (openaimodel.py:105-120 Upsample): tap pixel (ih, iw) of the up-sampled map is
+        // pixel (ih >> 1, iw >> 1) of the stored one — not linear in the tap, so set_tap() computes it per row
+        a_org[i] = p.ups ? p.x + (long)b * (p.H >> 1) * (p.W >> 1) * p.ldx + a_chunk
+                         : p.x + ((long)b * p.H * p.W + (long)ih0 * p.W + iw0) * p.ldx + a_chunk;
+        a_hw0[i] = ((ih0 + 8) << 16) | (iw0 + 8);
         unsigned msk = 0;
         for (int t = 0; t < p.taps; ++t) {
             const int ih = ih0 + t / p.kw, iw = iw0 + t % p.kw;
@@ -238,7 +245,12 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const bool inb = (a_mask[i] >> ltap) & 1u;
-            a_cur[i] = inb ? a_org[i] + tap_off : (a_valid[i] ? seg_fill : zero16);
+            long off = tap_off;
+            if (p.ups) {                              // wave-uniform; once per tap, not per K-step
+                const int ih = (a_hw0[i] >> 16) - 8 + lrr, iw = (a_hw0[i] & 0xffff) - 8 + lq;
+                off = ((long)(ih >> 1) * (p.W >> 1) + (iw >> 1)) * p.ldx + seg_c0;
+            }
+            a_cur[i] = inb ? a_org[i] + off : (a_valid[i] ? seg_fill : zero16);
             a_inc[i] = inb ? 64 : 0;
         }
     };
@@ -912,41 +924,6 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const int32_t* __r
     }
 }
 
-// EXPERIMENTAL (QD_FIN_VEC=1, off by default): the same second pass with four consecutive output channels per thread —
-// 16-byte loads of every slice, of the residual and the row bias, one 16-byte store (the scalar version moves 4 bytes per lane
-// per access).  fp32 only, Cout % 4 == 0, 16-byte aligned rows.  Same float sequence per element.
-__global__ __launch_bounds__(256) void splitk_finalize4_kernel(const int32_t* __restrict__ part, int nsplit, long MN, int Cout, int HoWo,
-                                                               const float* __restrict__ scale, const int* __restrict__ zc,
-                                                               const int* __restrict__ zw, const int* __restrict__ zfill,
-                                                               const float* __restrict__ bias, const float* __restrict__ rowbias, long ldrb,
-                                                               const float* __restrict__ residual, long ldr, float* __restrict__ out, long ldo) {
-    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (e >= MN) return;
-    const long m = e / Cout;
-    const int  n = (int)(e - m * Cout);
-    v4i I = {0, 0, 0, 0};
-    for (int s = 0; s < nsplit; ++s) I += *reinterpret_cast<const v4i*>(part + (long)s * MN + e);
-    const int kz = zfill ? zfill[1] : 0;
-    v4f v;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int Ij = I[j] - (zc ? zc[n + j] : 0) + (zw ? zw[n + j] : 0) * kz;
-        v[j] = (float)Ij * scale[n + j];
-        v[j] += bias ? bias[n + j] : 0.f;
-    }
-    if (rowbias) {
-        const v4f rb = *reinterpret_cast<const v4f*>(rowbias + (m / HoWo) * ldrb + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += rb[j];
-    }
-    if (residual) {
-        const v4f rs = *reinterpret_cast<const v4f*>(residual + m * ldr + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += rs[j];
-    }
-    *reinterpret_cast<v4f*>(out + m * ldo + n) = v;
-}
-
 // tile-ordered s8 packer: thread = one 16-byte unit (row n, 16 consecutive K), stored byte = W - 128
 __global__ __launch_bounds__(256) void pack_t8_kernel(const float* __restrict__ w, const float* __restrict__ alpha,
                                                       const float* __restrict__ delta, const float* __restrict__ zp,
@@ -1044,7 +1021,8 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
     QD_REQUIRE(d->x && d->w && (d->out || iout), "qd_conv2d_i8: null tensor pointer");
     QD_REQUIRE(d->w_tiled, "qd_conv2d_i8: weights must be in the tile order of qd_pack_weights_t4 / _t8 (w_tiled = 1)");
     QD_REQUIRE(d->wbits == 4 || d->wbits == 8, "qd_conv2d_i8: wbits must be 4 or 8 (got %d)", d->wbits);
-    QD_REQUIRE(!d->upsample2x, "qd_conv2d_i8: upsample2x is a qd_conv3x3_halo_i8 feature");
+    QD_REQUIRE(!d->upsample2x || (d->stride == 1 && d->kh * d->kw > 1 && d->H % 2 == 0 && d->W % 2 == 0 && d->pad_t < 8 && d->pad_l < 8),
+               "qd_conv2d_i8: upsample2x needs stride 1, more than one tap, even H and W");
     QD_REQUIRE(d->out_dtype == QD_F32 || d->out_dtype == QD_F16, "qd_conv2d_i8: out_dtype must be f32/f16");
     QD_REQUIRE(d->nseg == 1 || d->nseg == 2, "qd_conv2d_i8: nseg must be 1 or 2");
     QD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, "qd_conv2d_i8: bad shape");
@@ -1062,6 +1040,7 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
     k.M = d->B * d->Ho * d->Wo; k.taps = d->kh * d->kw; k.nseg = d->nseg;
     static const bool pw_ok = !(getenv("QD_POINTWISE") && atoi(getenv("QD_POINTWISE")) == 0);          // A/B knob
     k.pointwise = pw_ok && k.taps == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->H == d->Ho && d->W == d->Wo;
+    k.ups = d->upsample2x ? 1 : 0;
     k.ntiles = (d->Cout + 31) / 32;
     for (int s = 0; s < d->nseg; ++s) {
         const qd_conv_seg& g = d->seg[s];
@@ -1139,16 +1118,6 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
         const SegD& sg = k.seg[0];
         const long MN = M * N;
         dim3 grid((unsigned)((MN + 255) / 256)), block(256);
-        static const bool fin_vec = getenv("QD_FIN_VEC") && atoi(getenv("QD_FIN_VEC")) == 1;     // experimental, see splitk_finalize4_kernel
-        if (fin_vec && d->out_dtype == QD_F32 && N % 4 == 0 && d->ldo % 4 == 0 && qd_aligned(d->out, 16) &&
-            (!d->residual || (d->ldr % 4 == 0 && qd_aligned(d->residual, 16))) &&
-            (!d->rowbias || (d->ld_rowbias % 4 == 0 && qd_aligned(d->rowbias, 16)))) {
-            dim3 g4((unsigned)((MN / 4 + 255) / 256));
-            hipLaunchKernelGGL(splitk_finalize4_kernel, g4, block, 0, st, k.iout, nsplit, MN, N, d->Ho * d->Wo, sg.scale, sg.zc, sg.zw,
-                               sg.zfill, k.bias, k.rowbias, k.ldrb, (const float*)k.residual, k.ldr, (float*)k.out, k.ldo);
-            QD_LAUNCH_CHECK("qd_conv2d_i8 (split-K)");
-            return 0;
-        }
         if (d->out_dtype == QD_F16)
             hipLaunchKernelGGL(splitk_finalize_kernel<__half>, grid, block, 0, st, k.iout, nsplit, MN, N, d->Ho * d->Wo, sg.scale, sg.zc, sg.zw,
                                sg.zfill, k.bias, k.rowbias, k.ldrb, (const __half*)k.residual, k.ldr, (__half*)k.out, k.ldo);

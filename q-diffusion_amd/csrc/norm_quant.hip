@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
-// EXPERIMENTAL (QD_GN_ROWS=2|4, off by default): the same apply pass with U rows per thread — the U 16-byte loads of a thread
+// The apply pass with U rows per thread (default U = 2 since round 3: -0.15 ms per SD evaluation, profiles/r03_first_call_ab.md; QD_GN_ROWS=0|2|4) — the U 16-byte loads of a thread
 // are issued back to back before any of them is used (more bytes in flight per wave: the one-row kernel streams at
 // 3.8 TB/s of the ~5.5 the HBM sustains), the per-(sample, channel) affine is fetched once per U rows.  fp32 input, 16-byte
 // aligned rows, no float output; U consecutive rows always belong to one sample (S % U == 0).  Same arithmetic per element.
@@ -390,7 +390,7 @@ static int groupnorm_impl(const void* x, int x_dtype, int64_t B, int64_t S, int 
     }
     long rows = B * S;
     long total = rows * (C / 4);
-    static const int gn_rows_knob = getenv("QD_GN_ROWS") ? atoi(getenv("QD_GN_ROWS")) : 0;       // experimental, see gn_apply_rows_kernel
+    static const int gn_rows_knob = getenv("QD_GN_ROWS") ? atoi(getenv("QD_GN_ROWS")) : 2;       // rows per thread: 2 (default), 4, or 0 = the one-row kernel (A/B knob)
     if ((gn_rows_knob == 2 || gn_rows_knob == 4) && x_dtype == QD_F32 && vec && out && !yout && S % gn_rows_knob == 0) {
         const long tot = (rows / gn_rows_knob) * (C / 4);
         dim3 g2((unsigned)((tot + 255) / 256));

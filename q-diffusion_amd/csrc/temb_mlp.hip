@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void temb_kernel(const float* __restrict__ x, 
     const QP q = qd_load_qp(L.qp);
 
     // ---- 1. SiLU -> this layer's activation quantiser -> int8 rows in LDS, row sums ---------------------------------
-    if (tid < B) sAsum[tid] = 0;
+    for (int b = tid; b < B; b += 256) sAsum[b] = 0;                     // B may exceed the block (K = 128: up to 352 rows per launch)
     __syncthreads();
     const int k4n = K >> 2;
     auto quant = [&](auto ft) __attribute__((always_inline)) {

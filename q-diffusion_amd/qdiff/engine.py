@@ -321,12 +321,10 @@ class _SlotSide:
         return self.slot.part(self.i, B, nchunk, C, device)
 
 
-def halo_upsample_ok(plan, B, H, W):
-    """The experimental halo kernel (QDIFF_HALO=1) can run `plan` on the nearest-2x up-sampling of a half-resolution map
-    whose up-sampled size is H x W (mirrors qd_conv3x3_halo_ok) and its blocks would fill the chip."""
-    return bool(hip.HALO and hip.halo_blocks(B, H, W, plan.Cout) >= hip.HALO_MINBLK and plan.kh == 3 and plan.kw == 3 and plan.stride == 1 and plan.pad == 1 and len(plan.segs) == 1
-                and plan.pack.tiled and plan.pack.wbits == 4 and W in (16, 32, 64) and (H * W) % 128 == 0
-                and H % (128 // W) == 0 and H % 2 == 0 and plan.Cout % 320 == 0 and plan.segs[0]["clen"] % 16 == 0)
+def upsample_fold_ok(plan, H, W):
+    """qd_conv2d_i8 can run `plan` on the nearest-2x up-sampling of a half-resolution map (qd_conv_desc.upsample2x: the
+    replication is folded into the im2col source address of the gather kernel); H x W is the UP-SAMPLED size."""
+    return bool(plan.pack.tiled and plan.kh * plan.kw > 1 and plan.stride == 1 and H % 2 == 0 and W % 2 == 0)
 
 
 def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, residual=None, acc_out=None,
@@ -359,7 +357,7 @@ def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, re
                         splitk=splitk, upsample2x=upsample2x)
     part = None
     if (gn_stats and acc_out is None and plan.pack.tiled and out.dtype == torch.float32 and (Ho * Wo) % 128 == 0
-            and out.stride(1) == 1 and (upsample2x or splitk is False or hip.splitk_ws_bytes(call) == 0)):
+            and out.stride(1) == 1 and (splitk is False or hip.splitk_ws_bytes(call) == 0)):
         if slot is not None:
             part = slot.part(B, Ho * Wo // 128, plan.Cout, xq.device)
         if part is None:

@@ -65,7 +65,7 @@ EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_make_qparams",
            "qd_conv2d_i8", "qd_conv2d_i8_splitk_ws_bytes",
            "qd_conv2d_i8_acc", "qd_groupnorm_ws_bytes", "qd_groupnorm_silu_quant", "qd_groupnorm_mod_silu_quant", "qd_layernorm_quant",
            "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8", "qd_bmm_qk_i8", "qd_bmm_pv_i8", "qd_temb_mlp",
-           "qd_fakequant_blocks", "qd_fakequant_fwd", "qd_fakequant_bwd", "qd_conv3x3_halo_ok", "qd_conv3x3_halo_i8"]
+           "qd_fakequant_blocks", "qd_fakequant_fwd", "qd_fakequant_bwd"]
 
 _lib = None
 
@@ -111,9 +111,7 @@ def load():
     lib.qd_fakequant_blocks.argtypes = [i64]
     lib.qd_fakequant_fwd.argtypes = [vp, i64, vp, vp, i32, i32, vp, vp]
     lib.qd_fakequant_bwd.argtypes = [vp, vp, i64, vp, vp, i32, i32, vp, vp, vp]
-    lib.qd_conv3x3_halo_ok.argtypes = [ctypes.POINTER(ConvDesc)]
-    lib.qd_conv3x3_halo_i8.argtypes = [ctypes.POINTER(ConvDesc), vp]
-    if lib.qd_abi_version() != 15:
+    if lib.qd_abi_version() != 16:
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -241,28 +239,9 @@ def splitk_ws_bytes(c):
     return int(load().qd_conv2d_i8_splitk_ws_bytes(ctypes.byref(_conv_desc(c))))
 
 
-HALO = os.environ.get("QDIFF_HALO", "0") == "1"       # EXPERIMENTAL 3x3 kernel with the activation patch resident in LDS
-HALO_MINBLK = int(os.environ.get("QDIFF_HALO_MINBLK", "200"))   # ... only where its 128 x 320 blocks fill the chip (else split-K)
-
-
-def halo_blocks(B, H, W, Cout):
-    return (B * H * W // 128) * (Cout // 320)
-
-
-def halo_covers(c):
-    """The experimental 3x3 kernel (QDIFF_HALO=1) would take ConvCall `c` (shape fields and pointers only are looked at)."""
-    return bool(HALO and load().qd_conv3x3_halo_ok(ctypes.byref(_conv_desc(c))))
-
-
 def conv2d_i8(c, acc_out=None):
     """c: ConvCall.  segs: list of dicts {c0, clen, kofs, wzp, scale, zc, zw, zfill} (tensors or None)."""
     d = _conv_desc(c)
-    if c.upsample2x and not (HALO and acc_out is None and load().qd_conv3x3_halo_ok(ctypes.byref(d))):
-        raise HipEngineError("upsample2x needs the experimental halo kernel (QDIFF_HALO=1) and a shape it covers")
-    if (HALO and acc_out is None and (c.upsample2x or halo_blocks(c.B, c.H, c.W, c.Cout) >= HALO_MINBLK)
-            and load().qd_conv3x3_halo_ok(ctypes.byref(d))):
-        _check(load().qd_conv3x3_halo_i8(ctypes.byref(d), _stream()), "qd_conv3x3_halo_i8")
-        return
     if acc_out is None:
         if c.w_tiled and c.splitk is not False:
             need = int(load().qd_conv2d_i8_splitk_ws_bytes(ctypes.byref(d)))

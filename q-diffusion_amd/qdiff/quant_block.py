@@ -266,13 +266,16 @@ class ContextKV:
         if not all(blk.attn2.use_act_quant and blk._attn_inited(blk.attn2) for blk in self.members):
             return
         B, S, Cc = context.shape
-        ctx = context.reshape(B * S, Cc).float()
-        if ctx.stride(1) != 1:
-            ctx = ctx.contiguous()
         bufs = self.__dict__.setdefault("_bufs", {})
         dev = context.device
 
         def work():
+            # the fp32 row view of the context is made HERE, i.e. on the side stream when there is one: a converted /
+            # compacted copy (fp16 CLIP output under autocast) then belongs to the side stream's allocator pool and
+            # cannot be handed to a main-stream kernel while the branch still reads it
+            ctx = context.reshape(B * S, Cc).float()
+            if ctx.stride(1) != 1:
+                ctx = ctx.contiguous()
             out = {}
             for blk in self.members:
                 att = blk.attn2
@@ -300,9 +303,18 @@ class ContextKV:
         if self._side is None:
             self._side = torch.cuda.Stream(device=dev)
         self._side.wait_stream(main)                  # after everything queued so far (incl. the previous evaluation's readers)
+        context.record_stream(self._side)             # the caller's tensor is read by the branch: not reusable before it ends
         with torch.cuda.stream(self._side):
             self._out = work()
         self._joined = False
+
+    def finish(self):
+        """End of a UNet evaluation (forward hook of the model): a branch no cross-attention joined — every block took
+        the in-line path, or the walk stopped early (calibration capture) — is joined NOW, so that no work dangles on the
+        side stream past the evaluation, in particular not past the end of a HIP-graph capture."""
+        if not self._joined and self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._joined = True
 
 
 def time_mlp(lin0, lin1, t_emb, act=F.silu):

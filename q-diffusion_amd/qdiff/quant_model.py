@@ -84,6 +84,7 @@ class QuantModel(nn.Module):
             if isinstance(m, QuantBasicTransformerBlock):
                 ctx.register(m)
         self.model.register_forward_pre_hook(lambda _m, _a: (group.reset(), ctx.reset(), engine.begin_evaluation()) and None)
+        self.model.register_forward_hook(lambda _m, _a, _o: ctx.finish(), always_call=True)
         te = getattr(self.model, "time_embed", None)
         if (isinstance(te, nn.Sequential) and len(te) == 3 and isinstance(te[0], QuantModule) and isinstance(te[2], QuantModule)
                 and isinstance(te[1], nn.SiLU)):

@@ -150,7 +150,10 @@ def _unpack_rows(c, seg):
 
 def conv2d_i8(c, acc_out=None):
     B, H, W, Ho, Wo = c.B, c.H, c.W, c.Ho, c.Wo
-    x = c.x.view(B, H, W, c.ldx).to(torch.int64)
+    if getattr(c, "upsample2x", False):                     # x is the half-resolution map: nearest-2x replication of its rows
+        x = c.x.view(B, H // 2, 1, W // 2, 1, c.ldx).expand(B, H // 2, 2, W // 2, 2, c.ldx).reshape(B, H, W, c.ldx).to(torch.int64)
+    else:
+        x = c.x.view(B, H, W, c.ldx).to(torch.int64)
     total = None
     for seg in c.segs:
         zf = seg.get("zfill")

@@ -29,8 +29,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("name", ["cifar_tiny", "ldm_tiny", "sd_tiny", "cifar_full", "ldm_full", "sd_full",
-                                  pytest.param("ldm_updown_tiny", marks=pytest.mark.late),
-                                  pytest.param("churches_full", marks=pytest.mark.late)])
+                                  "ldm_updown_tiny",
+                                  "churches_full"])
 def test_blocks_teacher_forced(cuda, name):
     fx = load_fixture(f"model_{name}.pt")
     qnn = _resume(fx, cuda)

@@ -234,7 +234,6 @@ def test_data_parallel_calibration_two_ranks_gloo(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.late
 def test_calibration_runs_on_the_gpu(cuda, tmp_path):
     """The whole calibration sequence on the MI355X (HBM-resident unit caches, fused fake-quant kernels in the step-size
     phase), then the checkpoint it wrote drives the INTEGER engine: keys as produced on the CPU, finite values, and the

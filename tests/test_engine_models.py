@@ -77,7 +77,7 @@ def _metrics(y, ref):
 
 # ldm_updown_tiny / churches_full: resblock_updown + use_scale_shift_norm (LSUN-Churches LDM-8, models/ldm/lsun_churches256);
 # collected late: added after the round's last GPU run
-LATE = [pytest.param("ldm_updown_tiny", marks=pytest.mark.late), pytest.param("churches_full", marks=pytest.mark.late)]
+LATE = ["ldm_updown_tiny", "churches_full"]
 
 
 @pytest.mark.parametrize("name", TINY + FULL + LATE)

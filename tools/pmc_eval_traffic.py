@@ -64,6 +64,7 @@ def main(path, evals, out_path, kind="sd"):
         out["hbm_bytes_per_call_corrected"] = round(ig["bytes_per_eval_corrected"] / calls)
     out["correction"] = ("MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half the bytes of a 16-B/lane streaming read -> "
                          "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; an upper bound for kernels with narrower reads")
+    out["commit"] = os.environ.get("QD_COMMIT")          # the GPU box has no .git: the caller passes `git rev-parse --short HEAD`
     json.dump(out, open(out_path, "w"), indent=1)
     print(json.dumps(out)[:1500])
 
