@@ -570,6 +570,69 @@ def test_attention_fused(cuda, case):
     assert ((got - want_fq).abs() > 1e-3 * rng).float().mean().item() <= 1e-2
 
 
+PIPE_CASES = [
+    # name,            B, H, T,    S,    d,  sm_bits, q_sym, q_nonneg, peaky
+    ("even_tiles",     2, 4, 160,  256,  40, 16, False, False, False),     # 8 full key tiles, no ragged tile
+    ("odd_tiles",      1, 8, 96,   224,  40, 16, False, False, False),     # 7 full tiles
+    ("odd_plus_tail",  2, 4, 64,   237,  40, 16, False, False, False),     # 7 full + ragged
+    ("even_plus_tail", 2, 4, 64,   77,   40, 16, False, False, False),     # 2 full + ragged (the cross-attention shape)
+    ("tail_only",      1, 4, 200,  19,   40, 16, False, False, False),     # the ragged tile alone
+    ("one_tile",       1, 4, 64,   32,   40, 16, False, False, False),
+    ("hi_dead_4096",   1, 2, 256,  4096, 40, 16, False, False, False),     # thousands of keys: no code reaches 256 (8-bit constants)
+    ("hi_live_peaky",  2, 4, 128,  320,  40, 16, False, False, True),      # sharp rows: hi bytes alive, upper clamp possible
+    ("p8_asym",        2, 8, 128,  192,  24, 8,  False, False, False),     # dpad 32 (DT = 1), 8-bit probabilities
+    ("p8_sym_d48",     2, 8, 96,   160,  48, 8,  True,  False, False),
+    ("p16_sym",        1, 4, 96,   130,  40, 16, True,  False, True),
+    ("zq-128_fallback", 2, 4, 96,  77,   40, 16, False, True,  False),     # -zq' = 128: the unpipelined two-constant body
+    ("ragged_T_blocks", 2, 4, 300, 200,  40, 16, False, False, False),     # 3 query blocks per head, the last one with idle waves
+    ("octaves_repeat", 1, 2, 256,  512,  40, 16, False, False, "huge"),    # the row maximum rises > 64 octaves after tile 0: repeat pass
+]
+
+
+@pytest.mark.parametrize("case", PIPE_CASES, ids=[c[0] for c in PIPE_CASES])
+def test_attention_pipe_equals_lean(cuda, case, monkeypatch):
+    """attn_lds_kernel (K / V^T tiles staged once per block in LDS by DMA, score chain back to back, P.V between the softmax
+    VALU, hi-byte skip) and attn_pipe_kernel (register-fed software pipeline) against attn_lean_kernel on the same operands: the
+    arithmetic, the operand order and the summation order are the same, so outputs must be BIT-IDENTICAL — fp32 rows and
+    the int8 rows of the quantising epilogue.  (The lean kernel itself is held to the integer oracle by test_attention_fused.)"""
+    from qdiff import engine
+    name, B, H, T, S, d, smb, qsym, qpos, peaky = case
+    g = torch.Generator().manual_seed(77)
+    C = H * d
+    q, k, v = (torch.randn(B, L, C, generator=g) for L in (T, S, S))
+    if qpos:
+        q = q.abs()
+    if peaky == "huge":
+        q, k = q * 6.0, k * 6.0
+        k[:, :40] *= 0.02                        # small scores in the first key tile, large ones later
+    elif peaky:
+        q, k = q * 3.0, k * 3.0
+
+    def mk(t, n_bits=8, s=False, always_zero=False):
+        dd, zz = R.uaq_init_scale(t, n_bits, s, False, "max", always_zero)
+        return NS(delta=dd, zero_point=zz, n_bits=n_bits, sym=s)
+    heads = lambda t, L: t.view(B, L, H, d).permute(0, 2, 1, 3).reshape(B * H, L, d)
+    scale = d ** -0.5
+    p = (torch.einsum("bid,bjd->bij", heads(q, T), heads(k, S)) * scale).softmax(-1)
+    ap = engine.build_attn_plan(mk(q, 8, qsym), mk(k, 8, qsym), mk(v, 8, qsym), mk(p, smb, False, True), scale, 1.0, cuda)
+    Tp, Sp, dp = engine.pad32(T), engine.pad32(S), engine.pad32(d)
+    q8 = torch.zeros((B * H, Tp, dp), dtype=torch.int8, device=cuda)
+    k8 = torch.zeros((B * H, Sp, dp), dtype=torch.int8, device=cuda)
+    v8 = torch.zeros((B * H, dp, Sp), dtype=torch.int8, device=cuda)
+    vsum = torch.zeros((B * H, dp), dtype=torch.int32, device=cuda)
+    for which, (t, L, buf) in enumerate(((q, T, q8), (k, S, k8), (v, S, v8))):
+        engine.heads_from_float(ap, which, t.to(cuda), B, L, H, d, (L * C, C, d, 1), buf, vsum)
+    outs = {}
+    for mode in ("0", "1", "2"):                  # 0: attn_lean_kernel, 1: attn_pipe_kernel (registers), 2: attn_lds_kernel (default)
+        monkeypatch.setenv("QD_ATTN_PIPE", mode)
+        o = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d)
+        torch.cuda.synchronize()
+        outs[mode] = o.clone()
+    assert torch.isfinite(outs["0"]).all() and outs["0"].abs().max() > 0
+    for mode in ("1", "2"):
+        assert torch.equal(outs["0"], outs[mode]), (mode, (outs["0"] - outs[mode]).abs().max().item())
+
+
 @pytest.mark.parametrize("T,N,K", [(128, 320, 320), (256, 640, 640), (512, 320, 1280)])
 def test_projection_heads_epilogue_matches_quantize_heads(cuda, T, N, K):
     """q/k/v projections that write attention operand bytes from the GEMM epilogue (QD_EPI_HEADS_*) produce

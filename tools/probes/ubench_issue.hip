@@ -18,14 +18,17 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define ITERS 400
 
 enum { T_FMA, T_PKFMA, T_EXP, T_MAX3, T_PERM, T_CVT, T_ADDU, T_DOT4, T_MUL24, T_MFMA32_IND, T_MFMA32_DEP, T_MFMA16_IND, T_MFMA16_DEP,
-       T_MIX_ATTN1, T_MIX_MFMA_FMA4, T_MIX_MFMA_FMA8, T_MIX_MFMA_EXP4, T_SPLIT_ROLES, T_LDSR128, T_MIX_MFMA_LDS, T_COUNT };
+       T_MIX_ATTN1, T_MIX_MFMA_FMA4, T_MIX_MFMA_FMA8, T_MIX_MFMA_EXP4, T_SPLIT_ROLES, T_LDSR128, T_MIX_MFMA_LDS,
+       T_S2_MIX, T_S2_NOEXP, T_S2_NOPK, T_S2_NOPERM, T_S2_ALLFMA, T_S2_VALUONLY, T_S2_MIX_DEP, T_COUNT };
 
 static const char* NAMES[T_COUNT] = {"v_fma_f32 x32", "v_pk_fma_f32 x32", "v_exp_f32 x32", "v_max3_i32 x32", "v_perm_b32 x32", "v_cvt_f32_i32 x32",
     "v_add_u32 x32", "v_dot4_i32_i8 x32", "v_mul_i32_i24 x32", "mfma_i32_32x32x32_i8 x8 (4 independent acc)", "mfma_i32_32x32x32_i8 x8 (1 dependent acc)",
     "mfma_i32_16x16x64_i8 x8 (4 independent acc)", "mfma_i32_16x16x64_i8 x8 (1 dependent acc)",
     "attention sweep-1 tile: 4 mfma32 (dep) + 8x(max3, pk_fma, 2 exp, pk_add)", "4 mfma32 (ind) + 16 v_fma interleaved", "4 mfma32 (ind) + 32 v_fma interleaved",
-    "4 mfma32 (ind) + 16 v_exp interleaved", "waves 0,1: 8 mfma32 only | waves 2,3 (other SIMDs) ... see note", "ds_read_b128 x16", "4 mfma32 (ind) + 8 ds_read_b128"};
-static const int NINSTR[T_COUNT] = {32, 32, 32, 32, 32, 32, 32, 32, 32, 8, 8, 8, 8, 4 + 8 * 5, 20, 36, 20, 8, 16, 12};
+    "4 mfma32 (ind) + 16 v_exp interleaved", "waves 0,1: 8 mfma32 only | waves 2,3 (other SIMDs) ... see note", "ds_read_b128 x16", "4 mfma32 (ind) + 8 ds_read_b128",
+    "sweep-2 slice x4: mfma(ind) + 2 pk_fma, 2 exp, 3 perm, 2 xor", "  ... exp -> v_fma", "  ... pk_fma -> 2 v_fma", "  ... perm/xor -> v_fma",
+    "  ... every VALU -> v_fma (9 per mfma)", "  ... the VALU mix without the MFMAs", "  ... the mix with a DEPENDENT mfma chain (one accumulator)"};
+static const int NINSTR[T_COUNT] = {32, 32, 32, 32, 32, 32, 32, 32, 32, 8, 8, 8, 8, 4 + 8 * 5, 20, 36, 20, 8, 16, 12, 40, 40, 48, 40, 40, 36, 40};
 
 template <int T>
 __global__ __launch_bounds__(256) void bench(long long* out, int seed) {
@@ -127,6 +130,39 @@ __global__ __launch_bounds__(256) void bench(long long* out, int seed) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc[u & 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[u & 3], 0, 0, 0);
             }
+        } else if constexpr (T >= T_S2_MIX && T <= T_S2_MIX_DEP) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (T == T_S2_MIX_DEP) acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[0], 0, 0, 0);
+                else if constexpr (T != T_S2_VALUONLY) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[u], 0, 0, 0);
+                // 2 pk_fma
+                if constexpr (T == T_S2_NOPK || T == T_S2_ALLFMA) {
+#pragma unroll
+                    for (int v = 0; v < (T == T_S2_NOPK ? 4 : 2); ++v) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[v & 7]) : "v"(f[(v + 1) & 7]), "v"(1.0f));
+                } else {
+                    asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p2[0]) : "v"(p2[1]));
+                    asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p2[2]) : "v"(p2[3]));
+                }
+                // 2 exp
+                if constexpr (T == T_S2_NOEXP || T == T_S2_ALLFMA) {
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[4]) : "v"(f[5]), "v"(1.0f));
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[6]) : "v"(f[7]), "v"(1.0f));
+                } else {
+                    asm volatile("v_exp_f32 %0, %0" : "+v"(f[4]));
+                    asm volatile("v_exp_f32 %0, %0" : "+v"(f[6]));
+                }
+                // 3 perm + 2 xor
+                if constexpr (T == T_S2_NOPERM || T == T_S2_ALLFMA) {
+#pragma unroll
+                    for (int v = 0; v < 5; ++v) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[v & 3]) : "v"(f[(v + 1) & 3]), "v"(1.0f));
+                } else {
+                    asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(n[0]) : "v"(n[1]), "v"(0x05010400));
+                    asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(n[2]) : "v"(n[3]), "v"(0x05010400));
+                    asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(n[4]) : "v"(n[5]), "v"(0x05040100));
+                    asm volatile("v_xor_b32 %0, %0, %1" : "+v"(n[6]) : "v"(0x80808080));
+                    asm volatile("v_xor_b32 %0, %0, %1" : "+v"(n[7]) : "v"(0x80808080));
+                }
+            }
         } else if constexpr (T == T_LDSR128) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
@@ -181,7 +217,8 @@ void run(long long* dout, std::vector<long long>& h) {
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool only_s2 = argc > 1 && std::string(argv[1]) == "s2";
     long long* dout;
     hipMalloc(&dout, sizeof(long long) * (1 + 256 * 3 * 4));
     std::vector<long long> h(1 + 256 * 3 * 4);
@@ -201,10 +238,14 @@ int main() {
         printf("calibration: kernel wall %.1f us, wave ticks %lld -> %.1f ticks/us; %d mfma32 per wave -> %.1f ns per MFMA\n", ms * 1000.0, h[1],
                (double)h[1] / (ms * 1000.0), ITERS * 8, ms * 1e6 / (ITERS * 8));
     }
+    if (!only_s2) {
     run<T_FMA>(dout, h); run<T_PKFMA>(dout, h); run<T_EXP>(dout, h); run<T_MAX3>(dout, h); run<T_PERM>(dout, h); run<T_CVT>(dout, h);
     run<T_ADDU>(dout, h); run<T_DOT4>(dout, h); run<T_MUL24>(dout, h);
     run<T_MFMA32_IND>(dout, h); run<T_MFMA32_DEP>(dout, h); run<T_MFMA16_IND>(dout, h); run<T_MFMA16_DEP>(dout, h);
     run<T_MIX_ATTN1>(dout, h); run<T_MIX_MFMA_FMA4>(dout, h); run<T_MIX_MFMA_FMA8>(dout, h); run<T_MIX_MFMA_EXP4>(dout, h);
     run<T_SPLIT_ROLES>(dout, h); run<T_LDSR128>(dout, h); run<T_MIX_MFMA_LDS>(dout, h);
+    }
+    run<T_S2_MIX>(dout, h); run<T_S2_NOEXP>(dout, h); run<T_S2_NOPK>(dout, h); run<T_S2_NOPERM>(dout, h); run<T_S2_ALLFMA>(dout, h);
+    run<T_S2_VALUONLY>(dout, h); run<T_S2_MIX_DEP>(dout, h);
     return 0;
 }
