@@ -322,7 +322,7 @@ __device__ __attribute__((aligned(16))) int qd_ones16[4] = {0x01010101, 0x010101
 template <int DT, bool P16, bool ASYM>
 __device__ __forceinline__ void attn_lean_body(const AttnK& p) {
     // a*b+c written as such stays unfused: hipcc's default -ffp-contract=fast lets the optimiser fuse (or not) depending on the
-    // surrounding code, and the lean / pipelined / LDS-staged bodies must produce the same normaliser bit for bit
+    // surrounding code, and the lean and the LDS-staged bodies must produce the same normaliser bit for bit
 #pragma clang fp contract(off)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frow = lane & 31, half = lane >> 5;
@@ -573,23 +573,7 @@ __device__ __forceinline__ void attn_lean_body(const AttnK& p) {
 template <int DT, bool P16, bool ASYM>
 __global__ __launch_bounds__(256, QD_ATTN_LEAN_OCC) void attn_lean_kernel(const AttnK p) { attn_lean_body<DT, P16, ASYM>(p); }
 
-// ---- pipelined variant of the lean kernel (round 3) ---------------------------------------------------------------------
-// What round 2's counters could not say and the round-3 probe did (tools/probes/ubench_issue.hip, profiles/r03_ubench_issue.txt,
-// and the ISA of the loops above): one tile of the lean kernel is a DEPENDENT chain of 4 MFMAs (128 matrix-pipe cycles), an
-// s_nop, then 44-60 VALU instructions that consume the accumulator (176-220 vector-pipe cycles), then — in sweep 2 — 4 more
-// MFMAs; a wave issues these phases strictly one after the other, and the three waves of a SIMD hide almost nothing of each
-// other's phases: the measured time per tile is the SUM of matrix and vector time (plus issue gaps), not their maximum.  The
-// same probe shows that ONE wave overlaps independent MFMAs and VALU almost perfectly when they alternate in its instruction
-// stream (4 MFMA + 16 FMA: 144 cycles against 128 for the MFMAs alone).  So this variant software-pipelines the tile loop
-// inside each wave: while the vector pipe runs the softmax of tile j on accumulator set A, the matrix pipe computes the
-// scores of tile j+1 into set B and (sweep 2) the P.V products of tile j-1 — every MFMA is issued between ~8 VALU
-// instructions of an independent chain (__builtin_amdgcn_sched_group_barrier pins that order).  Costs: a second accumulator,
-// second K / V / P operand sets (~60 VGPRs: 2 waves per SIMD instead of 3).  Arithmetic, operand order and summation order
-// are those of attn_lean_kernel: results are bit-identical (tests/test_hip_kernels.py::test_attention_pipe_equals_lean).
-// On top (P16 only, exact): when no row of the wave can produce a probability code >= 256 (emax * inv + ubias < 255.5 for all
-// lanes — the common case with thousands of keys), every hi operand byte is the constant 0x80: the hi MFMAs and their
-// v_perm / v_xor are skipped and the epilogue uses the 8-bit zero-point constants.
-constexpr int QD_ONES_ROW = 16384;                             // longest padded key axis the pipelined kernel takes (bytes of ones)
+constexpr int QD_ONES_ROW = 16384;                             // longest padded key axis the LDS-staged kernel takes (bytes of ones)
 struct OnesRow {                                               // constant-initialised: lives in the code object's data segment
     int v[QD_ONES_ROW / 4 + 4];
     constexpr OnesRow() : v() {
@@ -599,403 +583,26 @@ struct OnesRow {                                               // constant-initi
 __device__ __attribute__((aligned(16))) OnesRow qd_ones_row_obj = OnesRow();   // not `const`: a constant-address-space pointer would turn the V loads into flat loads
 #define qd_ones_row (qd_ones_row_obj.v)
 
-// Packed fp32 VALU (v_pk_fma_f32 / v_pk_add_f32) halves the instruction count of the softmax chain, but MI355X_MICROARCH.md
-// prices one v_pk_fma_f32 beside MFMAs at +22 cycles against two v_fma_f32: QD_PIPE_SCALAR=1 issues the scalar forms (inline
-// asm: the SLP vectoriser would re-pack plain C).  Same values either way.
-#ifndef QD_PIPE_SCALAR
-#define QD_PIPE_SCALAR 0
-#endif
-__device__ __forceinline__ v2f qd_pfma(v2f a, v2f b, v2f c) {
-#if QD_PIPE_SCALAR
-    float ox, oy;
-    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(ox) : "v"(a.x), "v"(b.x), "v"(c.x));
-    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(oy) : "v"(a.y), "v"(b.y), "v"(c.y));
-    return v2f{ox, oy};
-#else
-    return __builtin_elementwise_fma(a, b, c);
-#endif
-}
-__device__ __forceinline__ v2f qd_padd(v2f a, v2f b) {
-#if QD_PIPE_SCALAR
-    float ox, oy;
-    asm("v_add_f32 %0, %1, %2" : "=v"(ox) : "v"(a.x), "v"(b.x));
-    asm("v_add_f32 %0, %1, %2" : "=v"(oy) : "v"(a.y), "v"(b.y));
-    return v2f{ox, oy};
-#else
-    return a + b;
-#endif
-}
-
-// measurement-only builds (wrong results) of the pipelined kernel: QD_ABL_ATTN is a bit mask — 1: exp2 replaced by a move,
-// 2: no score MFMAs, 4: no P.V MFMAs, 8: no byte packing (v_perm / v_xor), 16: no K / V loads after the first tiles
-#ifndef QD_ABL_ATTN
-#define QD_ABL_ATTN 0
-#endif
-#define QD_PIPE_EXP2(x) ((QD_ABL_ATTN & 1) ? (x) : __builtin_amdgcn_exp2f(x))
-template <int DT, bool P16, bool ASYM>
-__global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnK p) {
-    // a*b+c written as such stays unfused: hipcc's default -ffp-contract=fast lets the optimiser fuse (or not) depending on the
-    // surrounding code, and the lean / pipelined / LDS-staged bodies must produce the same normaliser bit for bit
-#pragma clang fp contract(off)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int frow = lane & 31, half = lane >> 5;
-    const int lblk = p.xcd ? qd_xcd_remap(blockIdx.x, p.gx * p.BH) : (int)blockIdx.x;
-    const int bh = lblk / p.gx;
-    const int q0 = ((lblk - bh * p.gx) * 4 + wave) * 32;
-    if (q0 >= p.T) return;
-
-    const float cs2 = p.prm[0] * 1.4426950408889634f;
-    const int nzq = -(int)p.prm[1];
-    const float dw = p.prm[3], zpw = p.prm[4], oscale = p.prm[5];
-    const int zv = (int)p.prm[6];
-    const int izpw = (int)zpw;
-    const float urange = p.wmax - p.wmin;
-    const float ubias = zpw - p.wmin;
-    constexpr float MAGIC = 12582912.f;
-    constexpr int   MAGICI = 0x4B400000;
-    constexpr int   MASKED = -(1 << 30);
-    const float nc0 = -(MAGIC * cs2);
-    if (ASYM && nzq > 127) {                                  // zq' = -128: -zq' does not fit one int8 constant — the (rare) two-constant
-        attn_lean_body<DT, P16, ASYM>(p);                     // schedule of the unpipelined body (wave-uniform: prm is a kernel argument)
-        return;
-    }
-
-    v4i qf[DT];
-    const int8_t* qrow = p.q + ((long)bh * p.Tpad + q0 + frow) * p.dpad + half * 16;
-#pragma unroll
-    for (int kk = 0; kk < DT; ++kk) qf[kk] = *reinterpret_cast<const v4i*>(qrow + kk * 32);
-    const int8_t* kbase_u = p.k + (long)bh * p.Spad * p.dpad;     // wave-uniform base + scalar tile offset + 32-bit lane offset:
-    const unsigned klane = (unsigned)(frow * p.dpad + half * 16);  // the K loads need no per-tile vector address arithmetic
-    const int c1w = (nzq & 0xff) * 0x01010101;               // -zq' as one int8 constant
-    const v4i c1v = {c1w, c1w, c1w, c1w};
-    const int ntile = p.Spad >> 5;
-    const int nfull = (p.S & 31) ? ntile - 1 : ntile;        // full tiles; tile `nfull` (if < ntile) is the ragged one
-    const long kstride = 32L * p.dpad;
-
-    auto load_k = [&](int jt, v4i (&kf)[DT]) __attribute__((always_inline)) {
-        // scalar 32-bit tile offset (a head's K operand is < 2 GB: checked by the launcher) + lane offset: one v_add_u32 per tile,
-        // the loads use the scalar-base addressing mode.  Past the end: a harmless re-read of the last tile
-#if (defined(QD_ABL_ATTN_LOADS) && QD_ABL_ATTN_LOADS == 2) || (QD_ABL_ATTN & 16)   // measurement-only build (wrong results): no K / V loads after the first tile
-        if (jt > 1) return;
-#endif
-#if defined(QD_ABL_ATTN_LOADS) && QD_ABL_ATTN_LOADS == 1   // measurement-only build (wrong results): every load re-reads tile 0 (issue cost, no latency)
-        jt = 0;
-#endif
-        const unsigned off = (unsigned)min(jt, ntile - 1) * (unsigned)kstride + klane;
-#pragma unroll
-        for (int kk = 0; kk < DT; ++kk) kf[kk] = *reinterpret_cast<const v4i*>(kbase_u + off + kk * 32);
-    };
-    // acc[4g+e] = init + score of key jt*32 + e + 8g + 4*half (per-query constants dropped); initv is the first MFMA's C operand.
-    // qk_step(g): the g-th of the QKM MFMAs of one score tile (a dependent chain on `acc`)
-    auto qk_step = [&](int g, const v4i (&kf)[DT], const v16i& initv, v16i& acc) __attribute__((always_inline)) {
-        const int kk = ASYM ? g >> 1 : g;
-        const bool zpt = ASYM && (g & 1);
-        if (QD_ABL_ATTN & 2) {
-            if (g == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = initv[r] + (kf[0][r & 3] & 1023);
-            }
-            return;
-        }
-        if (g == 0) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[0], qf[0], initv, 0, 0, 0);
-        else acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], zpt ? c1v : qf[kk], acc, 0, 0, 0);
-    };
-    constexpr int QKM = DT * (ASYM ? 2 : 1);                  // MFMAs of one score tile
-    auto qk = [&](const v4i (&kf)[DT], const v16i& initv, v16i& acc) __attribute__((always_inline)) {
-#pragma unroll
-        for (int g = 0; g < QKM; ++g) qk_step(g, kf, initv, acc);
-    };
-    auto key_ok = [&](int jt, int r) __attribute__((always_inline)) { return jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half < p.S; };
-    auto splat16 = [&](int v) __attribute__((always_inline)) {
-        v16i o;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = v;
-        return o;
-    };
-    const v2f cs2v = {cs2, cs2}, nc0v = {nc0, nc0};
-
-    // ---- sweep 1 ----------------------------------------------------------------------------------------------------
-    int m0, mx = 0;
-    float l = 0.f;
-    {
-        v4i kfr[2][DT];
-        v16i acc[2];
-        load_k(0, kfr[0]);
-        {
-            qk(kfr[0], splat16(0), acc[0]);
-            if (nfull == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) if (!key_ok(0, r)) acc[0][r] = MASKED;
-            }
-            m0 = acc[0][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m0 = max(m0, acc[0][r]);
-        }
-        for (int pass = 0; pass < 2; ++pass) {
-            const v16i initv = splat16(MAGICI - m0);
-            int mxa = 0;
-            v2f a2 = {0.f, 0.f};
-            load_k(1, kfr[1]);
-            qk(kfr[0], initv, acc[0]);
-            // iteration jt: softmax statistics of tile jt (accumulator set C) on the vector pipe while the matrix pipe
-            // contracts tile jt+1 into set N; K fragments of tile jt+2 replace those of tile jt
-            auto s1_iter = [&](int jt, auto par_tag, auto tail_tag) __attribute__((always_inline)) {
-                constexpr int C = decltype(par_tag)::value, N = 1 - C;
-                constexpr bool tail = decltype(tail_tag)::value;
-                load_k(jt + 2, kfr[C]);
-                if (tail) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) if (!key_ok(jt, r)) acc[C][r] = 0;
-                }
-                // slice g: the g-th MFMA of tile jt+1, then 16/QKM scores of tile jt's (independent) softmax chain; the
-                // scheduling barrier pins that order — left alone, hipcc regroups the MFMAs into one dependent burst
-                constexpr int RPS = 16 / QKM;
-#pragma unroll
-                for (int g = 0; g < QKM; ++g) {
-                    qk_step(g, kfr[N], initv, acc[N]);
-#pragma unroll
-                    for (int r = g * RPS; r < (g + 1) * RPS; r += 2) {
-                        mxa = max(max(mxa, acc[C][r]), acc[C][r + 1]);
-                        const v2f F = {__int_as_float(acc[C][r]), __int_as_float(acc[C][r + 1])};
-                        const v2f x = qd_pfma(F, cs2v, nc0v);
-                        v2f e = {QD_PIPE_EXP2(x.x), QD_PIPE_EXP2(x.y)};
-                        if (tail) {
-                            if (acc[C][r] == 0) e.x = 0.f;
-                            if (acc[C][r + 1] == 0) e.y = 0.f;
-                        }
-                        a2 = qd_padd(a2, e);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            };
-            int jt = 0;
-            for (; jt + 2 <= nfull; jt += 2) {
-                s1_iter(jt, std::integral_constant<int, 0>{}, std::false_type{});
-                s1_iter(jt + 1, std::integral_constant<int, 1>{}, std::false_type{});
-            }
-            if (jt < nfull) {
-                s1_iter(jt, std::integral_constant<int, 0>{}, std::false_type{});
-                ++jt;
-                if (jt < ntile) s1_iter(jt, std::integral_constant<int, 1>{}, std::true_type{});
-            } else if (jt < ntile) {
-                s1_iter(jt, std::integral_constant<int, 0>{}, std::true_type{});
-            }
-            l = a2.x + a2.y;
-            mx = mxa ? mxa - MAGICI : 0;
-            if (!__any((float)mx * cs2 > 64.f)) break;
-            m0 += mx;                                             // (rare) start again against the true maximum
-            load_k(0, kfr[0]);
-        }
-    }
-    int mi = m0 + mx;
-    l *= __builtin_amdgcn_exp2f(-(float)mx * cs2);
-    {
-        const int mo = __shfl_xor(mi, 32);
-        const float lo = __shfl_xor(l, 32);
-        const int mf = max(mi, mo);
-        l = l * __builtin_amdgcn_exp2f((float)(mi - mf) * cs2) + lo * __builtin_amdgcn_exp2f((float)(mo - mf) * cs2);
-        mi = mf;
-    }
-    const float inv = 1.0f / (l * dw);
-    const float emax = __builtin_amdgcn_exp2f(__builtin_fmaf(MAGIC, cs2, nc0));
-
-    // ---- sweep 2 ----------------------------------------------------------------------------------------------------
-    v16i ol[DT], oh[P16 ? DT : 1];
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            ol[t][r] = 0;
-            if (P16) oh[P16 ? t : 0][r] = 0;
-        }
-    const int t1 = p.d >> 5, frow1 = p.d & 31;                     // where the row of ones sits
-    // the lane that would read the padding row `d` of V^T reads a row of ones instead (a constant buffer as long as a V^T row, so
-    // that every lane advances by the same scalar tile offset: one 64-bit add per fragment, no per-lane stride)
-    const int8_t* vp[DT];
-#pragma unroll
-    for (int t = 0; t < DT; ++t) {
-        const bool ones = (t == t1) && (frow == frow1);
-        vp[t] = ones ? reinterpret_cast<const int8_t*>(qd_ones_row) + half * 16 : p.vt + ((long)bh * p.dpad + t * 32 + frow) * p.Spad + half * 16;
-    }
-    // wave-uniform: can any code of this wave's rows reach 256?  (P16 only; see the header comment)
-    const bool need_clamp = __any(!(emax * inv * 1.0001f + ubias + 0.5f <= urange)) || (((int)ubias) & 1);
-    const bool hi_live = P16 && (need_clamp || __any(!(emax * inv * 1.0001f + ubias + 0.5f < 256.f)));
-    {
-        v4i kfr[2][DT], vfr[2][DT];
-        v16i acc[2];
-        v4i plo[2], phi[2];
-        plo[1] = v4i{0, 0, 0, 0};                                  // "tile -1": operand bytes 0 contribute nothing
-        phi[1] = v4i{0, 0, 0, 0};
-        const v16i initv = splat16(MAGICI - mi);
-        const v2f invv = {inv, inv}, ubv = {ubias, ubias}, magic = {MAGIC, MAGIC}, ubm = {ubias + MAGIC, ubias + MAGIC};
-        auto load_v = [&](int jt, v4i (&vf)[DT]) __attribute__((always_inline)) {
-#if (defined(QD_ABL_ATTN_LOADS) && QD_ABL_ATTN_LOADS == 2) || (QD_ABL_ATTN & 16)
-            if (jt > 1) return;
-#endif
-#if defined(QD_ABL_ATTN_LOADS) && QD_ABL_ATTN_LOADS == 1
-            jt = 0;
-#endif
-            const long off = (long)min(jt, ntile - 1) * 32;            // scalar
-#pragma unroll
-            for (int t = 0; t < DT; ++t) vf[t] = *reinterpret_cast<const v4i*>(vp[t] + off);
-        };
-        load_k(0, kfr[0]);
-        load_k(1, kfr[1]);
-        load_v(0, vfr[0]);
-#pragma unroll
-        for (int t = 0; t < DT; ++t) vfr[1][t] = v4i{0, 0, 0, 0};
-        qk(kfr[0], initv, acc[0]);
-        // iteration jt: P.V of tile jt-1 (operand set N) and the scores of tile jt+1 (accumulator set N) on the matrix pipe,
-        // the quantisation of tile jt's probabilities (accumulator set C -> operand set C) on the vector pipe
-        auto s2_iter = [&](int jt, auto par_tag, auto tail_tag, auto clamp_tag, auto hi_tag) __attribute__((always_inline)) {
-            constexpr int C = decltype(par_tag)::value, N = 1 - C;
-            constexpr bool tail = decltype(tail_tag)::value, CLAMP = decltype(clamp_tag)::value, HI = decltype(hi_tag)::value;
-            constexpr int NPV = DT * (HI ? 2 : 1), NM = NPV + QKM;   // MFMAs of this iteration: P.V of tile jt-1, scores of tile jt+1
-            load_k(jt + 2, kfr[C]);
-            unsigned ub[16];
-            // slice m: one MFMA, then the next 8/NM score pairs of tile jt's probability chain (+ the byte packing of every
-            // completed group of four scores); pinned by scheduling barriers as in sweep 1
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                if (m < NPV) {
-                    const int t = HI ? m >> 1 : m;
-                    if (QD_ABL_ATTN & 4) {
-                        if (HI && (m & 1)) oh[P16 ? t : 0][0] += phi[N][0] ^ vfr[N][t][1];
-                        else ol[t][0] += plo[N][0] ^ vfr[N][t][0] ^ plo[N][3];
-                    } else
-                    if (HI && (m & 1)) oh[P16 ? t : 0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(phi[N], vfr[N][t], oh[P16 ? t : 0], 0, 0, 0);
-                    else ol[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(plo[N], vfr[N][t], ol[t], 0, 0, 0);
-                    if (m == NPV - 1) load_v(jt + 1, vfr[N]);          // the operand set of tile jt-1 is free from here on
-                } else {
-                    qk_step(m - NPV, kfr[N], initv, acc[N]);
-                }
-#pragma unroll
-                for (int sidx = (8 * m) / NM; sidx < (8 * (m + 1)) / NM; ++sidx) {
-                    const int r = 2 * sidx;
-                    const v2f F = {__int_as_float(acc[C][r]), __int_as_float(acc[C][r + 1])};
-                    const v2f x = qd_pfma(F, cs2v, nc0v);
-                    const v2f e = {QD_PIPE_EXP2(x.x), QD_PIPE_EXP2(x.y)};
-                    v2f t;
-                    if (CLAMP) {
-                        t = qd_pfma(e, invv, ubv);
-                        t.x = fminf(t.x, urange);
-                        t.y = fminf(t.y, urange);
-                        t = qd_padd(t, magic);
-                    } else {
-                        t = qd_pfma(e, invv, ubm);
-                    }
-                    ub[r] = __float_as_uint(t.x);
-                    ub[r + 1] = __float_as_uint(t.y);
-                    if (tail) {
-                        if (!key_ok(jt, r)) ub[r] = 0x8080u;
-                        if (!key_ok(jt, r + 1)) ub[r + 1] = 0x8080u;
-                    }
-                    if (sidx & 1) {
-                        const int g = sidx >> 1;
-                        if (QD_ABL_ATTN & 8) {
-                            plo[C][g] = (int)(ub[4 * g] + ub[4 * g + 1] + ub[4 * g + 2] + ub[4 * g + 3]);
-                            if (HI) phi[C][g] = plo[C][g];
-                            continue;
-                        }
-                        const unsigned a01 = __builtin_amdgcn_perm(ub[4 * g + 1], ub[4 * g], 0x05010400u);
-                        const unsigned a23 = __builtin_amdgcn_perm(ub[4 * g + 3], ub[4 * g + 2], 0x05010400u);
-                        plo[C][g] = (int)(__builtin_amdgcn_perm(a23, a01, 0x05040100u) ^ 0x80808080u);
-                        if (HI) phi[C][g] = (int)(__builtin_amdgcn_perm(a23, a01, 0x07060302u) ^ 0x80808080u);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        auto run = [&](auto clamp_tag, auto hi_tag) __attribute__((always_inline)) {
-            int jt = 0;
-            for (; jt + 2 <= nfull; jt += 2) {
-                s2_iter(jt, std::integral_constant<int, 0>{}, std::false_type{}, clamp_tag, hi_tag);
-                s2_iter(jt + 1, std::integral_constant<int, 1>{}, std::false_type{}, clamp_tag, hi_tag);
-            }
-            int last = 1;                                             // operand set of the last tile processed
-            if (jt < nfull) {
-                s2_iter(jt, std::integral_constant<int, 0>{}, std::false_type{}, clamp_tag, hi_tag);
-                ++jt;
-                last = 0;
-                if (jt < ntile) { s2_iter(jt, std::integral_constant<int, 1>{}, std::true_type{}, std::true_type{}, hi_tag); last = 1; }
-            } else if (jt < ntile) {
-                s2_iter(jt, std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{}, hi_tag);
-                last = 0;
-            }
-            // drain: P.V of the last tile
-            constexpr bool HI = decltype(hi_tag)::value;
-#pragma unroll
-            for (int t = 0; t < DT; ++t) {
-                if (last == 0) {
-                    ol[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(plo[0], vfr[0][t], ol[t], 0, 0, 0);
-                    if (HI) oh[P16 ? t : 0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(phi[0], vfr[0][t], oh[P16 ? t : 0], 0, 0, 0);
-                } else {
-                    ol[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(plo[1], vfr[1][t], ol[t], 0, 0, 0);
-                    if (HI) oh[P16 ? t : 0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(phi[1], vfr[1][t], oh[P16 ? t : 0], 0, 0, 0);
-                }
-            }
-        };
-        if (need_clamp) run(std::true_type{}, std::integral_constant<bool, P16>{});
-        else if (hi_live) run(std::false_type{}, std::true_type{});
-        else run(std::false_type{}, std::false_type{});
-    }
-
-    // ---- epilogue (attn_lean_kernel's, with the 8-bit constants when the hi bytes were provably all zero) --------------
-    const int b = bh / p.H, hh = bh % p.H;
-    const QP oqp = p.out8 ? qd_load_qp(p.oq) : QP{1.f, 0.f, 1.f, false};
-    const long kconst = (hi_live ? 256L * 128L : 0L) + 128L + (long)p.iwmin - (long)izpw;
-    int us[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int sl = 0, sh = 0;
-#pragma unroll
-        for (int t = 0; t < DT; ++t)
-            if (t == t1) {
-                sl = ol[t][r];
-                if (P16) sh = oh[P16 ? t : 0][r];
-            }
-        sl = __shfl(sl, frow1 + 32 * half);
-        if (P16) sh = __shfl(sh, frow1 + 32 * half);
-        us[r] = sl + 128 * p.S + (hi_live ? 256 * (sh + 128 * p.S) : 0) + p.S * p.iwmin;
-    }
-    auto epi = [&](auto ft) __attribute__((always_inline)) {
-    constexpr bool FAST = decltype(ft)::value;
-#pragma unroll
-    for (int t = 0; t < DT; ++t) {
-        const int dd = t * 32 + frow;
-        const long vs = (dd < p.d) ? p.vsum[(long)bh * p.dpad + dd] : 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int il = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int i = q0 + il;
-            if (dd >= p.d || i >= p.T) continue;
-            long I = (long)ol[t][r] + kconst * vs - (long)zv * us[r] + (long)p.S * izpw * zv;
-            if (hi_live) I += 256L * (long)oh[P16 ? t : 0][r];
-            const float o = (float)I * oscale;
-            if (p.out8) p.out8[((long)b * p.T + i) * p.ldo8 + hh * p.d + dd] = (int8_t)(qd_code_t<FAST>(o, oqp, p.oqmin, p.oqmax) - p.oqoff);
-            else p.out[((long)b * p.T + i) * p.ldo + hh * p.d + dd] = o;
-        }
-    }
-    };
-    QD_FAST_DISPATCH(oqp.fast, epi);
-}
-
-// ---- LDS-staged variant (round 3, after the ablations of profiles/r03_attn_ablation.md) --------------------------------------
-// What the ablations of the pipelined kernel showed (T = S = 4096, d = 40, 128 heads; 1200 us per call):
-//   * the softmax / packing VALU work alone is 175 us — the vector pipe was never the limit;
-//   * the K / V fragment loads alone are ~580 us: every wave loads every K / V^T tile itself (6 KB per tile pair, 12.9 GB per
-//     call), and a CU's vector-memory return path delivers ~46 B/clk — re-reading tile 0 for every tile (all L1 hits) costs
-//     the same as the real stream, i.e. it is the L1 data path, not latency and not L2 (97.6 % hits after the XCD remap);
-//   * the 12 MFMAs of a tile pair cost twice their pipe time as soon as vector instructions sit between the links of the
-//     DEPENDENT score chain (k0.q0 -> k0.c -> k1.q1 -> k1.c on one accumulator): a dependent MFMA that does not follow its
-//     producer back to back waits for the full write-back (MI355X_MICROARCH.md "one extra issue slot ... +43 cycles").
-// Hence: (1) the 4 waves of a block share each K / V^T tile through LDS — one 16-byte-per-lane DMA instruction per wave per
-// tile into a 4-stage ring (global_load_lds_dwordx4, no VGPR round trip), one barrier per tile; fragments come from LDS by
-// conflict-free ds_read_b128 (XOR swizzle applied to the DMA's SOURCE chunk, as in igemm_dma.hip); the L1 traffic drops 4x;
-// (2) the score chain of tile j+1 is issued back to back (accumulator forwarding: 32 cycles per link) at the END of
-// iteration j, the four INDEPENDENT P.V MFMAs of tile j-1 are spread between the softmax VALU of tile j; two blocks per CU
-// give every SIMD a second wave for the time a wave spends inside its own chain.  Arithmetic, operand order and summation
-// order are those of attn_lean_kernel: bit-identical results.
+// ---- LDS-staged variant (round 3; measurements: profiles/r03_attn_ablation.md) ---------------------------------------------
+// The 4 waves of a block share each K / V^T tile through LDS instead of loading every fragment themselves: one 16-byte-per-
+// lane DMA instruction per wave per tile into a 4-stage ring (global_load_lds_dwordx4, no VGPR round trip), one barrier per
+// tile; fragments come from LDS by conflict-free ds_read_b128 (XOR swizzle applied to the DMA's SOURCE chunk, as in
+// igemm_dma.hip).  The vector-memory return path of a CU (~46 B/clk measured: re-reading tile 0 for every tile costs the same
+// as the real stream) carries a quarter of the bytes.  The tile loop is software-pipelined one tile deep: the P.V MFMAs of
+// tile j-1 (independent accumulators) sit between the probability VALU of tile j, the score chain of tile j+1 follows back
+// to back.  On top (P16 only, exact): when no row of the wave can produce a probability code >= 256 (emax * inv + ubias <
+// 255.5 for all lanes — the common case with thousands of keys and unpeaked rows), every hi operand byte is the constant
+// 0x80: the hi MFMAs and their v_perm / v_xor are skipped and the epilogue uses the 8-bit zero-point constants.
+// Arithmetic, operand order and summation order are those of attn_lean_kernel: bit-identical results
+// (tests/test_hip_kernels.py::test_attention_lds_equals_lean).
+// What it buys, honestly: 64x64 self-attention of SD (T = S = 4096, d = 40, 128 heads) 1170 -> 1047 us on unpeaked rows
+// (-10 %, most of it the skipped hi MFMAs), 1180 -> 1143 us on peaked rows; short key axes (77-token cross-attention) are
+// SLOWER (ring start-up, barriers) and stay on attn_lean_kernel.  What did NOT help, all measured on the same shape: a
+// register-fed pipeline with every MFMA spread between VALU slices at 2 waves per SIMD (1200 us), the same spreading in
+// this kernel at 3 waves per SIMD with the hi part computed in a second sweep (1020 us unpeaked, 1650 us peaked), a one-sweep
+// formulation (needs the 16 x 4096 scores of a block in registers and 7 bytes of K / V per score from L1: > 64 B/clk per CU).
+// Counters of every variant say the same thing: the matrix pipe is busy ~32 % and the vector pipe ~27 % of a SIMD's cycles and
+// the two barely overlap — the kernel is bound by in-order instruction issue of the ~135 non-MFMA instructions per tile pair.
 __device__ __forceinline__ void attn_glds16(const void* gsrc, unsigned lds_base) {
     asm volatile(
         "s_mov_b32 m0, %1\n\t"
@@ -1012,7 +619,7 @@ __device__ __forceinline__ void attn_wait_lgkm0() { asm volatile("s_waitcnt lgkm
 template <int DT, bool P16, bool ASYM>
 __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
     // a*b+c written as such stays unfused: hipcc's default -ffp-contract=fast lets the optimiser fuse (or not) depending on the
-    // surrounding code, and the lean / pipelined / LDS-staged bodies must produce the same normaliser bit for bit
+    // surrounding code, and the lean and the LDS-staged bodies must produce the same normaliser bit for bit
 #pragma clang fp contract(off)
     constexpr int NST = 4;                                    // ring stages (tiles): jt+1 in use, jt+2 landed / landing, jt+3 issued
     constexpr int KB = 1024 * DT, VB = 1024 * DT;             // K tile: 32 keys x dpad bytes; V^T tile: dpad rows x 32 keys
@@ -1394,16 +1001,6 @@ int launch_lds(const AttnK& k, bool p16, bool asym, hipStream_t st) {
 }
 
 template <int DT>
-int launch_pipe(const AttnK& k, bool p16, bool asym, hipStream_t st) {
-    dim3 grid((unsigned)(k.gx * k.BH));
-    if (p16 && asym) hipLaunchKernelGGL((attn_pipe_kernel<DT, true, true>), grid, dim3(256), 0, st, k);
-    else if (p16) hipLaunchKernelGGL((attn_pipe_kernel<DT, true, false>), grid, dim3(256), 0, st, k);
-    else if (asym) hipLaunchKernelGGL((attn_pipe_kernel<DT, false, true>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((attn_pipe_kernel<DT, false, false>), grid, dim3(256), 0, st, k);
-    return 0;
-}
-
-template <int DT>
 int launch_lean(const AttnK& k, bool p16, bool asym, hipStream_t st) {
     dim3 grid((unsigned)(k.gx * k.BH));
     if (p16 && asym) hipLaunchKernelGGL((attn_lean_kernel<DT, true, true>), grid, dim3(256), 0, st, k);
@@ -1448,17 +1045,15 @@ extern "C" int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt, co
     const bool p16 = wbits == 16;
     // lean variant: needs a padding row of V^T (d not a multiple of 32) and |score differences| < 2^22 (d < 64)
     static const bool lean_ok = !(getenv("QD_ATTN_LEAN") && atoi(getenv("QD_ATTN_LEAN")) == 0);
-    // pipelined lean kernel (default since round 3; QD_ATTN_PIPE=0 selects the unpipelined one: A/B and the equality test)
-    const char* pipe_env = getenv("QD_ATTN_PIPE");                       // read per call: tests flip it inside one process
-    const int pipe_mode = pipe_env ? atoi(pipe_env) : 2;                 // 2: LDS-staged (default), 1: register-pipelined, 0: plain lean
-    const bool pipe_ok = pipe_mode != 0;
+    // QD_ATTN_PIPE (read per call: tests flip it inside one process): 2 = LDS-staged kernel wherever it pays (default),
+    // 0 = attn_lean_kernel everywhere (A/B runs and the equality test), 3 = LDS-staged kernel on every eligible shape
+    const char* pipe_env = getenv("QD_ATTN_PIPE");
+    const int pipe_mode = pipe_env ? atoi(pipe_env) : 2;
     if (lean_ok && d < 64 && (d & 31) != 0) {
-        if (pipe_mode == 2 && Spad <= QD_ONES_ROW && (long)Spad * dpad < (1L << 31)) {
+        const bool lds_fits = Spad <= QD_ONES_ROW && (long)Spad * dpad < (1L << 31);
+        if (lds_fits && (pipe_mode == 3 || (pipe_mode == 2 && S >= 512))) {       // short key axes: ring start-up and barriers lose
             if (dpad == 32) launch_lds<1>(a, p16, asym, st);
             else launch_lds<2>(a, p16, asym, st);
-        } else if (pipe_ok && Spad <= QD_ONES_ROW && (long)Spad * dpad < (1L << 31)) {
-            if (dpad == 32) launch_pipe<1>(a, p16, asym, st);
-            else launch_pipe<2>(a, p16, asym, st);
         } else if (dpad == 32) launch_lean<1>(a, p16, asym, st);
         else launch_lean<2>(a, p16, asym, st);
         QD_LAUNCH_CHECK("qd_attn_i8");

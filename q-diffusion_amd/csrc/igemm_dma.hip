@@ -473,10 +473,12 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
 #else
                 acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks][i], bf, acc[i][j], 0, 0, 0);
 #endif
+#ifndef QD_ABL_NOASUM        // measurement-only build (wrong results): the K-step without its activation row sums (4 v_dot4 per A fragment)
             if (j == 0) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) asum[i] += bytesum16(af[ks][i]);
             }
+#endif
 #ifndef QD_DMA_FRONT
             if (s < PER) issue_one(nxt, s);
 #else                      // A/B knob: all DMAs of the step right behind the first MFMA group
