@@ -287,6 +287,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-denominators", action="store_true", help="skip the fp32 / fake-quant GPU denominators")
     ap.add_argument("--decode", action="store_true", help="also time the first-stage decode of the image batch (sd / ldm / churches; extra field)")
+    ap.add_argument("--stream", default=None, choices=["fp32", "fp16"],
+                    help="storage type of the inter-kernel activations (default: QDIFF_STREAM or fp32); fp16 = the precision the "
+                         "reference scripts run at (--precision autocast); compute stays int8 MFMA / fp32 epilogues")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only (gloo, no GPU): prove that `python bench.py --gpus N` becomes N ranks; used by tests")
     a = ap.parse_args()
@@ -327,8 +330,11 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
-    from qdiff import hip, sampling
+    from qdiff import engine, hip, sampling
     hip.load()
+    if a.stream:
+        engine.set_stream_dtype(torch.float16 if a.stream == "fp16" else torch.float32)
+    stream_name = "fp16" if engine.STREAM_DTYPE == torch.float16 else "fp32"
 
     kind, n = a.model, a.images_per_gpu
     # rank 0 owns the calibrated model (synthetic here: data-dependent init + AdaRound conversion); every other rank
@@ -410,7 +416,7 @@ def main():
         "metric": "denoising images/sec (whole node), SD-v1.4 W4A8 512x512 50-step PLMS" if kind == "sd" else f"denoising images/sec ({kind})",
         "value": round(images_per_s, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "int8xint4->int32 (fp32 residual stream)", "data": "synthetic",
+        "dtype": f"int8xint4->int32 ({stream_name} residual stream)", "data": "synthetic",
         "config": {"workload": f"{kind} UNet eval batch {2 * n if guide != 1.0 else n} per GPU, {evals} evals per image batch, "
                                f"W{qspec['w_bits']}A8 sm_abit={qspec['sm_abit']}{'' if kind == 'churches' else ' split'}, hip-graph={'off' if a.no_graph else 'on'}",
                    "images_per_gpu": n, "global_batch": gb, "single_unet_step_ms": round(ms_per_step, 4),

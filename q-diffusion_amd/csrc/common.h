@@ -46,6 +46,21 @@ template <typename T> __device__ __forceinline__ float qd_ld(const T* p);
 template <> __device__ __forceinline__ float qd_ld<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float qd_ld<__half>(const __half* p) { return __half2float(*p); }
 
+// four halves <-> four floats through one 8-byte access (fp16 activation streams)
+__device__ __forceinline__ v4f qd_ld4h(const __half* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    const __half2 a = *reinterpret_cast<const __half2*>(&u.x), b = *reinterpret_cast<const __half2*>(&u.y);
+    const float2 fa = __half22float2(a), fb = __half22float2(b);
+    return v4f{fa.x, fa.y, fb.x, fb.y};
+}
+__device__ __forceinline__ void qd_st4h(__half* p, const v4f& v) {
+    const __half2 a = __floats2half2_rn(v[0], v[1]), b = __floats2half2_rn(v[2], v[3]);
+    uint2 u;
+    u.x = *reinterpret_cast<const unsigned*>(&a);
+    u.y = *reinterpret_cast<const unsigned*>(&b);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+
 // 4 consecutive elements; `vec` = the caller proved 4-element alignment (one 16-/8-byte load)
 template <typename T>
 __device__ __forceinline__ void qd_ld4(const T* p, bool vec, float (&v)[4]) {

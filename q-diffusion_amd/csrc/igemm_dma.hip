@@ -75,6 +75,7 @@ struct ConvD {
     int    gn_nchunk;         //   i.e. the first level of GroupNorm's statistics (layout of gn_partial_kernel); S/128
     long   gn_ld;             //   channels per chunk row of gnpart (>= Cout: column range of a wider statistics buffer)
     int    pointwise;         // 1x1 convolution / linear layer without padding or stride: output row m is input pixel m
+    int    res_f16;           // O_HROWS: the fp residual is fp16 (else fp32)
     int    ups;               // x is the HALF-resolution map [B][H/2][W/2][ldx]; the convolution runs on its nearest-2x up-sampling
 };
 
@@ -581,6 +582,8 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
         const int bidx = m0 / p.hdT, t0 = m0 - bidx * p.hdT;
         const bool hres = p.residual != nullptr;
         const float* rf = reinterpret_cast<const float*>(p.residual);
+        const __half* rh16 = reinterpret_cast<const __half*>(p.residual);
+        const bool res16 = p.res_f16 != 0;             // the residual stream is fp16 (8-byte loads of four halves)
         auto epi = [&](auto ft) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(ft)::value;
 #pragma unroll
@@ -606,8 +609,11 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
                 v4f rs[4];
                 if (hres) {
 #pragma unroll
-                    for (int ps = 0; ps < 4; ++ps)
-                        rs[ps] = *reinterpret_cast<const v4f*>(rf + (long)(m0 + rbase + ps * 8 + rr0) * p.ldr + nn);
+                    for (int ps = 0; ps < 4; ++ps) {
+                        const long ro = (long)(m0 + rbase + ps * 8 + rr0) * p.ldr + nn;
+                        if (res16) rs[ps] = qd_ld4h(rh16 + ro);
+                        else rs[ps] = *reinterpret_cast<const v4f*>(rf + ro);
+                    }
                 }
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
@@ -698,7 +704,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
     // optional GroupNorm statistics of the tensor being written (consumed by qd_groupnorm_silu_quant instead of its own
     // pass over HBM): per-column partials of the lane's rows -> butterfly over the 8 lanes that share the columns ->
     // fixed-order LDS reduction over the waves of each 128-row chunk -> one {sum, sumsq} pair per (chunk, channel).
-    const bool gn = OUT == O_F32 && p.gnpart != nullptr;
+    const bool gn = (OUT == O_F32 || OUT == O_F16) && p.gnpart != nullptr;   // statistics of the fp32 values (before an fp16 store)
     float* sGn = reinterpret_cast<float*>(smem + 4 * 4096);       // [4 waves][WCOLS][2], behind the transposition tiles
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -770,8 +776,11 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
                             }
                         } else {
                             const __half* src = rh + mrow[ps] * p.ldr + n4c;
+                            if (vec && nok4) rs[ps] = qd_ld4h(src);
+                            else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) rs[ps][e] = n4 + e < p.Cout ? __half2float(src[e]) : 0.f;
+                                for (int e = 0; e < 4; ++e) rs[ps][e] = n4 + e < p.Cout ? __half2float(src[e]) : 0.f;
+                            }
                         }
                     }
                 }
@@ -792,8 +801,11 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
                             }
                         } else {
                             __half* dst = oh + mrow[ps] * p.ldo + n4;
+                            if (vec && nok4) qd_st4h(dst, v);
+                            else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) if (n4 + e < p.Cout) dst[e] = __float2half(v[e]);
+                                for (int e = 0; e < 4; ++e) if (n4 + e < p.Cout) dst[e] = __float2half(v[e]);
+                            }
                         }
                         if (gn) {
 #pragma unroll
@@ -986,7 +998,7 @@ int dispatch(ConvD& k, bool split, int out, hipStream_t st, int nsplit = 1) {
         return 0;                                                                                   \
     }
     QD_CASE(false, O_F32)
-    if constexpr (WM == 4) { QD_CASE(false, O_F16) }
+    QD_CASE(false, O_F16)
     if constexpr (MT == 1 && WM == 4) { QD_CASE(false, O_I32) QD_CASE(true, O_F32) QD_CASE(true, O_F16) QD_CASE(false, O_PART) }
     if constexpr (WB == 4 && WM == 4) { QD_CASE(false, O_HROWS) QD_CASE(false, O_HTR) }
     if constexpr (NT == 4 && WB == 4 && WM == 4) { QD_CASE(false, O_GEGLU) }
@@ -1061,9 +1073,10 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
                                             : (iout ? O_I32 : (d->out_dtype == QD_F16 ? O_F16 : O_F32));
     // 16-byte row-major accesses in the epilogue: every base and row stride a multiple of 4 elements
     const size_t esz = d->out_dtype == QD_F16 ? 2 : 4;
+    // (fp16 streams: four halves = 8 bytes per access; the row bias is always fp32)
     k.vec = d->Cout % 4 == 0 && (iout ? qd_aligned(iout, 16)
-                                      : (d->ldo % 4 == 0 && qd_aligned(d->out, 4 * esz) && d->out_dtype == QD_F32 &&
-                                         (!d->residual || (d->ldr % 4 == 0 && qd_aligned(d->residual, 16))) &&
+                                      : (d->ldo % 4 == 0 && qd_aligned(d->out, 4 * esz) &&
+                                         (!d->residual || (d->ldr % 4 == 0 && qd_aligned(d->residual, 4 * esz))) &&
                                          (!d->rowbias || (d->ld_rowbias % 4 == 0 && qd_aligned(d->rowbias, 16)))));
     if (heads) {
         QD_REQUIRE(!iout && d->nseg == 1 && d->oq_params && d->out, "qd_conv2d_i8: heads epilogue needs one segment, oq_params and out");
@@ -1073,8 +1086,9 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
         QD_REQUIRE(d->hd_T > 0 && d->hd_T % 128 == 0 && k.M % d->hd_T == 0, "qd_conv2d_i8: heads epilogue: tokens per sample (%d) must be a multiple of 128 dividing M", d->hd_T);
         QD_REQUIRE(d->hd_Tpad % 32 == 0 && d->hd_Tpad >= d->hd_T && d->hd_dpad >= d->hd_d, "qd_conv2d_i8: heads epilogue: bad padded dims");
         QD_REQUIRE(qd_aligned(d->out, 16) && (d->epilogue != QD_EPI_HEADS_T_I8 || d->hd_sum), "qd_conv2d_i8: heads epilogue: out unaligned or hd_sum missing");
-        QD_REQUIRE(!d->rowbias && (!d->residual || (d->epilogue == QD_EPI_HEADS_I8 && d->out_dtype == QD_F32 && d->ldr % 4 == 0 && qd_aligned(d->residual, 16))),
-                   "qd_conv2d_i8: heads epilogue takes no rowbias; an fp32 residual (16-byte aligned rows) only with QD_EPI_HEADS_I8");
+        QD_REQUIRE(!d->rowbias && (!d->residual || (d->epilogue == QD_EPI_HEADS_I8 && d->ldr % 4 == 0 && qd_aligned(d->residual, 4 * esz))),
+                   "qd_conv2d_i8: heads epilogue takes no rowbias; a residual (fp32 or fp16 as out_dtype says, 4-element aligned rows) only with QD_EPI_HEADS_I8");
+        k.res_f16 = d->out_dtype == QD_F16 ? 1 : 0;
         k.oq = d->oq_params; k.oqmin = (float)d->oq_min; k.oqmax = (float)d->oq_max; k.oqoff = d->oq_off;
         k.hdH = d->hd_H; k.hdd = d->hd_d; k.hdT = d->hd_T; k.hdTpad = d->hd_Tpad; k.hddpad = d->hd_dpad;
         k.oqpre = d->oq_prescale; k.hdsum = d->hd_sum;
@@ -1082,7 +1096,7 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
         k.hdrcp = (unsigned)((0x100000000ULL + (unsigned)d->hd_d - 1) / (unsigned)d->hd_d);
     }
     if (d->gn_part) {
-        QD_REQUIRE(!iout && !heads && !geglu && d->out_dtype == QD_F32, "qd_conv2d_i8: gn_part needs the plain fp32 epilogue");
+        QD_REQUIRE(!iout && !heads && !geglu, "qd_conv2d_i8: gn_part needs the plain fp32 / fp16 epilogue");
         QD_REQUIRE((d->Ho * d->Wo) % 128 == 0, "qd_conv2d_i8: gn_part needs Ho*Wo %% 128 == 0 (a 128-row chunk stays inside one sample)");
         k.gnpart = d->gn_part;
         k.gn_nchunk = d->Ho * d->Wo / 128;
@@ -1155,7 +1169,7 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
     } else if (geglu) {
         if (force_gmt == 2) rc = dispatch<2, 4, 4, 1>(k, split, out, st);
         else rc = dispatch<1, 4, 4, 1>(k, split, out, st);
-    } else if (wide_tile && N % 320 == 0 && out == O_F32 && !split && Ktot >= wide_mink && blocks(128, 320) >= wide_minblk &&
+    } else if (wide_tile && N % 320 == 0 && (out == O_F32 || out == O_F16) && !split && Ktot >= wide_mink && blocks(128, 320) >= wide_minblk &&
                (wide_tile >= 2 || blocks(256, 160) < 2 * 256)) {
         // 2 x 2 waves of 64 x 160: a 128 x 320 block moves 18 KB per K-step into LDS for 40960 MACs per K element where the
         // 256 x 160 block of 4 x 1 waves moves 21 KB — the long-K convolutions are bound by exactly that L2 -> LDS traffic

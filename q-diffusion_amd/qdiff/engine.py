@@ -9,6 +9,8 @@ Integer conventions: DESIGN.md §3 (stored byte a' = code - off, "true zero" z' 
 """
 import math
 
+import os
+
 import torch
 
 from . import hip
@@ -271,6 +273,20 @@ def conv_out_hw(H, W, plan, pad_br=None):
     return Ho, Wo
 
 
+# Storage type of the activations BETWEEN kernels (the residual stream: convolution / projection outputs, skip buffers).
+# fp32 is the parity-first default (the reference's arithmetic); fp16 is the reference scripts' own default precision
+# (`--precision autocast`, scripts/txt2img.py:231-236) and halves the traffic of the HBM-bound launches.  Every kernel computes
+# in fp32 / exact integers either way; only the stored tensor changes.  QDIFF_STREAM=fp16, or engine.set_stream_dtype().
+STREAM_DTYPE = torch.float16 if os.environ.get("QDIFF_STREAM", "fp32").lower() in ("fp16", "half", "float16") else torch.float32
+
+
+def set_stream_dtype(dtype):
+    global STREAM_DTYPE
+    if dtype not in (torch.float32, torch.float16):
+        raise ValueError("activation stream dtype must be torch.float32 or torch.float16")
+    STREAM_DTYPE = dtype
+
+
 class CatSlot:
     """Planned destination of one skip concatenation `th.cat([h, hs.pop()], dim=1)` (openaimodel.py:776, ddim
     diffusion.py:340): the kernel that produces the decoder-side `h` (side 0) and the kernel that produced the encoder-side
@@ -291,8 +307,8 @@ class CatSlot:
         if C != self.c[i]:
             return None
         if self.buf is None:
-            self.buf = torch.empty((M, self.c[0] + self.c[1]), dtype=torch.float32, device=device)
-        if self.buf.shape[0] != M or self.buf.device != device:
+            self.buf = torch.empty((M, self.c[0] + self.c[1]), dtype=STREAM_DTYPE, device=device)
+        if self.buf.shape[0] != M or self.buf.device != device or self.buf.dtype != STREAM_DTYPE:
             return None
         c0 = 0 if i == 0 else self.c[0]
         return self.buf[:, c0:c0 + C]
@@ -328,7 +344,7 @@ def upsample_fold_ok(plan, H, W):
 
 
 def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, residual=None, acc_out=None,
-                 out_dtype=torch.float32, pad_tl=None, splitk=None, gn_stats=False, slot=None, upsample2x=False):
+                 out_dtype=None, pad_tl=None, splitk=None, gn_stats=False, slot=None, upsample2x=False):
     """Run K3/K4 on quantised rows xq [B*H*W][ldx].  Returns out [B*Ho*Wo][Cout] (row-major).
     splitk=False forbids the split-K schedule (tests compare it with the default, which lets the library decide).
     gn_stats=True: when the layer is eligible (tile-ordered int4, fp32 out, Ho*Wo % 128 == 0, not a split-K layer) the
@@ -338,8 +354,12 @@ def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, re
     if Ho is None:
         Ho, Wo = conv_out_hw(H, W, plan)
     M = B * Ho * Wo
+    if out_dtype is None:
+        out_dtype = out.dtype if out is not None else STREAM_DTYPE
+    if residual is not None and acc_out is None and residual.dtype != out_dtype:
+        residual = residual.to(out_dtype)                  # the kernel reads the residual in the output's type
     if out is None and acc_out is None:
-        if slot is not None and out_dtype == torch.float32:
+        if slot is not None and out_dtype == STREAM_DTYPE:
             out = slot.rows(M, plan.Cout, xq.device)
         if out is None:
             slot = None
@@ -356,7 +376,7 @@ def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, re
                         pad_t=pad, pad_l=pad, wbits=plan.pack.wbits, w_tiled=plan.pack.tiled, segs=plan.segs,
                         splitk=splitk, upsample2x=upsample2x)
     part = None
-    if (gn_stats and acc_out is None and plan.pack.tiled and out.dtype == torch.float32 and (Ho * Wo) % 128 == 0
+    if (gn_stats and acc_out is None and plan.pack.tiled and out.dtype in (torch.float32, torch.float16) and (Ho * Wo) % 128 == 0
             and out.stride(1) == 1 and (splitk is False or hip.splitk_ws_bytes(call) == 0)):
         if slot is not None:
             part = slot.part(B, Ho * Wo // 128, plan.Cout, xq.device)
@@ -558,14 +578,18 @@ def head_buffers(device, BH, T, S, d):
 # a per-device arena that QuantModel's forward pre-hook zeroes once per UNet evaluation (begin_evaluation); a block whose
 # slice is not known to be clean — called outside a QuantModel evaluation, or twice in one — zeroes it itself.
 _VSUM = {}
-_VSUM_ARENA_INTS = 4 << 20
+_VSUM_ARENA_INTS = 1 << 20
+_VSUM_OWNER = [None]          # the QuantModel whose evaluation is being issued (set by begin_evaluation)
 
 
 def vsum_slice(owner, device, shape):
-    """int32 tensor of `shape` for `owner` (any hashable), carved out of the device arena."""
-    st = _VSUM.get(device)
+    """int32 tensor of `shape` for `owner` (any hashable), carved out of the arena of (device, model under evaluation).
+    One arena per MODEL: two QuantModels evaluating on different streams of one device (a capture warm-up next to a live
+    model) never zero or mark clean each other's in-flight column sums."""
+    mkey = (device, _VSUM_OWNER[0])
+    st = _VSUM.get(mkey)
     if st is None:
-        st = _VSUM[device] = dict(arena=torch.zeros(_VSUM_ARENA_INTS, dtype=torch.int32, device=device), used=0, views={}, clean=set())
+        st = _VSUM[mkey] = dict(arena=torch.zeros(_VSUM_ARENA_INTS, dtype=torch.int32, device=device), used=0, views={}, clean=set())
     key = (owner, tuple(shape))
     v = st["views"].get(key)
     if v is None:
@@ -583,16 +607,18 @@ def vsum_slice(owner, device, shape):
     return v
 
 
-def begin_evaluation():
-    """Start of a UNet evaluation (QuantModel forward pre-hook): one memset for all attention blocks' V^T column sums."""
-    for st in _VSUM.values():
-        if st["used"]:
+def begin_evaluation(model_key=None):
+    """Start of a UNet evaluation (QuantModel forward pre-hook): one memset for all attention blocks' V^T column sums of
+    THIS model (`model_key`: id of the QuantModel; None = the anonymous arena of code that drives blocks directly)."""
+    _VSUM_OWNER[0] = model_key
+    for (dev, mk), st in _VSUM.items():
+        if mk == model_key and st["used"]:
             st["arena"][:st["used"]].zero_()
             st["clean"] = {id(v) for v in st["views"].values() if v.untyped_storage().data_ptr() == st["arena"].untyped_storage().data_ptr()}
 
 
 def _vsum_prepare(vsum):
-    st = _VSUM.get(vsum.device)
+    st = _VSUM.get((vsum.device, _VSUM_OWNER[0]))
     if st is not None and id(vsum) in st["clean"]:
         st["clean"].discard(id(vsum))
         return

@@ -269,7 +269,8 @@ def _conv_desc(c):
         c.oq_params = _qp(c.oq_params)              # kept on the call object: the pointer must outlive the launch
         d.oq_params = _ptr(c.oq_params, "oq_params")
         d.oq_min, d.oq_max, d.oq_off = c.oq_grid.qmin, c.oq_grid.qmax, c.oq_grid.off
-        d.out_dtype = F32                           # unused: the output is int8
+        # the output is int8; with a residual (QD_EPI_HEADS_I8) out_dtype names the RESIDUAL's type (fp32 / fp16 stream)
+        d.out_dtype = _dtype(c.residual) if c.residual is not None else F32
         if d.epilogue in (EPI_HEADS_I8, EPI_HEADS_T_I8):
             hd = c.heads                            # dict(H, d, T, Tpad, dpad, prescale, sum)
             d.hd_H, d.hd_d, d.hd_T, d.hd_Tpad, d.hd_dpad = hd["H"], hd["d"], hd["T"], hd["Tpad"], hd["dpad"]

@@ -118,6 +118,8 @@ class UniformAffineQuantizer(nn.Module):
         """Data-dependent init from the first tensor seen (reference quant_layer.py:68-75)."""
         if self.inited:
             return
+        if x.dtype != torch.float32:
+            x = x.float()                                  # an fp16 activation stream: ranges and step sizes are fp32 all the same
         delta, zero_point = self.init_quantization_scale(x, self.channel_wise)
         self.delta = nn.Parameter(delta) if self.leaf_param else delta
         self.zero_point = zero_point

@@ -83,7 +83,7 @@ class QuantModel(nn.Module):
         for m in self.model.modules():
             if isinstance(m, QuantBasicTransformerBlock):
                 ctx.register(m)
-        self.model.register_forward_pre_hook(lambda _m, _a: (group.reset(), ctx.reset(), engine.begin_evaluation()) and None)
+        self.model.register_forward_pre_hook(lambda _m, _a: (group.reset(), ctx.reset(), engine.begin_evaluation(id(self))) and None)
         self.model.register_forward_hook(lambda _m, _a, _o: ctx.finish(), always_call=True)
         te = getattr(self.model, "time_embed", None)
         if (isinstance(te, nn.Sequential) and len(te) == 3 and isinstance(te[0], QuantModule) and isinstance(te[2], QuantModule)
@@ -211,12 +211,14 @@ class QuantModel(nn.Module):
     def forward(self, x, timesteps=None, context=None):
         if self._graphs is not None and not torch.is_grad_enabled() and torch.is_tensor(timesteps) and x.is_cuda:
             from .graph import GraphedUNet, signature
-            key = signature(x, timesteps, context) + (self._quant_state,)
+            key = signature(x, timesteps, context) + (self._quant_state, engine.STREAM_DTYPE)
             g = self._graphs.get(key)
             if g is None:
                 g = self._graphs[key] = GraphedUNet(self, x, timesteps, context)
-            return g(x, timesteps, context).clone()
-        return self.model(x, timesteps, context)
+            return g(x, timesteps, context).to(x.dtype, copy=True)
+        y = self.model(x, timesteps, context)
+        # an fp16 activation stream ends here: the samplers' update arithmetic runs in the latent's own type
+        return y.to(x.dtype) if torch.is_tensor(y) and y.dtype == torch.float16 and x.dtype != torch.float16 else y
 
     def invalidate_plans(self):
         """Forget every packed weight / epilogue constant / captured graph (see QuantModule.invalidate)."""

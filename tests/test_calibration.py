@@ -29,6 +29,19 @@ def _summary(t):
 
 @pytest.mark.parametrize("name", ["cifar_tiny", "sd_tiny", "ldm_tiny", "ldm_updown_tiny"])
 def test_calibration_matches_the_reference(name):
+    _calibration_vs_reference_fixture(name, torch.device("cpu"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cifar_tiny", "sd_tiny", "ldm_updown_tiny"])
+def test_calibration_matches_the_reference_on_gpu(cuda, name):
+    """The same fixtures — produced by the REFERENCE's own calibration code on the CPU — with the model, the cached unit
+    inputs / outputs and the fused fake-quant kernels on the MI355X (mini-batch indices come from the host generator, so
+    the batch sequence is the reference's): the same bounds as on the CPU."""
+    _calibration_vs_reference_fixture(name, cuda, on_gpu=True)
+
+
+def _calibration_vs_reference_fixture(name, dev, on_gpu=False):
     import qdiff
     from qdiff.adaptive_rounding import AdaRoundQuantizer
     from qdiff.calibrate import recon_model
@@ -38,12 +51,13 @@ def test_calibration_matches_the_reference(name):
     cond = spec["ctx"] is not None
     wq, aq = quant_params(spec)
     xs, ts, cs = _inputs(spec, fx["n_cal"], fx["cal_seed"])
-    cali = (xs, ts, cs) if cond else (xs, ts)
-    test = tuple(a for a in _inputs(spec, 2, fx["test_seed"]) if a is not None)
-    qnn = qdiff.QuantModel(build_engine_model(spec), wq, aq, sm_abit=spec["sm_abit"]).eval()
+    cali = (xs, ts, cs) if cond else (xs, ts)                # calibration data stays on the host, as in the scripts
+    test = tuple(a.to(dev) for a in _inputs(spec, 2, fx["test_seed"]) if a is not None)
+    qnn = qdiff.QuantModel(build_engine_model(spec).to(dev), wq, aq, sm_abit=spec["sm_abit"]).to(dev).eval()
+    on_dev = lambda batch: tuple(a.to(dev) for a in batch)
     qnn.set_quant_state(True, False)
     with torch.no_grad():
-        qnn(*cali)
+        qnn(*on_dev(cali))
     torch.manual_seed(fx["seed"])
     np.random.seed(fx["seed"])
     if fx["iters_w"]:                                     # (the LDM fixture covers the activation phase only: see the tool)
@@ -54,26 +68,36 @@ def test_calibration_matches_the_reference(name):
     assert set(got) == set(fx["alphas"]), "the set of AdaRound quantisers differs from the reference's"
     lr = 1e-3                                             # Adam default: the size of one step
     flips = total = 0
+    worst_frac = 0.0
     for k, want in fx["alphas"].items():
         g = got[k]
         assert g["numel"] == want["numel"], k
-        d = (g["sample"] - want["sample"]).abs()
+        d = (g["sample"].cpu() - want["sample"]).abs()
         assert d.max().item() <= 2 * lr * fx["iters_w"] + 1e-5, (k, d.max().item())     # never further than every step reversed
-        assert (d > 1e-4).float().mean().item() <= 0.05, (k, (d > 1e-4).float().mean().item())
+        worst_frac = max(worst_frac, (d > 1e-4).float().mean().item())
+        if not on_gpu:
+            # same library, same summation order as the run that produced the fixture: only Adam's sign noise on ~0 gradients
+            assert (d > 1e-4).float().mean().item() <= 0.05, (k, (d > 1e-4).float().mean().item())
         flips += abs(g["n_up"] - want["n_up"])
         total += want["numel"]
-        assert abs(g["l2"] - want["l2"]) <= 1e-3 * want["l2"] + 1e-4, k
-    assert flips <= 1e-4 * total, f"{flips} of {total} rounding decisions differ"
+        assert abs(g["l2"] - want["l2"]) <= (5e-3 if on_gpu else 1e-3) * want["l2"] + 1e-4, (k, g["l2"], want["l2"])
+    # On the GPU the fp32 convolutions of the simulation (MIOpen) sum in another order than the CPU's: most AdaRound
+    # gradients of these few-iteration fixtures are noise-level, Adam normalises them to +-lr steps, so the element-wise
+    # agreement above is not available; what is: no element further than the reachable distance, the norms, the rounding
+    # DECISIONS (sign of alpha) and the network output after the weight phase.
+    print(f"\n[{name}{' gpu' if on_gpu else ''}] AdaRound: worst fraction of sampled elements beyond 1e-4 = {worst_frac:.3f}, "
+          f"rounding decisions that differ = {flips} of {total} ({flips / max(total, 1):.2e})")
+    assert flips <= (2e-3 if on_gpu else 1e-4) * total, f"{flips} of {total} rounding decisions differ"
     qnn.eval()
     with torch.no_grad():
         y = qnn(*test)
-    assert (y - fx["out_w"]).abs().max().item() <= 2e-3 * fx["out_w"].abs().max().item()
+    assert (y.cpu() - fx["out_w"]).abs().max().item() <= 2e-3 * fx["out_w"].abs().max().item()
     # activation phase
     from qdiff import engine
     qnn.set_quant_state(True, True)
     with torch.no_grad(), engine.simulation():
         inds = torch.as_tensor(np.random.choice(xs.shape[0], 4, replace=False))
-        qnn(*(a[inds] for a in cali))
+        qnn(*(a[inds].to(dev) for a in cali))
     recon_model(qnn, cali_data=cali, batch_size=fx["batch"], iters=fx["iters_a"], act_quant=True, opt_mode='mse', lr=4e-4, p=2.4,
                 cond=cond)
     qnn.set_quant_state(True, True)
@@ -83,13 +107,14 @@ def test_calibration_matches_the_reference(name):
     moved = 0
     for k, want in fx["deltas"].items():
         g = deltas[k]
-        assert torch.allclose(g.reshape(-1), want.reshape(-1), rtol=5e-3, atol=2 * 4e-4 * fx["iters_a"]), (k, g, want)
+        assert torch.allclose(g.reshape(-1).cpu(), want.reshape(-1), rtol=5e-3, atol=2 * 4e-4 * fx["iters_a"]), (k, g, want)
         moved += 1
     assert moved > 20
     qnn.eval()
     with torch.no_grad(), engine.simulation():
         y = qnn(*test)
     # a fake-quantised network amplifies the 1e-3-level step-size differences above through round() ties
+    y = y.cpu()
     cos = torch.nn.functional.cosine_similarity(y.flatten(), fx["out_wa"].flatten(), dim=0).item()
     assert (y - fx["out_wa"]).abs().max().item() <= 0.12 * fx["out_wa"].abs().max().item() and cos >= 0.99, cos
 

@@ -570,6 +570,59 @@ def test_attention_fused(cuda, case):
     assert ((got - want_fq).abs() > 1e-3 * rng).float().mean().item() <= 1e-2
 
 
+@pytest.mark.parametrize("shape", [(2, 320, 32, 320, 3), (1, 640, 16, 640, 3), (2, 320, 64, 320, 1), (3, 96, 16, 200, 3), (16, 256, 8, 1280, 3)])
+def test_conv_fp16_stream_is_the_rounded_fp32_epilogue(cuda, shape):
+    """fp16 activation stream (out / residual stored as halves): the epilogue computes the SAME fp32 value and rounds it once
+    (RN) on the store, reads the residual as float(half) — so with a half-representable residual the fp16 output equals
+    `fp32_output.half()` bit for bit, the GroupNorm statistics (taken from the fp32 values) are identical, on the 128x320
+    tile, the 256x160 / 128x160 tiles, a ragged width (scalar path) and the split-K schedule alike."""
+    from qdiff import engine
+    B, Cin, H, Cout, k = shape
+    g = torch.Generator().manual_seed(53)
+    x = F.silu(torch.randn(B, Cin, H, H, generator=g))
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
+    q = _weight_quantizer(w, 4, True, g)
+    d, z = R.uaq_init_scale(x, 8, False, False, "max")
+    plan = engine.build_conv_plan(engine.pack_module_weights(w.to(cuda), [q], 0), [_aq(d, z)], k, k, 1, k // 2,
+                                  torch.randn(Cout, generator=g).to(cuda))
+    xq = engine.quantize_rows(x.to(cuda), plan, B, Cin, H * H, (Cin * H * H, H * H, 1))
+    rowbias = torch.randn(B, Cout, generator=g).to(cuda)
+    res16 = torch.randn(B * H * H, Cout, generator=g).to(cuda).half()
+    gn = (H * H) % 128 == 0
+    for kw in (dict(gn_stats=gn, splitk=False), dict()):
+        o32 = engine.conv_forward(plan, xq, B, H, H, rowbias=rowbias, residual=res16.float(), out_dtype=torch.float32, **kw)
+        o16 = engine.conv_forward(plan, xq, B, H, H, rowbias=rowbias, residual=res16, out_dtype=torch.float16, **kw)
+        torch.cuda.synchronize()
+        assert o16.dtype == torch.float16 and torch.equal(o16, o32.half())
+        if hasattr(o32, "qd_gn_part"):
+            assert hasattr(o16, "qd_gn_part") and torch.equal(o16.qd_gn_part, o32.qd_gn_part)
+
+
+def test_linear_to_rows_with_fp16_residual(cuda):
+    """QD_EPI_HEADS_I8 ("Linear + residual -> the next Linear's int8 rows") with the residual stored as halves: the same
+    bytes as with the residual widened to fp32 first."""
+    from qdiff import engine
+    g = torch.Generator().manual_seed(59)
+    B, T, K, N = 2, 256, 1280, 320
+    x = torch.randn(B * T, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.05
+    q = _weight_quantizer(w, 4, True, g)
+    dx, zx = R.uaq_init_scale(x, 8, False, False, "max")
+    plan = engine.build_conv_plan(engine.pack_module_weights(w.to(cuda), [q], 0), [_aq(dx, zx)], 1, 1, 1, 0, torch.randn(N, generator=g).to(cuda))
+    xq = engine.quantize_rows(x.to(cuda), plan, 1, K, B * T, (0, 1, K))
+    res16 = torch.randn(B * T, N, generator=g).to(cuda).half()
+    y = engine.conv_forward(plan, xq, 1, 1, B * T, residual=res16.float(), out_dtype=torch.float32)
+    w2 = torch.randn(N, N, generator=g) * 0.05
+    q2 = _weight_quantizer(w2, 4, True, g)
+    d2, z2 = R.uaq_init_scale(y.cpu(), 8, False, False, "max")
+    nxt = engine.build_conv_plan(engine.pack_module_weights(w2.to(cuda), [q2], 0), [_aq(d2, z2)], 1, 1, 1, 0, None)
+    assert engine.rows_i8_fusable(plan, nxt, T)
+    a = engine.linear_to_rows_i8(plan, xq, B, T, nxt, residual=res16.float())
+    b = engine.linear_to_rows_i8(plan, xq, B, T, nxt, residual=res16)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and a.abs().max() > 0
+
+
 PIPE_CASES = [
     # name,            B, H, T,    S,    d,  sm_bits, q_sym, q_nonneg, peaky
     ("even_tiles",     2, 4, 160,  256,  40, 16, False, False, False),     # 8 full key tiles, no ragged tile
