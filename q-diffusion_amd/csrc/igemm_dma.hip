@@ -496,7 +496,11 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
 
     {
         unsigned cur = 0, nxt = 2 * STAGE;
+#ifdef QD_ABL_NOKLOOP          // measurement-only build (wrong results): prologue + epilogue, one K-step
+        for (int it = 0; it < 1; ++it) {
+#else
         for (int it = 0; it < total; ++it) {
+#endif
             step(cur, nxt);
             if (SPLIT && p.nseg == 2 && it == nst0 - 1) flush_segment0();
             nxt = cur;
@@ -506,6 +510,17 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
     }
 
     // ---- epilogue ----------------------------------------------------------------------------------------------
+#ifdef QD_ABL_NOEPI            // measurement-only build (wrong results): prologue + K loop, one store per lane instead of the epilogue
+    {
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) t += acc[i][j][0] ^ acc[i][j][7] ^ acc[i][j][15];
+        if (t == 0x7fffffff) reinterpret_cast<int*>(p.out)[threadIdx.x] = t;
+        return;
+    }
+#endif
     publish_asum();
     __syncthreads();                                   // sAsum / sRowB visible to every wave; the ring is dead from here on
     const SegD& sg = p.seg[p.nseg - 1];

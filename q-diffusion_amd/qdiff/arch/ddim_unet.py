@@ -54,6 +54,21 @@ class Upsample(nn.Module):
     qd_takes_out_slot = True
 
     def forward(self, x, out_slot=None):
+        if self.with_conv:
+            from .. import engine, quant_block as qb
+            from .ldm_unet import UPSAMPLE_FOLD
+            conv = self.conv
+            if (UPSAMPLE_FOLD and isinstance(conv, qb.QuantModule) and qb._int_mode(conv) and conv.split == 0
+                    and conv.act_quantizer.inited and not conv.act_quantizer.running_stat and x.dim() == 4):
+                # quantisation commutes with nearest-neighbour replication, and the replication itself is folded into the
+                # convolution's im2col gather (qd_conv_desc.upsample2x): quantise the SMALL map, convolve its up-sampling
+                b, c, h, w = x.shape
+                plan = conv.conv_plan()
+                if engine.upsample_fold_ok(plan, 2 * h, 2 * w):
+                    rows = qb._nhwc_rows(x)
+                    xq = engine.quantize_rows(rows, plan, 1, c, b * h * w, (0, 1, rows.stride(0)))
+                    out = conv.forward_codes(xq, b, 2 * h, 2 * w, gn_stats=True, slot=out_slot, upsample2x=True)
+                    return qb._rows_to_nchw(out, b, 2 * h, 2 * w)
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         if self.with_conv and out_slot is not None and getattr(self.conv, "qd_takes_out_slot", False):
             return self.conv(x, out_slot=out_slot)
@@ -281,4 +296,6 @@ class Model(nn.Module):
                 h = run(stage.upsample, h, slot=dec_slot())
         self.__dict__["_cat_plan"] = seen
 
+        if h.dtype != torch.float32:
+            h = h.float()                                   # fp16 activation stream: the torch output head runs on fp32
         return self.conv_out(nonlinearity(self.norm_out(h)))

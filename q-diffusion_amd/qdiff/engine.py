@@ -280,11 +280,23 @@ def conv_out_hw(H, W, plan, pad_br=None):
 STREAM_DTYPE = torch.float16 if os.environ.get("QDIFF_STREAM", "fp32").lower() in ("fp16", "half", "float16") else torch.float32
 
 
+# The stream type in force for the evaluation being issued: STREAM_DTYPE once the whole model runs on the integer path (every
+# activation quantiser initialised, no range tracking), fp32 before — the floating-point compositions that initialise the
+# quantisers are torch code on fp32 parameters.  Set by QuantModel's forward pre-hook; code that drives kernels directly
+# (tests, micro-benchmarks) gets STREAM_DTYPE.
+_EFFECTIVE = [None]
+
+
+def stream_dtype():
+    return _EFFECTIVE[0] if _EFFECTIVE[0] is not None else STREAM_DTYPE
+
+
 def set_stream_dtype(dtype):
     global STREAM_DTYPE
     if dtype not in (torch.float32, torch.float16):
         raise ValueError("activation stream dtype must be torch.float32 or torch.float16")
     STREAM_DTYPE = dtype
+    _EFFECTIVE[0] = None
 
 
 class CatSlot:
@@ -307,8 +319,8 @@ class CatSlot:
         if C != self.c[i]:
             return None
         if self.buf is None:
-            self.buf = torch.empty((M, self.c[0] + self.c[1]), dtype=STREAM_DTYPE, device=device)
-        if self.buf.shape[0] != M or self.buf.device != device or self.buf.dtype != STREAM_DTYPE:
+            self.buf = torch.empty((M, self.c[0] + self.c[1]), dtype=stream_dtype(), device=device)
+        if self.buf.shape[0] != M or self.buf.device != device or self.buf.dtype != stream_dtype():
             return None
         c0 = 0 if i == 0 else self.c[0]
         return self.buf[:, c0:c0 + C]
@@ -355,11 +367,11 @@ def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, re
         Ho, Wo = conv_out_hw(H, W, plan)
     M = B * Ho * Wo
     if out_dtype is None:
-        out_dtype = out.dtype if out is not None else STREAM_DTYPE
+        out_dtype = out.dtype if out is not None else stream_dtype()
     if residual is not None and acc_out is None and residual.dtype != out_dtype:
         residual = residual.to(out_dtype)                  # the kernel reads the residual in the output's type
     if out is None and acc_out is None:
-        if slot is not None and out_dtype == STREAM_DTYPE:
+        if slot is not None and out_dtype == stream_dtype():
             out = slot.rows(M, plan.Cout, xq.device)
         if out is None:
             slot = None

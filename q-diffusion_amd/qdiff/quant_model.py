@@ -19,7 +19,7 @@ from types import MethodType
 from .quant_block import (BaseQuantBlock, ContextKV, EmbGroup, QuantAttentionBlock, QuantAttnBlock, QuantBasicTransformerBlock,
                           QuantQKMatMul, QuantResBlock, QuantResnetBlock, QuantSMVMatMul, get_specials, reference_classes,
                           time_mlp)
-from .quant_layer import QuantModule, StraightThrough
+from .quant_layer import QuantModule, StraightThrough, UniformAffineQuantizer
 from .arch import ddim_unet, ldm_unet
 
 logger = logging.getLogger(__name__)
@@ -83,7 +83,8 @@ class QuantModel(nn.Module):
         for m in self.model.modules():
             if isinstance(m, QuantBasicTransformerBlock):
                 ctx.register(m)
-        self.model.register_forward_pre_hook(lambda _m, _a: (group.reset(), ctx.reset(), engine.begin_evaluation(id(self))) and None)
+        self.model.register_forward_pre_hook(lambda _m, _a: (group.reset(), ctx.reset(), engine.begin_evaluation(id(self)),
+                                                             self._select_stream()) and None)
         self.model.register_forward_hook(lambda _m, _a, _o: ctx.finish(), always_call=True)
         te = getattr(self.model, "time_embed", None)
         if (isinstance(te, nn.Sequential) and len(te) == 3 and isinstance(te[0], QuantModule) and isinstance(te[2], QuantModule)
@@ -202,7 +203,31 @@ class QuantModel(nn.Module):
             elif ref.get("Upsample") is not None and type(m) is ref["Upsample"] and getattr(m, "dims", 2) == 2:
                 m.qd_takes_out_slot = True
 
+    def _select_stream(self):
+        """fp16 activation stream (engine.STREAM_DTYPE) only for evaluations that run entirely on the integer path; the
+        verdict is cached once positive (set_quant_state / invalidate_plans / set_running_stat drop it)."""
+        if engine.STREAM_DTYPE == torch.float32:
+            engine._EFFECTIVE[0] = None
+            return
+        ready = self.__dict__.get("_stream_ready", False)
+        if not ready and self._quant_state == (True, True) and not torch.is_grad_enabled() and not engine.SIMULATE and not self.model.training:
+            ready = True
+            for m in self.model.modules():
+                if isinstance(m, QuantModule):
+                    if not m.int_ready() or any((not q.inited) or q.running_stat for q in m._act_quantizers()):
+                        ready = False
+                        break
+                else:
+                    qs = [getattr(m, n, None) for n in ("act_quantizer_q", "act_quantizer_k", "act_quantizer_v", "act_quantizer_w")]
+                    if any(isinstance(q, UniformAffineQuantizer) and ((not q.inited) or q.running_stat) for q in qs):
+                        ready = False
+                        break
+            self.__dict__["_stream_ready"] = ready
+        ok = ready and self._quant_state == (True, True) and not torch.is_grad_enabled() and not engine.SIMULATE
+        engine._EFFECTIVE[0] = engine.STREAM_DTYPE if ok else torch.float32
+
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
+        self.__dict__["_stream_ready"] = False
         self._quant_state = (bool(weight_quant), bool(act_quant))
         for m in self.model.modules():
             if isinstance(m, (QuantModule, BaseQuantBlock)):
@@ -222,6 +247,7 @@ class QuantModel(nn.Module):
 
     def invalidate_plans(self):
         """Forget every packed weight / epilogue constant / captured graph (see QuantModule.invalidate)."""
+        self.__dict__["_stream_ready"] = False
         for m in self.model.modules():
             if isinstance(m, QuantModule):
                 m.invalidate()
@@ -237,6 +263,7 @@ class QuantModel(nn.Module):
 
     def set_running_stat(self, running_stat: bool, sm_only=False):
         """reference :71-87"""
+        self.__dict__["_stream_ready"] = False
         for m in self.model.modules():
             if isinstance(m, QuantBasicTransformerBlock):
                 names = ("act_quantizer_w",) if sm_only else ("act_quantizer_q", "act_quantizer_k", "act_quantizer_v",

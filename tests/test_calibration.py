@@ -87,7 +87,7 @@ def _calibration_vs_reference_fixture(name, dev, on_gpu=False):
     # DECISIONS (sign of alpha) and the network output after the weight phase.
     print(f"\n[{name}{' gpu' if on_gpu else ''}] AdaRound: worst fraction of sampled elements beyond 1e-4 = {worst_frac:.3f}, "
           f"rounding decisions that differ = {flips} of {total} ({flips / max(total, 1):.2e})")
-    assert flips <= (2e-3 if on_gpu else 1e-4) * total, f"{flips} of {total} rounding decisions differ"
+    assert flips <= (5e-4 if on_gpu else 1e-4) * total       # GPU, measured round 3: 1.5e-4 (cifar_tiny), 0 (sd_tiny), f"{flips} of {total} rounding decisions differ"
     qnn.eval()
     with torch.no_grad():
         y = qnn(*test)

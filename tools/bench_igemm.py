@@ -61,7 +61,7 @@ def main():
         plan = engine.build_conv_plan(pack, [aq], k, k, stride, k // 2, torch.zeros(Cout, device=dev))
         xq = torch.randint(-128, 127, (B * H * H, plan.ldx), dtype=torch.int8, device=dev, generator=g)
         Ho, Wo = engine.conv_out_hw(H, H, plan)
-        out = torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=dev)
+        out = torch.empty((B * Ho * Wo, Cout), dtype=torch.float16 if os.environ.get("IGEMM_OUT") == "fp16" else torch.float32, device=dev)
         for _ in range(3):
             engine.conv_forward(plan, xq, B, H, H, Ho, Wo, out=out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
