@@ -238,11 +238,11 @@ def cpu_baseline(qnn, qspec, kind, cfg, k=2):
     torch.set_num_threads(cands[len(cands) // 2])
     one()                                              # warm-up (allocator, oneDNN primitives)
     sweep = {}
-    for t in cands:
-        torch.set_num_threads(t)
+    for nthr in cands:
+        torch.set_num_threads(nthr)
         t0 = time.time()
         one()
-        sweep[t] = time.time() - t0
+        sweep[nthr] = time.time() - t0
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
     t0 = time.time()
@@ -250,7 +250,7 @@ def cpu_baseline(qnn, qspec, kind, cfg, k=2):
         one()
     dt = (time.time() - t0) / k
     torch.set_num_threads(n0)
-    return dt, best, {str(t): round(v, 2) for t, v in sweep.items()}
+    return dt, best, {str(n): round(v, 2) for n, v in sweep.items()}
 
 
 def first_stage_decode_ms(kind, n, dev, k=3):

@@ -164,6 +164,6 @@ def run_block_parity(qnn, fx, dev, sync=None):
         lines.append(f"[{name}] {n64} block(s) were judged against the fp64 evaluation of the block (reference fp32 noise envelope)")
     if total:
         lines.append(f"[{name}] code-flip rate at the first quantiser of the residual blocks: {flips} / {total} = {flips / total:.3e}")
-        if flips / total > 2e-3:
-            failures.append(f"code-flip rate {flips / total:.3e} > 2e-3")
+        if flips / total > 2e-5:                                   # measured on the MI355X, round 3: 0 ... 3.9e-6
+            failures.append(f"code-flip rate {flips / total:.3e} > 2e-5")
     return lines, failures

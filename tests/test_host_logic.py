@@ -5,6 +5,7 @@ the real reference's golden outputs; the product path refuses to run without the
 import ctypes
 import os
 import re
+import sys
 import tempfile
 
 import pytest
@@ -552,3 +553,19 @@ def test_cat_channels_only_takes_the_view_when_it_is_one():
         assert torch.equal(qb.cat_channels(*bad), torch.cat(list(bad), dim=1))
     # a slot refuses producers of the wrong width / row count instead of mis-placing them
     assert slot.rows(0, B * H * W, C1 + 1, dev) is None and slot.rows(1, B * H * W + 1, C2, dev) is None
+
+
+def test_bench_cpu_baseline_leg_runs_on_the_host(monkeypatch):
+    """bench.py's `cpu_baseline` leg (the oracle timed on the host cores, thread-count sweep) only runs after the GPU part of the
+    driver's command: a bug in it costs the whole bench line (round 3: a loop variable shadowed the timestep tensor).  Run it
+    here on the CIFAR model built through the ABI emulator."""
+    import abi_emulator
+    abi_emulator.install(monkeypatch)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    qnn, qspec = bench.build_quantised_unet("cifar", torch.device("cpu"))
+    ocfg = dict(ch=128, ch_mult=[1, 2, 2, 2], num_res_blocks=2, attn_resolutions=[16], resolution=32)
+    dt, threads, sweep = bench.cpu_baseline(qnn, qspec, "cifar", ocfg, k=1)
+    assert dt > 0 and threads >= 1 and str(threads) in sweep
