@@ -263,12 +263,18 @@ def first_stage_decode_ms(kind, n, dev, k=3):
     m = m.to(dev).eval()
     z = torch.randn({"sd": (n, 4, 64, 64), "ldm": (n, 3, 64, 64), "churches": (n, 4, 32, 32)}[kind], device=dev)
     res = {}
-    for name, dt in (("fp32", None), ("bf16_autocast", torch.bfloat16)):
-        fs.decode_first_stage(m, z, scale, autocast_dtype=dt, to_uint8=True)
+    ref = None
+    for name, dt, eng in (("fp32", None, None), ("bf16_autocast", torch.bfloat16, None), ("hip_bf16", None, "hip")):
+        out = fs.decode_first_stage(m, z, scale, autocast_dtype=dt, engine=eng).float()
+        if ref is None:
+            ref = out
+        else:   # distance of the reduced-precision decoders from the fp32 library decode of the same latents
+            res[name + "_max_err_of_range"] = float(f"{((out - ref).abs().max() / ref.abs().max()).item():.3e}")
+        del out
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(k):
-            img = fs.decode_first_stage(m, z, scale, autocast_dtype=dt, to_uint8=True)
+            img = fs.decode_first_stage(m, z, scale, autocast_dtype=dt, to_uint8=True, engine=eng)
         torch.cuda.synchronize()
         res[name + "_ms_per_image"] = round((time.perf_counter() - t0) * 1000.0 / k / n, 3)
     res["images"] = n

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 16
+#define QD_ABI_VERSION 17
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -128,7 +128,7 @@ typedef struct {
     int64_t        ldx, ldk, ldo, ldr, ld_rowbias;
     int32_t        B, H, W, Ho, Wo, Cout;
     int32_t        kh, kw, stride, pad_t, pad_l;
-    int32_t        wbits;    /* 8 or 4                                                             */
+    int32_t        wbits;    /* 8 or 4 (16: qd_conv2d_bf16)                                        */
     int32_t        out_dtype;/* QD_F32 / QD_F16                                                    */
     int32_t        nseg;     /* 1 or 2                                                             */
     int32_t        w_tiled;  /* must be 1 (the row-major layouts of ABI <= 9 are gone)                  */
@@ -360,6 +360,33 @@ int qd_fakequant_fwd(const float* x, int64_t n, const float* delta, const float*
                      void* stream);
 int qd_fakequant_bwd(const float* x, const float* gy, int64_t n, const float* delta, const float* zero_point, int qmin, int qmax,
                      float* gx, float* gdelta_part, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * First-stage decoder: the convolutions of the KL-f8 / VQ-f4 `Decoder`
+ *     (ldm/modules/diffusionmodules/model.py:465-572 `Decoder.forward`: conv_in, ResnetBlock :80-141, AttnBlock :144-196
+ *     q/k/v/proj_out, Upsample :48-63 nearest-2x + conv, conv_out; called from ldm/models/autoencoder.py:330-333 `decode`
+ *     and ldm/models/diffusion/ddpm.py `decode_first_stage`) as bf16 x bf16 -> fp32 implicit GEMMs on
+ *     v_mfma_f32_32x32x16_bf16 — the loader, ring and epilogue of qd_conv2d_i8 in its floating-point mode.
+ *
+ *     qd_conv2d_bf16: same descriptor as qd_conv2d_i8 with
+ *         x          bf16 channels-last rows [B*H*W][ldx]; ldx, seg[0].c0, seg[0].clen count bf16 ELEMENTS (multiples of 8)
+ *         w          tile-ordered bf16 of qd_pack_weights_bf16 (wbits = 16, w_tiled = 1)
+ *         nseg = 1, epilogue = QD_EPI_LINEAR; seg[0].scale / zc / zw / zfill / fill16 unused (out-of-image taps read 0)
+ *         out        out[m][n] = sum_k x w + bias[n] (+ residual[m][n]); out_dtype = QD_F32 or QD_BF16, the residual has
+ *                    the type of the output
+ *         gn_part, upsample2x, kh/kw/stride/pad as for qd_conv2d_i8; rowbias, split-K, oq_* / hd_* unused.
+ *     qd_pack_weights_bf16: fp32 [Cout][Cin][taps] (OIHW) -> bf16 (round to nearest even) in the order the kernel reads:
+ *         per (tap, 32-channel K-step, 32-output-channel tile) 2 KB as [k-half (16 ch)][lane-half (8 ch)][n % 32][8 bf16];
+ *         channels Cin .. clen_pad-1 (clen_pad % 8 == 0 = the descriptor's clen) are zero.  wt: qd_pack_weights_bf16_bytes.
+ *     qd_groupnorm_silu_bf16: GroupNorm (+ SiLU) of fp32 rows into bf16 rows (model.py:38-45 `Normalize` / `nonlinearity`
+ *         in front of every convolution); ws / part_in / nchunk_in / part_ld as for qd_groupnorm_silu_quant.
+ * ------------------------------------------------------------------------------------------ */
+int qd_conv2d_bf16(const qd_conv_desc* d, void* stream);
+int64_t qd_pack_weights_bf16_bytes(int Cout, int taps, int clen_pad);
+int qd_pack_weights_bf16(const float* w, int Cout, int Cin, int taps, int clen_pad, uint8_t* wt, void* stream);
+int qd_groupnorm_silu_bf16(const float* x, int64_t B, int64_t S, int C, int64_t ldx, int groups, float eps,
+                           const float* gamma, const float* beta, int apply_silu, void* out, int64_t ldo, void* ws,
+                           const float* part_in, int nchunk_in, int64_t part_ld, void* stream);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <type_traits>
 #include "../../include/qdiff_hip.h"
@@ -45,6 +46,27 @@ __device__ __forceinline__ int qd_xcd_remap(int bid, int nwg) {
 template <typename T> __device__ __forceinline__ float qd_ld(const T* p);
 template <> __device__ __forceinline__ float qd_ld<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float qd_ld<__half>(const __half* p) { return __half2float(*p); }
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+
+// four bf16 <-> four floats through one 8-byte access (first-stage decoder: bf16 activations, fp32 accumulators).
+// bf16 -> fp32 is a 16-bit shift; fp32 -> bf16 rounds to nearest even (v_cvt_pk_bf16_f32 on gfx950).
+__device__ __forceinline__ v4f qd_ld4bf(const void* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return v4f{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+}
+__device__ __forceinline__ unsigned qd_pack2bf(float a, float b) {
+    const __hip_bfloat16 x = __float2bfloat16(a), y = __float2bfloat16(b);
+    return (unsigned)(*reinterpret_cast<const unsigned short*>(&x)) | ((unsigned)(*reinterpret_cast<const unsigned short*>(&y)) << 16);
+}
+__device__ __forceinline__ void qd_st4bf(void* p, const v4f& v) {
+    uint2 u;
+    u.x = qd_pack2bf(v[0], v[1]);
+    u.y = qd_pack2bf(v[2], v[3]);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+__device__ __forceinline__ float qd_bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
 // four halves <-> four floats through one 8-byte access (fp16 activation streams)
 __device__ __forceinline__ v4f qd_ld4h(const __half* p) {

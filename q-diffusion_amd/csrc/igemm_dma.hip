@@ -86,7 +86,8 @@ struct ConvD {
 // q/k/v activation quantiser and written as int8 straight into the head-major operand layout of
 // attn_i8.hip (rows [(b,h)][t][dpad] for q and k; transposed + key-permuted [(b,h)][dd][t] plus column
 // sums for v) — the fp32 projection output and the separate qd_quantize_heads pass disappear.
-enum { O_F32 = 0, O_F16 = 1, O_I32 = 2, O_GEGLU = 3, O_PART = 4, O_HROWS = 5, O_HTR = 6 };
+// O_BF16 (WB = 16 only): bf16 rows (+ bf16 residual) — the floating-point mode of the kernel (first-stage decoder, §N1).
+enum { O_F32 = 0, O_F16 = 1, O_I32 = 2, O_GEGLU = 3, O_PART = 4, O_HROWS = 5, O_HTR = 6, O_BF16 = 7 };
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -127,15 +128,22 @@ __device__ __forceinline__ constexpr int crow(int r) { return (r & 3) + 8 * (r >
 
 // WB = weight bits of the tile-ordered operand: 4 (raw nibbles, 1 KB per K-step x 32 channels) or 8 (s8 bytes W-128,
 // 2 KB); everything but the B tile size and the fragment read is shared.
+// WB = 16: the same kernel as a bf16 x bf16 -> fp32 convolution (v_mfma_f32_32x32x16_bf16).  A 64-byte K-step is 32 bf16
+// channels = two K = 16 MFMAs per tile — the byte geometry of the W8 path exactly (16-byte fragments, 2-KB weight tiles in
+// [k-half][lane-half][n % 32][16 B] order), so the DMA loader, the im2col gather, the ring and the barriers are untouched;
+// accumulators are fp32, there is no zero-point algebra (no row sums, no per-channel integer constants) and out-of-image
+// taps read zeros.  All sizes the loader sees (ldx, c0, clen) are BYTES.
 #ifndef QD_MT1_OCC
 #define QD_MT1_OCC 2      // waves per SIMD the 128-row tiles are compiled for (3 fits without spills; A/B knob of build.py)
 #endif
 template <int MT, int NT, int WM, int WN, bool SPLIT, int OUT, int WB>
 __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <= 5 ? QD_MT1_OCC : 2)) void igemm_kernel(const ConvD p) {
-    static_assert(WB == 4 || WB == 8, "weight bits");
+    static_assert(WB == 4 || WB == 8 || WB == 16, "weight bits (16 = bf16 mode)");
+    constexpr bool BF = WB == 16;
+    static_assert(!BF || (!SPLIT && (OUT == O_F32 || OUT == O_BF16)), "bf16 mode: one segment, fp32 / bf16 rows");
     static_assert(WM * WN == 4, "four waves per block");
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, NTB = NT * WN;
-    constexpr int TB = 256 * WB;                  // bytes of one (K-step, 32-channel) weight tile
+    constexpr int TB = BF ? 2048 : 256 * WB;      // bytes of one (K-step, 32-channel) weight tile
     constexpr int A_BYTES = BM * 64, B_BYTES = NTB * TB;
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int NA = BM / 64;                   // A DMA instructions per wave per stage (16 rows each)
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
     };
 
     // ---- accumulators ------------------------------------------------------------------------------------
-    v16i acc[MT][NT];
+    typename std::conditional<BF, v16f, v16i>::type acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
             const int row = wrow0 + i * 32 + frow;
             a_off[i][ks] = row * 64 + (((ks * 2 + fhalf) ^ ((row >> 2) & 3)) * 16);
         }
-    const unsigned b_off = A_BYTES + wn * NT * TB + (fhalf * 32 + frow) * (WB * 2);   // + ks*(TB/2) + j*TB
+    const unsigned b_off = A_BYTES + wn * NT * TB + (fhalf * 32 + frow) * (BF ? 16 : WB * 2);   // + ks*(TB/2) + j*TB
 
     constexpr int NPR = (BN + 255) / 256;              // per-channel constants fetched by each thread (BN may exceed the block size)
     float pr_scale[NPR], pr_bias[NPR];
@@ -377,7 +385,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
             const int cl = (int)threadIdx.x + 256 * u, pn = n0 + cl;
             pr_scale[u] = 0.f; pr_bias[u] = 0.f; pr_zc[u] = 0; pr_zw[u] = 0;
             if (cl < BN && pn < p.Cout) {
-                pr_scale[u] = sgl.scale[pn];
+                if (!BF) pr_scale[u] = sgl.scale[pn];
                 if (sgl.zc) pr_zc[u] = sgl.zc[pn];
                 if (sgl.zw) pr_zw[u] = sgl.zw[pn];
                 if (p.bias) pr_bias[u] = p.bias[pn];
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rowl = wrow0 + i * 32 + crow(r) + 4 * fhalf;
-                    const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rowl] - kz);
+                    const int I = (int)acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rowl] - kz);
                     facc[SPLIT ? i : 0][SPLIT ? j : 0][r] = (float)I * sc;
                     acc[i][j][r] = 0;
                 }
@@ -468,14 +476,20 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
                 bf = raw[s];
             }
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i) {
+                if constexpr (BF) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, af[ks][i]), __builtin_bit_cast(v8bf, bf),
+                                                                         acc[i][j], 0, 0, 0);
+                } else {
 #ifdef QD_ABL_NOMFMA       // measurement-only build (wrong results): the K-step without its matrix instructions
                 acc[i][j][0] += af[ks][i].x ^ bf.x ^ af[ks][i].w ^ bf.w;
 #else
                 acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks][i], bf, acc[i][j], 0, 0, 0);
 #endif
+                }
+            }
 #ifndef QD_ABL_NOASUM        // measurement-only build (wrong results): the K-step without its activation row sums (4 v_dot4 per A fragment)
-            if (j == 0) {
+            if (!BF && j == 0) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) asum[i] += bytesum16(af[ks][i]);
             }
@@ -709,6 +723,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
 
     // ---- linear epilogues: fp32 / fp16 rows, raw int32 (test hook), split-K partials ----------------------------------------
     constexpr bool INT_OUT = OUT == O_PART || OUT == O_I32;
+    constexpr bool H16_OUT = OUT == O_F16, B16_OUT = OUT == O_BF16;
     const bool has_rb = p.rowbias != nullptr, has_res = p.residual != nullptr;
     const bool vec = p.vec != 0;
     float*  const of = reinterpret_cast<float*>(p.out);
@@ -719,7 +734,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
     // optional GroupNorm statistics of the tensor being written (consumed by qd_groupnorm_silu_quant instead of its own
     // pass over HBM): per-column partials of the lane's rows -> butterfly over the 8 lanes that share the columns ->
     // fixed-order LDS reduction over the waves of each 128-row chunk -> one {sum, sumsq} pair per (chunk, channel).
-    const bool gn = (OUT == O_F32 || OUT == O_F16) && p.gnpart != nullptr;   // statistics of the fp32 values (before an fp16 store)
+    const bool gn = (OUT == O_F32 || OUT == O_F16 || OUT == O_BF16) && p.gnpart != nullptr;   // statistics of the fp32 values (before a 16-bit store)
     float* sGn = reinterpret_cast<float*>(smem + 4 * 4096);       // [4 waves][WCOLS][2], behind the transposition tiles
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -739,9 +754,11 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
             for (int r = 0; r < 16; ++r) {
                 const int rl = crow(r) + 4 * fhalf;
                 if constexpr (INT_OUT) {
-                    const int v = OUT == O_PART ? acc[i][j][r] - __mul24(zw_n, sAsum[rbase + rl])
-                                                : acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rbase + rl] - kz);
+                    const int v = OUT == O_PART ? (int)acc[i][j][r] - __mul24(zw_n, sAsum[rbase + rl])
+                                                : (int)acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rbase + rl] - kz);
                     tb[rl * 32 + frow] = (unsigned)v;
+                } else if constexpr (BF) {
+                    tb[rl * 32 + frow] = __float_as_uint((float)acc[i][j][r] + bias_n);
                 } else {
                     const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rbase + rl] - kz);
                     float v = (float)I * sc;
@@ -789,6 +806,13 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) rs[ps][e] = n4 + e < p.Cout ? src[e] : 0.f;
                             }
+                        } else if (B16_OUT) {
+                            const unsigned short* src = reinterpret_cast<const unsigned short*>(p.residual) + mrow[ps] * p.ldr + n4c;
+                            if (vec && nok4) rs[ps] = qd_ld4bf(src);
+                            else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) rs[ps][e] = n4 + e < p.Cout ? qd_bf2f(src[e]) : 0.f;
+                            }
                         } else {
                             const __half* src = rh + mrow[ps] * p.ldr + n4c;
                             if (vec && nok4) rs[ps] = qd_ld4h(src);
@@ -813,6 +837,14 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
                             else {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) if (n4 + e < p.Cout) dst[e] = v[e];
+                            }
+                        } else if (B16_OUT) {
+                            unsigned short* dst = reinterpret_cast<unsigned short*>(p.out) + mrow[ps] * p.ldo + n4;
+                            if (vec && nok4) qd_st4bf(dst, v);
+                            else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (n4 + e < p.Cout) dst[e] = (unsigned short)(qd_pack2bf(v[e], 0.f) & 0xffffu);
                             }
                         } else {
                             __half* dst = oh + mrow[ps] * p.ldo + n4;
@@ -1012,13 +1044,17 @@ int dispatch(ConvD& k, bool split, int out, hipStream_t st, int nsplit = 1) {
         hipLaunchKernelGGL((igemm_kernel<MT, NT, WM, WN, SP, O, WB>), grid, block, 0, st, k);       \
         return 0;                                                                                   \
     }
-    QD_CASE(false, O_F32)
-    QD_CASE(false, O_F16)
-    if constexpr (MT == 1 && WM == 4) { QD_CASE(false, O_I32) QD_CASE(true, O_F32) QD_CASE(true, O_F16) QD_CASE(false, O_PART) }
-    if constexpr (WB == 4 && WM == 4) { QD_CASE(false, O_HROWS) QD_CASE(false, O_HTR) }
-    if constexpr (NT == 4 && WB == 4 && WM == 4) { QD_CASE(false, O_GEGLU) }
+    if constexpr (WB == 16) {
+        QD_CASE(false, O_F32) QD_CASE(false, O_BF16)
+    } else {
+        QD_CASE(false, O_F32)
+        QD_CASE(false, O_F16)
+        if constexpr (MT == 1 && WM == 4) { QD_CASE(false, O_I32) QD_CASE(true, O_F32) QD_CASE(true, O_F16) QD_CASE(false, O_PART) }
+        if constexpr (WB == 4 && WM == 4) { QD_CASE(false, O_HROWS) QD_CASE(false, O_HTR) }
+        if constexpr (NT == 4 && WB == 4 && WM == 4) { QD_CASE(false, O_GEGLU) }
+    }
 #undef QD_CASE
-    qd_set_error("qd_conv2d_i8: unsupported variant split=%d out=%d tile %dx%d", (int)split, out, BM, BN);
+    qd_set_error("qd_conv2d_%s: unsupported variant split=%d out=%d tile %dx%d", WB == 16 ? "bf16" : "i8", (int)split, out, BM, BN);
     return 1;
 }
 
@@ -1208,7 +1244,108 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
     return 0;
 }
 
+// bf16 mode of the same kernel (first-stage decoder).  The descriptor's ldx / c0 / clen count bf16 ELEMENTS; the loader
+// works in bytes.
+int run_bf16(const qd_conv_desc* d, void* stream) {
+    QD_REQUIRE(d != nullptr, "qd_conv2d_bf16: null descriptor");
+    QD_REQUIRE(d->x && d->w && d->out, "qd_conv2d_bf16: null tensor pointer");
+    QD_REQUIRE(d->w_tiled && d->wbits == 16, "qd_conv2d_bf16: weights must come from qd_pack_weights_bf16 (w_tiled = 1, wbits = 16)");
+    QD_REQUIRE(!d->upsample2x || (d->stride == 1 && d->kh * d->kw > 1 && d->H % 2 == 0 && d->W % 2 == 0 && d->pad_t < 8 && d->pad_l < 8),
+               "qd_conv2d_bf16: upsample2x needs stride 1, more than one tap, even H and W");
+    QD_REQUIRE(d->out_dtype == QD_F32 || d->out_dtype == QD_BF16, "qd_conv2d_bf16: out_dtype must be f32/bf16");
+    QD_REQUIRE(d->nseg == 1 && d->epilogue == QD_EPI_LINEAR && !d->rowbias, "qd_conv2d_bf16: one segment, linear epilogue, no row bias");
+    QD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, "qd_conv2d_bf16: bad shape");
+    QD_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->kh * d->kw <= 32, "qd_conv2d_bf16: bad kernel/stride (at most 32 taps)");
+    QD_REQUIRE((long)d->B * d->Ho * d->Wo < (1L << 31), "qd_conv2d_bf16: M overflows int32");
+    QD_REQUIRE((long)d->B * d->H * d->W * d->ldx * 2 < (1L << 32), "qd_conv2d_bf16: activation exceeds the 4-GiB offset range");
+    QD_REQUIRE(d->ldx % 8 == 0 && qd_aligned(d->x, 16) && qd_aligned(d->w, 16), "qd_conv2d_bf16: x/w must be 16-byte aligned, ldx %% 8 == 0");
+    const qd_conv_seg& g = d->seg[0];
+    QD_REQUIRE(g.clen > 0 && g.clen % 8 == 0 && g.c0 % 8 == 0 && g.c0 + g.clen <= d->ldx, "qd_conv2d_bf16: c0/clen must be multiples of 8 inside the row");
+    ConvD k{};
+    k.x = reinterpret_cast<const int8_t*>(d->x); k.wt = d->w; k.out = d->out;
+    k.bias = d->bias; k.residual = d->residual;
+    k.ldx = d->ldx * 2; k.ldo = d->ldo; k.ldr = d->ldr;
+    k.B = d->B; k.H = d->H; k.W = d->W; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout;
+    k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad_t = d->pad_t; k.pad_l = d->pad_l;
+    k.M = d->B * d->Ho * d->Wo; k.taps = d->kh * d->kw; k.nseg = 1;
+    k.pointwise = k.taps == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->H == d->Ho && d->W == d->Wo;
+    k.ups = d->upsample2x ? 1 : 0;
+    k.ntiles = (d->Cout + 31) / 32;
+    k.seg[0] = SegD{g.c0 * 2, g.clen * 2, g.kstep0, (g.clen * 2 + 63) / 64, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t esz = d->out_dtype == QD_BF16 ? 2 : 4;
+    k.vec = d->Cout % 4 == 0 && d->ldo % 4 == 0 && qd_aligned(d->out, 4 * esz) &&
+            (!d->residual || (d->ldr % 4 == 0 && qd_aligned(d->residual, 4 * esz)));
+    if (d->gn_part) {
+        QD_REQUIRE((d->Ho * d->Wo) % 128 == 0, "qd_conv2d_bf16: gn_part needs Ho*Wo %% 128 == 0");
+        k.gnpart = d->gn_part;
+        k.gn_nchunk = d->Ho * d->Wo / 128;
+        QD_REQUIRE(d->gn_ld == 0 || d->gn_ld >= d->Cout, "qd_conv2d_bf16: gn_ld must be 0 or >= Cout");
+        k.gn_ld = d->gn_ld ? (long)d->gn_ld : (long)d->Cout;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int N = d->Cout, out = d->out_dtype == QD_BF16 ? O_BF16 : O_F32;
+    const long M = k.M;
+    static const int force_mt = getenv("QD_BF16_MT") ? atoi(getenv("QD_BF16_MT")) : 0;       // tuning knob: 1 / 2, 0 = heuristic
+    const bool mt2 = force_mt ? force_mt == 2 : ((M + 255) / 256) * ((N + 127) / 128) >= 256;
+    int rc;
+    if (N > 64) rc = mt2 ? dispatch<2, 4, 4, 1, 16>(k, false, out, st) : dispatch<1, 4, 4, 1, 16>(k, false, out, st);
+    else rc = dispatch<1, 2, 4, 1, 16>(k, false, out, st);
+    if (rc) return rc;
+    QD_LAUNCH_CHECK("qd_conv2d_bf16");
+    return 0;
+}
+
+// fp32 OIHW (or [N, K] linear) weights -> bf16 (round to nearest even) in the tile order of the bf16 mode: K-step (32
+// channels of one tap) x 32-output-channel tile = 2 KB as [k-half (16 ch)][lane-half (8 ch)][n % 32][8 bf16].
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, int clen_pad,
+                                                        uint8_t* __restrict__ wt, int ntiles, int nsteps_tap) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)taps * nsteps_tap * ntiles * 128;
+    if (gid >= total) return;
+    const int nn = (int)(gid & 31);
+    const int kh4 = (int)((gid >> 5) & 3);           // (k-half, lane-half): 8 channels each
+    long rest = gid >> 7;
+    const int jt = (int)(rest % ntiles);
+    rest /= ntiles;
+    const int cs = (int)(rest % nsteps_tap);
+    const int t = (int)(rest / nsteps_tap);
+    const int n = jt * 32 + nn;
+    const int cbase = cs * 32 + kh4 * 8;
+    v4i pk;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        float f[2] = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = cbase + gq * 2 + e;
+            if (n < Cout && c < Cin) f[e] = w[((long)n * Cin + c) * taps + t];
+        }
+        pk[gq] = (int)qd_pack2bf(f[0], f[1]);
+    }
+    const long kstep = (long)t * nsteps_tap + cs;
+    *reinterpret_cast<v4i*>(wt + (kstep * ntiles + jt) * 2048 + (kh4 * 32 + nn) * 16) = pk;
+}
+
 }  // namespace
+
+extern "C" int qd_conv2d_bf16(const qd_conv_desc* d, void* stream) { return run_bf16(d, stream); }
+
+extern "C" int64_t qd_pack_weights_bf16_bytes(int Cout, int taps, int clen_pad) {
+    return (int64_t)taps * ((clen_pad + 31) / 32) * ((Cout + 31) / 32) * 2048;
+}
+
+extern "C" int qd_pack_weights_bf16(const float* w, int Cout, int Cin, int taps, int clen_pad, uint8_t* wt, void* stream) {
+    QD_REQUIRE(w && wt, "qd_pack_weights_bf16: null pointer");
+    QD_REQUIRE(Cout > 0 && taps > 0 && Cin > 0, "qd_pack_weights_bf16: bad shape");
+    QD_REQUIRE(clen_pad % 8 == 0 && clen_pad >= Cin, "qd_pack_weights_bf16: clen_pad must be a multiple of 8 and >= Cin");
+    QD_REQUIRE(qd_aligned(wt, 16), "qd_pack_weights_bf16: wt must be 16-byte aligned");
+    const int ntiles = (Cout + 31) / 32, nsteps_tap = (clen_pad + 31) / 32;
+    const long total = (long)taps * nsteps_tap * ntiles * 128;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       w, Cout, Cin, taps, clen_pad, wt, ntiles, nsteps_tap);
+    QD_LAUNCH_CHECK("qd_pack_weights_bf16");
+    return 0;
+}
 
 extern "C" int64_t qd_conv2d_i8_splitk_ws_bytes(const qd_conv_desc* d) {
     if (!d) return 0;

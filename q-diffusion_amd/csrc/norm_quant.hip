@@ -335,7 +335,66 @@ void dispatch_ln(int nvl, hipStream_t st, const void* x, long M, int C, long ldx
     }
 }
 
+// First-stage decoder (bf16 convolutions, fp32 residual stream): the apply pass with a bf16 output — thread = 8 consecutive
+// channels of one row (two 16-byte loads, one 16-byte store), same statistics passes and per-(sample, channel) affine.
+__global__ __launch_bounds__(256) void gn_apply_bf16_kernel(const float* __restrict__ x, long rows, long S, int C, long ldx,
+                                                            const float* __restrict__ ab, int apply_silu,
+                                                            unsigned short* __restrict__ out, long ldo) {
+    const int chunks = C >> 3;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= rows * chunks) return;
+    const long row = gid / chunks;
+    const int c = (int)(gid - row * chunks) * 8;
+    const long b = row / S;
+    const float4 x0 = *reinterpret_cast<const float4*>(x + row * ldx + c);
+    const float4 x1 = *reinterpret_cast<const float4*>(x + row * ldx + c + 4);
+    const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    float y[8];
+    const float* abp = ab + (b * C + c) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 t = *reinterpret_cast<const float4*>(abp + 4 * j);
+        y[2 * j] = v[2 * j] * t.x + t.y;
+        y[2 * j + 1] = v[2 * j + 1] * t.z + t.w;
+    }
+    if (apply_silu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = y[j] * (1.0f / (1.0f + expf(-y[j])));
+    }
+    v4i pk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pk[j] = (int)qd_pack2bf(y[2 * j], y[2 * j + 1]);
+    *reinterpret_cast<v4i*>(out + row * ldo + c) = pk;
+}
+
 }  // namespace
+
+// GroupNorm (+ SiLU) of fp32 NHWC rows into bf16 rows: the producer of the bf16 convolutions of the first-stage decoder
+// (reference ldm/modules/diffusionmodules/model.py:38-45 Normalize / nonlinearity in front of every convolution).
+// gamma / beta may be null (x * rstd - mean * rstd).
+extern "C" int qd_groupnorm_silu_bf16(const float* x, int64_t B, int64_t S, int C, int64_t ldx, int groups, float eps,
+                                      const float* gamma, const float* beta, int apply_silu, void* out, int64_t ldo, void* ws,
+                                      const float* part_in, int nchunk_in, int64_t part_ld, void* stream) {
+    QD_REQUIRE(x && out && ws, "qd_groupnorm_silu_bf16: null pointer");
+    QD_REQUIRE(B > 0 && S > 0 && C > 0 && groups > 0 && C % groups == 0 && C % 8 == 0, "qd_groupnorm_silu_bf16: C=%d must be a multiple of 8 and of groups=%d", C, groups);
+    QD_REQUIRE(ldx >= C && ldx % 4 == 0 && qd_aligned(x, 16) && ldo >= C && ldo % 8 == 0 && qd_aligned(out, 16), "qd_groupnorm_silu_bf16: rows must be 16-byte aligned");
+    QD_REQUIRE(B < 65536, "qd_groupnorm_silu_bf16: batch too large");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nchunk_own = (int)((S + gn_rows(S) - 1) / gn_rows(S));
+    float* part = reinterpret_cast<float*>(ws);
+    float* ab = part + (size_t)B * nchunk_own * C * 2;
+    QD_REQUIRE(!part_in || (nchunk_in > 0 && (part_ld == 0 || part_ld >= C)), "qd_groupnorm_silu_bf16: part_in needs nchunk_in > 0 and part_ld >= C");
+    const long ldp = part_in && part_ld ? (long)part_ld : (long)C;
+    const int nchunk = part_in ? nchunk_in : nchunk_own;
+    if (!part_in)
+        hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, x, (long)S, C, (long)ldx, part, nchunk, 1);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, (unsigned)B), dim3(64), 0, st, part_in ? part_in : part, nchunk, ldp, (long)S, C, groups, eps, gamma, beta, ab);
+    const long rows = B * S, total = rows * (C / 8);
+    hipLaunchKernelGGL(gn_apply_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, rows, (long)S, C, (long)ldx, ab, apply_silu,
+                       reinterpret_cast<unsigned short*>(out), (long)ldo);
+    QD_LAUNCH_CHECK("qd_groupnorm_silu_bf16");
+    return 0;
+}
 
 extern "C" int64_t qd_groupnorm_ws_bytes(int64_t B, int64_t C, int64_t S) {
     int64_t nchunk = (S + gn_rows(S) - 1) / gn_rows(S);

@@ -259,26 +259,34 @@ def lsun_beds_first_stage():
 
 @torch.no_grad()
 def decode_first_stage(first_stage, z, scale_factor=1.0, force_not_quantize=False, autocast_dtype=None, to_uint8=False,
-                       max_activation_bytes=1 << 30):
+                       max_activation_bytes=1 << 30, engine=None):
     """`LatentDiffusion.decode_first_stage` (ddpm.py:710-770, the un-tiled branch): images = decode(z / scale_factor).
     On the GPU the latents go channels-last (MIOpen NHWC convolutions); `autocast_dtype` reproduces the reference scripts'
     `precision=autocast` mode; `to_uint8` applies the scripts' clamp((x + 1) / 2, 0, 1) * 255 post-processing
     (txt2img.py: `torch.clamp((x_samples + 1.0) / 2.0, min=0.0, max=1.0)`) on the device.
     The batch is decoded in chunks whose largest activation (ch x H_out x W_out fp32 per image) stays below
     `max_activation_bytes`: library convolutions index with 32-bit byte offsets, and 64 LDM-4 images put exactly 2^31 bytes
-    into one tensor (measured: a GPU memory fault inside the convolution; the reference decodes its small script batches)."""
+    into one tensor (measured: a GPU memory fault inside the convolution; the reference decodes its small script batches).
+    `engine="hip"`: the `Decoder` runs on this package's bf16 MFMA convolution / GroupNorm kernels (qdiff.first_stage_hip;
+    GPU only, raises without the library) instead of the library convolutions; `autocast_dtype` is then ignored."""
     dec = first_stage.decoder
     up = 2 ** (dec.num_resolutions - 1)
     per_image = dec.ch * z.shape[2] * up * z.shape[3] * up * 4
     chunk = max(1, int(max_activation_bytes // max(per_image, 1)))
     if z.shape[0] > chunk:
         return torch.cat([decode_first_stage(first_stage, z[i:i + chunk], scale_factor, force_not_quantize, autocast_dtype, to_uint8,
-                                             max_activation_bytes) for i in range(0, z.shape[0], chunk)], dim=0)
+                                             max_activation_bytes, engine) for i in range(0, z.shape[0], chunk)], dim=0)
     z = (1.0 / scale_factor) * z
     if z.is_cuda:
         z = z.contiguous(memory_format=torch.channels_last)
     kw = dict(force_not_quantize=force_not_quantize) if isinstance(first_stage, VQModelDecoder) else {}
-    if autocast_dtype is not None and z.is_cuda:
+    if engine == "hip":
+        from ..first_stage_hip import hip_decoder
+        quant = z if (not isinstance(first_stage, VQModelDecoder) or force_not_quantize) else first_stage.quantize(z)
+        x = hip_decoder(first_stage.decoder)(first_stage.post_quant_conv(quant).float())
+    elif engine is not None:
+        raise ValueError(f"decode_first_stage: unknown engine {engine!r}")
+    elif autocast_dtype is not None and z.is_cuda:
         with torch.autocast("cuda", dtype=autocast_dtype):
             x = first_stage.decode(z, **kw)
     else:

@@ -1,0 +1,157 @@
+"""First-stage decoder on the hand-written bf16 kernels.
+
+`HipDecoder(decoder)` evaluates a `qdiff.arch.first_stage.Decoder` (the reference's ldm/modules/diffusionmodules/model.py:465-572
+`Decoder.forward`) with every convolution on `qd_conv2d_bf16` — the bf16 mode of the implicit-GEMM kernel the quantised UNet
+runs on (csrc/igemm_dma.hip: v_mfma_f32_32x32x16_bf16, LDS-DMA ring) — and every GroupNorm (+ swish) on
+`qd_groupnorm_silu_bf16`.  Data layout in HBM:
+
+* the residual stream h is fp32 channels-last rows [B*H*W][C] (what a residual block adds to is never rounded);
+* every convolution INPUT is bf16 rows written by the GroupNorm that precedes it (model.py:121-137: norm -> swish -> conv) —
+  one read of the fp32 stream, half the bytes written, and the first-level statistics of that read come with the tensor
+  (the epilogue of the convolution that produced it wrote them: qd_conv_desc.gn_part), so a GroupNorm is one finalise + one
+  apply launch;
+* `Upsample` (model.py:48-63) never materialises the 4x map: the convolution gathers from the half-resolution rows
+  (`upsample2x`);
+* the single-head 4096-token mid-block attention (model.py:144-196) takes q | k | v from ONE 1x1 convolution with bf16 output
+  and runs torch's scaled_dot_product_attention on them (plumbing; 1 % of the decoder's arithmetic).
+
+Weights are rounded to bf16 once (`qd_pack_weights_bf16`, tile order); accumulation, bias, residual adds, GroupNorm
+statistics and swish are fp32.  The result therefore differs from the fp32 reference by bf16 operand rounding only;
+tests/test_first_stage.py states the bound.  There is no fallback: without the library or a GPU this raises.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import hip
+
+
+class _Conv:
+    __slots__ = ("wt", "bias", "cin_pad", "cout", "k", "pad")
+
+    def __init__(self, weight, bias, device):
+        w = weight.detach().to(device=device, dtype=torch.float32)
+        if w.dim() == 2:
+            w = w[:, :, None, None]
+        self.cout, cin, self.k = w.shape[0], w.shape[1], w.shape[2]
+        if w.shape[2] != w.shape[3] or self.k not in (1, 3):
+            raise hip.HipEngineError(f"first-stage convolution {tuple(w.shape)}: only 1x1 / 3x3")
+        self.pad = self.k // 2
+        self.cin_pad = hip.pad8(cin)
+        self.wt = hip.pack_weights_bf16(w)
+        self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class HipDecoder:
+    """Runs `decoder` (qdiff.arch.first_stage.Decoder, eval mode) on the bf16 kernels.  Packed weights are built on first use
+    per device and dropped by `invalidate()` (call it after loading another state dict)."""
+
+    def __init__(self, decoder):
+        if decoder.give_pre_end or decoder.tanh_out:
+            raise hip.HipEngineError("HipDecoder: give_pre_end / tanh_out decoders are not used by the reference's configs")
+        self.dec = decoder
+        self._packs = {}
+
+    def invalidate(self):
+        self._packs.clear()
+
+    # ---- weights ----
+    def _conv(self, dev, key, mod):
+        p = self._packs.get((dev, key))
+        if p is None:
+            p = self._packs[(dev, key)] = _Conv(mod.weight, mod.bias, dev)
+        return p
+
+    def _qkv(self, dev, key, attn):
+        p = self._packs.get((dev, key))
+        if p is None:
+            w = torch.cat([attn.q.weight, attn.k.weight, attn.v.weight], dim=0)
+            b = torch.cat([attn.q.bias, attn.k.bias, attn.v.bias], dim=0)
+            p = self._packs[(dev, key)] = _Conv(w, b, dev)
+        return p
+
+    # ---- launches ----
+    @staticmethod
+    def _part(B, S, C, dev):
+        """first-level GroupNorm statistics written by a convolution's epilogue (128-row chunks inside one sample)"""
+        return torch.empty((B, S // 128, C, 2), dtype=torch.float32, device=dev) if S % 128 == 0 else None
+
+    def _run_conv(self, c, x, B, H, W, out_dtype=torch.float32, residual=None, stats=True, upsample2x=False):
+        M = B * H * W
+        out = torch.empty((M, c.cout), dtype=out_dtype, device=x.device)
+        part = self._part(B, H * W, c.cout, x.device) if stats else None
+        hip.conv2d_bf16(x, c.wt, c.bias, out, B, H, W, c.cin_pad, c.cout, k=c.k, pad=c.pad, residual=residual, gn_part=part,
+                        upsample2x=upsample2x)
+        return out, part
+
+    @staticmethod
+    def _norm(norm, x, part, B, S, silu):
+        C = norm.num_channels
+        out = torch.empty((B * S, C), dtype=torch.bfloat16, device=x.device)
+        ws = torch.empty(hip.groupnorm_ws_bytes(B, C, S), dtype=torch.uint8, device=x.device)
+        hip.groupnorm_silu_bf16(x, B, S, C, norm.num_groups, norm.eps, norm.weight.detach().float(), norm.bias.detach().float(),
+                                silu, out, ws, part=part)
+        return out
+
+    def _resblock(self, key, blk, x, part, B, H, W):
+        dev, S = x.device, H * W
+        if blk.use_conv_shortcut and blk.in_channels != blk.out_channels:
+            raise hip.HipEngineError("HipDecoder: 3x3 conv_shortcut residual blocks are not used by the reference's decoders")
+        a = self._norm(blk.norm1, x, part, B, S, True)
+        h1, p1 = self._run_conv(self._conv(dev, key + ".conv1", blk.conv1), a, B, H, W)
+        b = self._norm(blk.norm2, h1, p1, B, S, True)
+        if blk.in_channels != blk.out_channels:
+            x, _ = self._run_conv(self._conv(dev, key + ".nin", blk.nin_shortcut), x.to(torch.bfloat16), B, H, W, stats=False)
+        return self._run_conv(self._conv(dev, key + ".conv2", blk.conv2), b, B, H, W, residual=x)
+
+    def _attn(self, key, att, x, part, B, H, W):
+        dev, S, C = x.device, H * W, att.in_channels
+        hn = self._norm(att.norm, x, part, B, S, False)
+        qkv, _ = self._run_conv(self._qkv(dev, key + ".qkv", att), hn, B, H, W, out_dtype=torch.bfloat16, stats=False)
+        q, k, v = (qkv[:, i * C:(i + 1) * C].reshape(B, 1, S, C) for i in range(3))
+        o = F.scaled_dot_product_attention(q, k, v, scale=int(C) ** (-0.5)).reshape(B * S, C).contiguous()
+        return self._run_conv(self._conv(dev, key + ".proj", att.proj_out), o, B, H, W, residual=x)
+
+    @torch.no_grad()
+    def __call__(self, z):
+        """z: fp32 [B, z_channels, h, w] on the GPU (after post_quant_conv) -> fp32 [B, out_ch, H, W] (NCHW view of NHWC rows)"""
+        if not z.is_cuda:
+            raise hip.HipEngineError("HipDecoder: the latents must live in GPU memory (no host path)")
+        d, dev = self.dec, z.device
+        B, zc, H, W = z.shape
+        if B * H * W * 4 ** (d.num_resolutions - 1) * max(d.ch, 8) * 4 >= 1 << 32:
+            raise hip.HipEngineError("HipDecoder: batch too large for 32-bit row offsets; decode in chunks (decode_first_stage does)")
+        cin = self._conv(dev, "conv_in", d.conv_in)
+        x0 = torch.zeros((B * H * W, cin.cin_pad), dtype=torch.bfloat16, device=dev)
+        x0[:, :zc] = z.permute(0, 2, 3, 1).reshape(B * H * W, zc)
+        h, part = self._run_conv(cin, x0, B, H, W)
+        h, part = self._resblock("mid.block_1", d.mid.block_1, h, part, B, H, W)
+        if hasattr(d.mid.attn_1, "proj_out"):
+            h, part = self._attn("mid.attn_1", d.mid.attn_1, h, part, B, H, W)
+        h, part = self._resblock("mid.block_2", d.mid.block_2, h, part, B, H, W)
+        for i_level in reversed(range(d.num_resolutions)):
+            stage = d.up[i_level]
+            for i_block in range(d.num_res_blocks + 1):
+                h, part = self._resblock(f"up.{i_level}.block.{i_block}", stage.block[i_block], h, part, B, H, W)
+                if len(stage.attn) > 0:
+                    h, part = self._attn(f"up.{i_level}.attn.{i_block}", stage.attn[i_block], h, part, B, H, W)
+            if i_level != 0:
+                if stage.upsample.with_conv:
+                    H, W = 2 * H, 2 * W
+                    h, part = self._run_conv(self._conv(dev, f"up.{i_level}.upsample", stage.upsample.conv), h.to(torch.bfloat16),
+                                             B, H, W, upsample2x=True)
+                else:
+                    C = h.shape[1]
+                    h = h.view(B, H, 1, W, 1, C).expand(B, H, 2, W, 2, C).reshape(B * 4 * H * W, C)
+                    H, W, part = 2 * H, 2 * W, None
+        a = self._norm(d.norm_out, h, part, B, H * W, True)
+        out, _ = self._run_conv(self._conv(dev, "conv_out", d.conv_out), a, B, H, W, stats=False)
+        return out.view(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def hip_decoder(decoder):
+    """the HipDecoder of a Decoder module (kept on the module, so packed weights are built once)"""
+    hd = decoder.__dict__.get("_hip_decoder")
+    if hd is None:
+        hd = HipDecoder(decoder)
+        decoder.__dict__["_hip_decoder"] = hd
+    return hd

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # QDIFF_HIP_LIB: an alternative build of the same library (q-diffusion_amd/build.py --variant ...), for A/B measurements
 LIB_PATH = os.environ.get("QDIFF_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libqdiff_hip.so")
 
-F32, F16 = 0, 1
+F32, F16, BF16 = 0, 1, 2
 _DT = {torch.float32: F32, torch.float16: F16}
 
 
@@ -65,7 +65,8 @@ EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_make_qparams",
            "qd_conv2d_i8", "qd_conv2d_i8_splitk_ws_bytes",
            "qd_conv2d_i8_acc", "qd_groupnorm_ws_bytes", "qd_groupnorm_silu_quant", "qd_groupnorm_mod_silu_quant", "qd_layernorm_quant",
            "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8", "qd_bmm_qk_i8", "qd_bmm_pv_i8", "qd_temb_mlp",
-           "qd_fakequant_blocks", "qd_fakequant_fwd", "qd_fakequant_bwd"]
+           "qd_fakequant_blocks", "qd_fakequant_fwd", "qd_fakequant_bwd",
+           "qd_conv2d_bf16", "qd_pack_weights_bf16_bytes", "qd_pack_weights_bf16", "qd_groupnorm_silu_bf16"]
 
 _lib = None
 
@@ -111,7 +112,12 @@ def load():
     lib.qd_fakequant_blocks.argtypes = [i64]
     lib.qd_fakequant_fwd.argtypes = [vp, i64, vp, vp, i32, i32, vp, vp]
     lib.qd_fakequant_bwd.argtypes = [vp, vp, i64, vp, vp, i32, i32, vp, vp, vp]
-    if lib.qd_abi_version() != 16:
+    lib.qd_conv2d_bf16.argtypes = [ctypes.POINTER(ConvDesc), vp]
+    lib.qd_pack_weights_bf16_bytes.restype = ctypes.c_int64
+    lib.qd_pack_weights_bf16_bytes.argtypes = [i32, i32, i32]
+    lib.qd_pack_weights_bf16.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    lib.qd_groupnorm_silu_bf16.argtypes = [vp, i64, i64, i32, i64, i32, f32, vp, vp, i32, vp, i64, vp, vp, i32, i64, vp]
+    if lib.qd_abi_version() != 17:
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -289,6 +295,56 @@ def _conv_desc(c):
         g.wzp, g.fill16 = _ptr(s.get("wzp"), "wzp"), _ptr(s.get("fill16"), "fill16")
         g.scale, g.zc, g.zw, g.zfill = _ptr(s["scale"], "scale"), _ptr(s.get("zc")), _ptr(s.get("zw")), _ptr(s.get("zfill"))
     return d
+
+
+# ---- first-stage decoder: bf16 mode of the convolution kernel (include/qdiff_hip.h, "First-stage decoder") ----
+
+def pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def pack_weights_bf16(w):
+    """fp32 [Cout][Cin][kh][kw] (or [Cout][Cin]) -> tile-ordered bf16 bytes for qd_conv2d_bf16 (Cin padded to 8)."""
+    w = w.detach().float().contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    taps = w[0, 0].numel()
+    cpad = pad8(Cin)
+    wt = torch.zeros(int(load().qd_pack_weights_bf16_bytes(Cout, taps, cpad)), dtype=torch.uint8, device=w.device)
+    _check(load().qd_pack_weights_bf16(_ptr(w, "w"), Cout, Cin, taps, cpad, _ptr(wt), _stream()), "qd_pack_weights_bf16")
+    return wt
+
+
+def conv2d_bf16(x, wt, bias, out, B, H, W, Cin_pad, Cout, k=3, pad=1, residual=None, gn_part=None, upsample2x=False):
+    """x: bf16 rows [B*Hin*Win][ldx] (Hin = H/2 when upsample2x, the kernel folds the nearest-2x copy into its gather);
+    out: fp32 or bf16 rows [B*H*W][ldo]; residual: rows of the output's type; stride-1 'same' convolution k x k."""
+    if x.dtype != torch.bfloat16 or out.dtype not in (torch.float32, torch.bfloat16):
+        raise HipEngineError("conv2d_bf16: x must be bf16, out fp32 / bf16")
+    if residual is not None and residual.dtype != out.dtype:
+        raise HipEngineError("conv2d_bf16: the residual has the type of the output")
+    d = ConvDesc()
+    d.x, d.w, d.out = _ptr(x, "x"), _ptr(wt, "w"), _ptr(out, "out")
+    d.bias, d.residual = _ptr(bias, "bias"), _ptr(residual, "residual")
+    d.ldx, d.ldo, d.ldr = x.stride(0), out.stride(0), residual.stride(0) if residual is not None else 0
+    d.B, d.H, d.W, d.Ho, d.Wo, d.Cout = B, H, W, H, W, Cout
+    d.kh = d.kw = k
+    d.stride, d.pad_t, d.pad_l = 1, pad, pad
+    d.wbits, d.w_tiled, d.epilogue = 16, 1, EPI_LINEAR
+    d.out_dtype = BF16 if out.dtype == torch.bfloat16 else F32
+    d.gn_part = _ptr(gn_part, "gn_part")
+    if gn_part is not None:
+        d.gn_ld = part_ld(gn_part)
+    d.upsample2x = 1 if upsample2x else 0
+    d.nseg = 1
+    d.seg[0].c0, d.seg[0].clen = 0, Cin_pad
+    _check(load().qd_conv2d_bf16(ctypes.byref(d), _stream()), "qd_conv2d_bf16")
+
+
+def groupnorm_silu_bf16(x, B, S, C, groups, eps, gamma, beta, silu, out, ws, part=None):
+    """fp32 rows [B*S][ldx] -> GroupNorm (+ SiLU) -> bf16 rows [B*S][ldo]; part: first-level statistics of the producer."""
+    nchunk, pld = (part.shape[1], part_ld(part)) if part is not None else (0, 0)
+    _check(load().qd_groupnorm_silu_bf16(_ptr(x, "x"), B, S, C, x.stride(0), groups, float(eps), _ptr(gamma), _ptr(beta),
+                                         1 if silu else 0, _ptr(out, "out"), out.stride(0), _ptr(ws, "ws"), _ptr(part), nchunk,
+                                         pld, _stream()), "qd_groupnorm_silu_bf16")
 
 
 def groupnorm_ws_bytes(B, C, S):

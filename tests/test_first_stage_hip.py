@@ -1,0 +1,185 @@
+"""N1 on this package's own kernels: the bf16 mode of the implicit-GEMM convolution (qd_conv2d_bf16), its weight packer,
+the GroupNorm(+swish) -> bf16 producer, and the whole `Decoder` (qdiff/first_stage_hip.py) against
+
+* a plain PyTorch fp32/fp64 evaluation of the SAME bf16-rounded operands (kernel level: only the fp32 accumulation order
+  differs), and
+* the outputs of the REAL reference Decoder (tests/golden/first_stage.pt; ldm/modules/diffusionmodules/model.py:465-572)
+  at a stated bf16 bound (decoder level: operand rounding of every convolution input and weight to bf16).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import load_fixture
+from test_first_stage import _build
+
+# kernel level: exact bf16 products, fp32 accumulation -> a few 1e-6 of the output range; bf16 outputs add half an ulp
+# (8 significand bits: spacing 2^-7 relative just above a power of two)
+ACC_TOL = 2e-5
+BF16_ULP = 2.0 ** -7
+# decoder level: every convolution input and weight rounded to bf16 (relative 2^-9 each), ~30 convolutions deep
+DECODER_TOL = 2.5e-2
+
+
+def test_hip_engine_has_no_host_path():
+    """no CPU fallback behind engine='hip': latents in host memory raise"""
+    from qdiff import hip
+    from qdiff.arch import first_stage as fs
+    fx = load_fixture("first_stage.pt")
+    m = _build(fx["kl_tiny"], "kl")
+    with pytest.raises(hip.HipEngineError):
+        fs.decode_first_stage(m, fx["kl_tiny"]["z"], 1.0, engine="hip")
+    with pytest.raises(ValueError):
+        fs.decode_first_stage(m, fx["kl_tiny"]["z"], 1.0, engine="cuda")
+
+
+def _bits(t):
+    return t.contiguous().view(torch.int16).cpu().numpy().astype(np.uint16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cout,Cin,k", [(70, 20, 3), (32, 64, 1), (3, 128, 3)])
+def test_bf16_weight_packer_layout(cuda, Cout, Cin, k):
+    """include/qdiff_hip.h: per (tap, 32-channel K-step, 32-output-channel tile) 2 KB as [k-half][lane-half][n % 32][8 bf16],
+    round to nearest even, zero padding"""
+    from qdiff import hip
+    g = torch.Generator().manual_seed(Cout * 131 + Cin)
+    w = torch.randn(Cout, Cin, k, k, generator=g)
+    wt = hip.pack_weights_bf16(w.to(cuda)).cpu().numpy().view(np.uint16)
+    taps, cpad = k * k, hip.pad8(Cin)
+    nst, ntl = (cpad + 31) // 32, (Cout + 31) // 32
+    want = np.zeros(taps * nst * ntl * 1024, dtype=np.uint16)
+    wb = _bits(w.bfloat16()).reshape(Cout, Cin, taps)
+    n, c, t = np.meshgrid(np.arange(Cout), np.arange(Cin), np.arange(taps), indexing="ij")
+    off = ((t * nst + c // 32) * ntl + n // 32) * 1024 + (((c % 32) // 8) * 32 + n % 32) * 8 + c % 8
+    want[off.ravel()] = wb.ravel()
+    assert wt.shape == want.shape and np.array_equal(wt, want)
+
+
+def _conv_case(cuda, B, H, W, Cin, Cout, k, out_dtype, residual, ups, seed):
+    from qdiff import hip
+    g = torch.Generator().manual_seed(seed)
+    hin, win = (H // 2, W // 2) if ups else (H, W)
+    cpad = hip.pad8(Cin)
+    x = torch.zeros(B, hin, win, cpad)
+    x[..., :Cin] = torch.randn(B, hin, win, Cin, generator=g)
+    xb = x.bfloat16()
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (Cin * k * k) ** -0.5
+    bias = torch.randn(Cout, generator=g)
+    res = torch.randn(B * H * W, Cout, generator=g).to(out_dtype) if residual else None
+    # reference: the same rounded operands, fp64
+    xr = xb[..., :Cin].double().permute(0, 3, 1, 2)
+    if ups:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xr, w.bfloat16().double(), bias.double(), padding=k // 2).permute(0, 2, 3, 1).reshape(B * H * W, Cout)
+    if residual:
+        ref = ref + res.double()
+    wt = hip.pack_weights_bf16(w.to(cuda))
+    out = torch.full((B * H * W, Cout), float("nan"), dtype=out_dtype, device=cuda)
+    part = torch.empty((B, H * W // 128, Cout, 2), dtype=torch.float32, device=cuda) if (H * W) % 128 == 0 else None
+    hip.conv2d_bf16(xb.reshape(-1, cpad).to(cuda), wt, bias.to(cuda), out, B, H, W, cpad, Cout, k=k, pad=k // 2,
+                    residual=None if res is None else res.to(cuda), gn_part=part, upsample2x=ups)
+    torch.cuda.synchronize()
+    return out.cpu(), ref, (None if part is None else part.cpu())
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, out dtype, residual, upsample2x
+    (2, 8, 8, 4, 64, 3, torch.float32, False, False),          # conv_in: 4 channels padded to 8, one partial K-step
+    (1, 16, 16, 64, 128, 3, torch.float32, True, False),       # 128-wide tile, fp32 residual, GroupNorm statistics
+    (2, 16, 16, 128, 128, 3, torch.float32, True, False),
+    (1, 32, 32, 40, 96, 3, torch.float32, False, False),       # K tail inside a K-step, N tail inside a tile
+    (1, 16, 24, 64, 3, 3, torch.float32, False, False),        # conv_out: 3 output channels (scalar stores)
+    (3, 16, 16, 96, 288, 1, torch.bfloat16, False, False),     # q | k | v: 1x1, bf16 rows
+    (1, 16, 16, 32, 64, 1, torch.bfloat16, True, False),       # bf16 residual
+    (2, 32, 32, 64, 64, 3, torch.float32, False, True),        # Upsample folded into the gather
+    (1, 64, 128, 128, 128, 3, torch.float32, True, False),     # 8192 rows
+    (8, 64, 64, 128, 128, 3, torch.float32, False, False),     # 256-row tiles (>= 256 blocks of 256 x 128)
+    (8, 64, 64, 64, 256, 3, torch.bfloat16, False, True),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v).replace("torch.", "") for v in c))
+def test_conv2d_bf16_equals_fp64_on_the_rounded_operands(cuda, case):
+    B, H, W, Cin, Cout, k, odt, residual, ups = case
+    out, ref, part = _conv_case(cuda, B, H, W, Cin, Cout, k, odt, residual, ups, seed=hash(case[:6]) % 1000)
+    assert torch.isfinite(out.float()).all()
+    scale = ref.abs().max().item()
+    tol = ACC_TOL * scale if odt == torch.float32 else (ACC_TOL + BF16_ULP / 2) * scale
+    err = (out.double() - ref).abs().max().item()
+    assert err <= tol, (err, tol)
+    if part is not None and odt == torch.float32:
+        # first-level GroupNorm statistics of the fp32 values: per (sample, 128-row chunk, channel) sum and sum of squares
+        v = ref.reshape(B, H * W // 128, 128, Cout)
+        want = torch.stack([v.sum(2), (v * v).sum(2)], dim=-1)
+        assert (part.double() - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,S,C,silu,own_stats", [(2, 64, 64, True, True), (2, 1024, 128, True, False), (1, 4096, 512, False, False),
+                                                  (3, 256, 32, True, True)])
+def test_groupnorm_silu_bf16(cuda, B, S, C, silu, own_stats):
+    """GroupNorm(32, C, eps=1e-6) (+ swish) of fp32 rows, written as bf16: the fp32 result of torch rounded once"""
+    from qdiff import hip
+    g = torch.Generator().manual_seed(C + S)
+    x = torch.randn(B * S, C, generator=g) * 3 + 0.5
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    xn = x.reshape(B, S, C).permute(0, 2, 1).double()
+    y = F.group_norm(xn, 32, gamma.double(), beta.double(), eps=1e-6)
+    if silu:
+        y = y * torch.sigmoid(y)
+    ref = y.permute(0, 2, 1).reshape(B * S, C)
+    part = None
+    if not own_stats:
+        v = x.double().reshape(B, S // 128, 128, C)
+        part = torch.stack([v.sum(2), (v * v).sum(2)], dim=-1).float().to(cuda)
+    out = torch.empty((B * S, C), dtype=torch.bfloat16, device=cuda)
+    ws = torch.empty(hip.groupnorm_ws_bytes(B, C, S), dtype=torch.uint8, device=cuda)
+    hip.groupnorm_silu_bf16(x.to(cuda), B, S, C, 32, 1e-6, gamma.to(cuda), beta.to(cuda), silu, out, ws, part=part)
+    err = (out.cpu().double() - ref).abs()
+    assert (err <= BF16_ULP / 2 * ref.abs() + 2e-5 * ref.abs().max()).all(), err.max().item()
+
+
+@pytest.mark.gpu
+def test_hip_decoder_matches_the_reference_golden(cuda):
+    """The whole Decoder on the bf16 kernels vs the reference's fp32 CPU output, KL-f8- and VQ-f4-shaped.  The bound is the
+    bf16 envelope stated at the top; the library's own bf16 autocast of the same module is reported beside it."""
+    from qdiff.arch import first_stage as fs
+    fx = load_fixture("first_stage.pt")
+    for name, kind in (("kl_tiny", "kl"), ("vq_tiny", "vq")):
+        case = fx[name]
+        m = _build(case, kind).to(cuda)
+        z = case["z"].to(cuda)
+        out = fs.decode_first_stage(m, z, 1.0, force_not_quantize=True, engine="hip")
+        assert out.shape == case["out"].shape and out.dtype == torch.float32
+        scale = case["out"].abs().max().item()
+        err = (out.cpu() - case["out"]).abs().max().item() / scale
+        auto = fs.decode_first_stage(m, z, 1.0, force_not_quantize=True, autocast_dtype=torch.bfloat16)
+        err_auto = (auto.float().cpu() - case["out"]).abs().max().item() / scale
+        print(f"{name}: hip bf16 decoder max err {err:.3e} of range (library bf16 autocast: {err_auto:.3e})")
+        assert err <= DECODER_TOL, (name, err)
+        # chunked decode and the uint8 post-processing go through the same engine
+        img = fs.decode_first_stage(m, torch.cat([z, z]), 1.0, force_not_quantize=True, engine="hip", to_uint8=True,
+                                    max_activation_bytes=m.decoder.ch * 32 * 32 * 4 * z.shape[0])
+        want = (torch.clamp((out + 1.0) / 2.0, 0.0, 1.0) * 255.0).round().to(torch.uint8)
+        assert torch.equal(img[:z.shape[0]], want) and torch.equal(img[z.shape[0]:], want)
+
+
+@pytest.mark.gpu
+def test_hip_decoder_sd_shape_smoke(cuda):
+    """one SD-v1 latent (4 x 64 x 64 -> 3 x 512 x 512) through the KL-f8 decoder with key-derived synthetic weights: the bf16
+    kernels against the fp32 library path on the same device"""
+    from qdiff import synthetic
+    from qdiff.arch import first_stage as fs
+    m, _ = fs.sd_v1_first_stage()
+    m.load_state_dict({k: synthetic.tensor_for(k, v.shape, seed=0) for k, v in m.state_dict().items()})
+    m = m.eval().to(cuda)
+    z = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(3)).to(cuda)
+    ref = fs.decode_first_stage(m, z, 1.0)
+    out = fs.decode_first_stage(m, z, 1.0, engine="hip")
+    scale = ref.abs().max().item()
+    err = (out - ref).abs().max().item() / scale
+    print(f"sd kl-f8 decoder: hip bf16 vs library fp32 max err {err:.3e} of range")
+    assert out.shape == (1, 3, 512, 512) and err <= DECODER_TOL
