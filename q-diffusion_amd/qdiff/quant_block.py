@@ -216,6 +216,9 @@ class EmbGroup:
 
 
 _CTX_BRANCH = os.environ.get("QDIFF_CTX_BRANCH", "1") != "0"     # A/B knob for measurements only
+# where the context branch forks off the main stream: "start" = the model's forward pre-hook (before the stem), "attn" = right
+# before the first self-attention kernel of the first transformer block, "late" = at the first cross-attention (= its join)
+_CTX_FORK = os.environ.get("QDIFF_CTX_FORK", "start")
 _FUSE_SKIP_QUANT = os.environ.get("QDIFF_FUSE_SKIP_QUANT", "1") != "0"     # A/B knob: skip-connection rows from the GroupNorm pass
 CAT_SLOTS = os.environ.get("QDIFF_CAT_SLOTS", "1") != "0"         # A/B knob: planned skip-concatenation buffers (engine.CatSlot)
 
@@ -225,10 +228,20 @@ class ContextKV:
     to_k / to_v of attn2 (reference quant_block.py:190-221, ldm attention.py:152-198) see only the conditioning `context`
     — [B, 77, 768] for SD — never the latent: 16 blocks x (row quantiser + two skinny GEMMs on B*77 rows + head-layout
     quantisers) = ~130 tiny dependent launches per evaluation that no single one of can fill the chip (~1.3 ms of an SD
-    evaluation when serialised into the main stream).  The first block that meets a new context tensor forks a branch
-    that prepares the int8 attention operands of every block while the main stream runs the stem / first residual
-    blocks / self-attention; the first cross-attention joins it.  Under HIP-graph capture the fork / join become
-    parallel branches of the graph.  Results are those of the in-line path bit for bit (same kernels, same inputs)."""
+    evaluation when serialised into the main stream).  The branch (`start`) prepares the int8 attention operands of every
+    block while the main stream does other work; the first cross-attention joins it.  Under HIP-graph capture the fork /
+    join become parallel branches of the graph.  Results are those of the in-line path bit for bit (same kernels, same
+    inputs).  Where it forks (`_CTX_FORK`, env QDIFF_CTX_FORK):
+      late   in `get`, i.e. AFTER the first self-attention and immediately before the join — what round 2 shipped: the
+             rocprofv3 timeline profiles/r03_sd_eval_timeline.tsv shows the 148 launches of the branch running alone for
+             1.07 ms (traced) with the main stream waiting;
+      start  (default) the model's forward pre-hook, before the stem: the branch runs under the stem / first residual block
+             / first self-attention.  It does overlap (profiles/r03_ctx_fork_ab.md), but those are launches of exactly one
+             wave of blocks (512 blocks on 256 CUs x 2): a branch kernel that holds a few slots at the wrong moment pushes
+             the last blocks of the big kernel into a second wave (82 -> 141 us on one of them) — net -0.12 ms per SD
+             evaluation (21.37 -> 21.25, A/B/A/B on one box), not the 0.5 ms the serial chain costs;
+      attn   right before the first self-attention KERNEL of the first transformer block (4096 blocks, 1.0 ms): +0.2 ms —
+             the attention kernel loses more to the stolen slots than the branch saves."""
 
     def __init__(self):
         self.members = []
@@ -245,11 +258,16 @@ class ContextKV:
             torch.cuda.current_stream().wait_stream(self._side)
         self._ctx, self._out, self._joined = None, None, True
 
-    def get(self, blk, context):
-        """(k8, v8, vsum) of blk.attn2 for this context, or None (in-line path)."""
-        if self._ctx is not context:
+    def start(self, context):
+        """Fork the branch for this evaluation's context (no-op for a context already started, for None, and whenever
+        `_prepare` finds a module that is not ready for the integer path: `get` then answers None = in-line path)."""
+        if context is not None and self._ctx is not context:
             self._ctx, self._out = context, None
             self._prepare(context)
+
+    def get(self, blk, context):
+        """(k8, v8, vsum) of blk.attn2 for this context, or None (in-line path)."""
+        self.start(context)
         if self._out is None:
             return None
         if not self._joined:
@@ -726,7 +744,7 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
         x = self.attn2(self.norm2(x), context=context) + x
         return self.ff(self.norm3(x)) + x
 
-    def _attn_int(self, att, rows, B, T, C, ln, ctx_rows, S, kv=None):
+    def _attn_int(self, att, rows, B, T, C, ln, ctx_rows, S, kv=None, pre_attention=None):
         """norm -> q/k/v projections -> fused quantised attention -> to_out (+ residual rows).
         kv: (k8, v8, vsum) prepared ahead of time for this block's context (ContextKV), else they are computed here."""
         h = att.heads
@@ -758,6 +776,8 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
         if kv is None:
             operand(att.to_k, xk, 1, S, k8)
             operand(att.to_v, xv, 2, S, v8)
+        if pre_attention is not None:
+            pre_attention()                     # the next launch on this stream is the attention kernel
         out_lin = att.to_out[0]
         if out_lin.act_quantizer.inited and out_lin.conv_plan().ldx == inner and len(out_lin.conv_plan().segs) == 1:
             # the attention epilogue quantises its output for to_out[0]: no fp32 round trip
@@ -771,12 +791,13 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
         rows = x.reshape(B * T, C)
         if rows.stride(1) != 1 or rows.stride(0) != C:
             rows = rows.contiguous()
-        rows = self._attn_int(self.attn1, rows, B, T, C, self.norm1, None, T)
+        grp = self.__dict__.get("_ctx_group")
+        fork = (lambda: grp.start(context)) if (grp is not None and context is not None and _CTX_FORK == "attn") else None
+        rows = self._attn_int(self.attn1, rows, B, T, C, self.norm1, None, T, pre_attention=fork)
         if context is None:
             rows = self._attn_int(self.attn2, rows, B, T, C, self.norm2, None, T)
         else:
             S = context.shape[1]
-            grp = self.__dict__.get("_ctx_group")
             kv = grp.get(self, context) if grp is not None else None
             ctx = None
             if kv is None:

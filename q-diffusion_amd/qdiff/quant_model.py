@@ -83,8 +83,13 @@ class QuantModel(nn.Module):
         for m in self.model.modules():
             if isinstance(m, QuantBasicTransformerBlock):
                 ctx.register(m)
+        # QDIFF_CTX_FORK=start: the context branch forks HERE, before the stem (`context` is the third positional argument of
+        # every UNet this package wraps; QuantModel.forward passes it positionally); see quant_block.ContextKV
+        from . import quant_block as _qb
         self.model.register_forward_pre_hook(lambda _m, _a: (group.reset(), ctx.reset(), engine.begin_evaluation(id(self)),
-                                                             self._select_stream()) and None)
+                                                             self._select_stream(),
+                                                             ctx.start(_a[2]) if _qb._CTX_FORK == "start" and len(_a) > 2 and torch.is_tensor(_a[2])
+                                                             else None) and None)
         self.model.register_forward_hook(lambda _m, _a, _o: ctx.finish(), always_call=True)
         te = getattr(self.model, "time_embed", None)
         if (isinstance(te, nn.Sequential) and len(te) == 3 and isinstance(te[0], QuantModule) and isinstance(te[2], QuantModule)

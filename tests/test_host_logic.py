@@ -569,3 +569,37 @@ def test_bench_cpu_baseline_leg_runs_on_the_host(monkeypatch):
     ocfg = dict(ch=128, ch_mult=[1, 2, 2, 2], num_res_blocks=2, attn_resolutions=[16], resolution=32)
     dt, threads, sweep = bench.cpu_baseline(qnn, qspec, "cifar", ocfg, k=1)
     assert dt > 0 and threads >= 1 and str(threads) in sweep
+
+
+def test_context_branch_fork_points(emu, monkeypatch):
+    """Where the cross-attention K / V branch (ContextKV) forks off the main stream — QDIFF_CTX_FORK = late (at the first
+    cross-attention, where the fork coincided with the join and the 148 launches of the branch ran alone:
+    profiles/r03_sd_eval_timeline.tsv), start (the model's forward pre-hook, before the stem), attn (right before the first
+    self-attention kernel) — changes the ORDER of the launches only: one branch per evaluation, the same output bit for bit."""
+    from qdiff import engine
+    from qdiff import quant_block as qb
+    fx = load_fixture("model_sd_tiny.pt")
+    x, t, c = fixture_inputs(fx, "test")
+    outs, orders = {}, {}
+    for mode in ("late", "start", "attn"):
+        monkeypatch.setattr(qb, "_CTX_FORK", mode)
+        qnn = _resume_cpu(fx)
+        grp = next(m for m in qnn.modules() if isinstance(m, qb.QuantBasicTransformerBlock)).__dict__["_ctx_group"]
+        events = []
+        prepare0, conv0, attn0 = grp._prepare, engine.conv_forward, engine.attention_codes
+        grp._prepare = lambda ctx, _p=prepare0: (events.append("fork" if ctx is c else "fork?"), _p(ctx), events.append("branch done"))[1]
+        monkeypatch.setattr(engine, "conv_forward", lambda *a, **k: (events.append("gemm"), conv0(*a, **k))[1])
+        monkeypatch.setattr(engine, "attention_codes", lambda *a, **k: (events.append("attention"), attn0(*a, **k))[1])
+        with torch.no_grad():
+            outs[mode] = qnn(x, t, c)
+        monkeypatch.setattr(engine, "conv_forward", conv0)
+        monkeypatch.setattr(engine, "attention_codes", attn0)
+        assert events.count("fork") == 1 and "fork?" not in events, "one branch per evaluation, for the context the UNet was given"
+        orders[mode] = events
+    assert torch.equal(outs["late"], outs["start"]) and torch.equal(outs["late"], outs["attn"])
+    assert orders["start"][0] == "fork", "before the stem"
+    for mode, n_before in (("attn", 0), ("late", 1)):
+        ev = orders[mode]
+        i = ev.index("fork")
+        assert ev[:i].count("attention") == n_before and "gemm" in ev[:i], (mode, ev[:i])
+        assert ev[ev.index("branch done") + 1] == "attention"      # attn: the first self-attention kernel; late: the first cross-attention
