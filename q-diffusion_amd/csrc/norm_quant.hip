@@ -75,6 +75,48 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     }
 }
 
+// finalize for long chunk lists (first-stage decoder: 512 x 512 maps = 2048 chunks of 128 rows, 4-16 channels per group —
+// the 64-thread kernel above walks 128-512 strided loads per thread there, 30-130 us): 256 threads, same fp64 sums in a
+// fixed order (thread-strided partial sums, wave butterflies, then the four wave results in wave order).
+__global__ __launch_bounds__(256) void gn_finalize_wide_kernel(const float* __restrict__ part, int nchunk, long ldp, long S, int C,
+                                                               int groups, float eps, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ ab) {
+    __shared__ double red[8];
+    const int g = blockIdx.x;
+    const long b = blockIdx.y;
+    const int cpg = C / groups;
+    double s = 0.0, q = 0.0;
+    const int items = nchunk * cpg;
+    for (int i = threadIdx.x; i < items; i += 256) {
+        int chunk = i / cpg, c = g * cpg + i % cpg;
+        const float* p = part + (((b * nchunk + chunk) * ldp) + c) * 2;
+        s += (double)p[0];
+        q += (double)p[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        q += __shfl_xor(q, o);
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red[4 + (threadIdx.x >> 6)] = q; }
+    __syncthreads();
+    s = ((red[0] + red[1]) + red[2]) + red[3];
+    q = ((red[4] + red[5]) + red[6]) + red[7];
+    const double n = (double)S * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float fmean = (float)mean;
+    for (int i = threadIdx.x; i < cpg; i += 256) {
+        int c = g * cpg + i;
+        float a = rstd * (gamma ? gamma[c] : 1.f);
+        float sh = (beta ? beta[c] : 0.f) - fmean * a;
+        ab[(b * C + c) * 2] = a;
+        ab[(b * C + c) * 2 + 1] = sh;
+    }
+}
+
 // use_scale_shift_norm residual blocks (reference quant_block.py:99-103: `out_norm(h) * (1 + scale) + shift`, scale | shift =
 // the two halves of the block's embedding projection, one row per sample): the modulation is folded into the per-(sample,
 // channel) affine the apply pass already uses — a' = a (1 + scale), sh' = sh (1 + scale) + shift — so the apply pass and its
@@ -388,7 +430,10 @@ extern "C" int qd_groupnorm_silu_bf16(const float* x, int64_t B, int64_t S, int 
     const int nchunk = part_in ? nchunk_in : nchunk_own;
     if (!part_in)
         hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, x, (long)S, C, (long)ldx, part, nchunk, 1);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, (unsigned)B), dim3(64), 0, st, part_in ? part_in : part, nchunk, ldp, (long)S, C, groups, eps, gamma, beta, ab);
+    if ((long)nchunk * (C / groups) >= 2048)
+        hipLaunchKernelGGL(gn_finalize_wide_kernel, dim3(groups, (unsigned)B), dim3(256), 0, st, part_in ? part_in : part, nchunk, ldp, (long)S, C, groups, eps, gamma, beta, ab);
+    else
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, (unsigned)B), dim3(64), 0, st, part_in ? part_in : part, nchunk, ldp, (long)S, C, groups, eps, gamma, beta, ab);
     const long rows = B * S, total = rows * (C / 8);
     hipLaunchKernelGGL(gn_apply_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, rows, (long)S, C, (long)ldx, ab, apply_silu,
                        reinterpret_cast<unsigned short*>(out), (long)ldo);

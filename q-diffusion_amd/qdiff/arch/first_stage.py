@@ -115,7 +115,7 @@ class Decoder(nn.Module):
                  **ignorekwargs):
         super().__init__()
         assert attn_type in ("vanilla", "none"), "linear attention is not used by any first-stage config of the reference"
-        self.ch, self.temb_ch = ch, 0
+        self.ch, self.temb_ch, self.ch_mult_last = ch, 0, ch_mult[len(ch_mult) - 1]
         self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
         self.resolution, self.in_channels = resolution, in_channels
         self.give_pre_end, self.tanh_out = give_pre_end, tanh_out
@@ -257,6 +257,22 @@ def lsun_beds_first_stage():
     return VQModelDecoder(dd, embed_dim=3, n_embed=8192), 1.0
 
 
+def largest_activation_bytes(dec, h, w):
+    """fp32 bytes per image of the largest tensor `Decoder.forward` materialises for an h x w latent: not the output-
+    resolution stream (ch x H x W) but the nearest-2x copy in front of the LAST upsampling convolution, which still has the
+    channel count of the level below (SD KL-f8: 256 x 512 x 512 = twice the 128-channel stream)."""
+    c = dec.ch * dec.ch_mult_last
+    best = c * h * w
+    for i_level in reversed(range(dec.num_resolutions)):
+        c = max(c, dec.up[i_level].block[0].out_channels)
+        best = max(best, c * h * w)
+        c = dec.up[i_level].block[0].out_channels
+        if i_level != 0:
+            h, w = 2 * h, 2 * w
+            best = max(best, c * h * w)
+    return 4 * best
+
+
 @torch.no_grad()
 def decode_first_stage(first_stage, z, scale_factor=1.0, force_not_quantize=False, autocast_dtype=None, to_uint8=False,
                        max_activation_bytes=1 << 30, engine=None):
@@ -264,14 +280,15 @@ def decode_first_stage(first_stage, z, scale_factor=1.0, force_not_quantize=Fals
     On the GPU the latents go channels-last (MIOpen NHWC convolutions); `autocast_dtype` reproduces the reference scripts'
     `precision=autocast` mode; `to_uint8` applies the scripts' clamp((x + 1) / 2, 0, 1) * 255 post-processing
     (txt2img.py: `torch.clamp((x_samples + 1.0) / 2.0, min=0.0, max=1.0)`) on the device.
-    The batch is decoded in chunks whose largest activation (ch x H_out x W_out fp32 per image) stays below
+    The batch is decoded in chunks whose largest activation (`largest_activation_bytes`) stays below
     `max_activation_bytes`: library convolutions index with 32-bit byte offsets, and 64 LDM-4 images put exactly 2^31 bytes
     into one tensor (measured: a GPU memory fault inside the convolution; the reference decodes its small script batches).
+    Until the end of round 3 the estimate was the output-resolution stream (ch x H_out x W_out), half the true maximum: 8 SD
+    latents put exactly 2^31 bytes into the upsampled 256 x 512 x 512 tensor, which the library survived or not depending
+    on the allocator state of the process (`bench.py --decode` faulted once in four runs).
     `engine="hip"`: the `Decoder` runs on this package's bf16 MFMA convolution / GroupNorm kernels (qdiff.first_stage_hip;
     GPU only, raises without the library) instead of the library convolutions; `autocast_dtype` is then ignored."""
-    dec = first_stage.decoder
-    up = 2 ** (dec.num_resolutions - 1)
-    per_image = dec.ch * z.shape[2] * up * z.shape[3] * up * 4
+    per_image = largest_activation_bytes(first_stage.decoder, z.shape[2], z.shape[3])
     chunk = max(1, int(max_activation_bytes // max(per_image, 1)))
     if z.shape[0] > chunk:
         return torch.cat([decode_first_stage(first_stage, z[i:i + chunk], scale_factor, force_not_quantize, autocast_dtype, to_uint8,

@@ -114,6 +114,11 @@ def test_decode_chunks_large_batches():
     m = _build(case, "kl")
     z = torch.cat([case["z"], case["z"] * 0.5, -case["z"]], dim=0)           # 6 latents
     whole = fs.decode_first_stage(m, z, 1.0)
-    per_image = m.decoder.ch * 32 * 32 * 4
+    per_image = fs.largest_activation_bytes(m.decoder, 8, 8)
+    # ch = 32, ch_mult (1, 2, 2): the largest tensor is the nearest-2x copy in front of the last upsampling convolution,
+    # 64 channels at 32 x 32 — twice the 32-channel output-resolution stream
+    assert per_image == 64 * 32 * 32 * 4
+    sd, _ = fs.sd_v1_first_stage()
+    assert fs.largest_activation_bytes(sd.decoder, 64, 64) == 256 * 512 * 512 * 4      # 8 images = 2^31 bytes: chunks of 4
     parts = fs.decode_first_stage(m, z, 1.0, max_activation_bytes=2 * per_image)   # chunks of 2
     assert parts.shape == whole.shape and torch.equal(parts, whole)
