@@ -115,7 +115,7 @@ class Decoder(nn.Module):
                  **ignorekwargs):
         super().__init__()
         assert attn_type in ("vanilla", "none"), "linear attention is not used by any first-stage config of the reference"
-        self.ch, self.temb_ch, self.ch_mult_last = ch, 0, ch_mult[len(ch_mult) - 1]
+        self.ch, self.temb_ch = ch, 0
         self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
         self.resolution, self.in_channels = resolution, in_channels
         self.give_pre_end, self.tanh_out = give_pre_end, tanh_out
@@ -261,7 +261,7 @@ def largest_activation_bytes(dec, h, w):
     """fp32 bytes per image of the largest tensor `Decoder.forward` materialises for an h x w latent: not the output-
     resolution stream (ch x H x W) but the nearest-2x copy in front of the LAST upsampling convolution, which still has the
     channel count of the level below (SD KL-f8: 256 x 512 x 512 = twice the 128-channel stream)."""
-    c = dec.ch * dec.ch_mult_last
+    c = dec.conv_in.out_channels
     best = c * h * w
     for i_level in reversed(range(dec.num_resolutions)):
         c = max(c, dec.up[i_level].block[0].out_channels)
