@@ -17,7 +17,8 @@ runs on (csrc/igemm_dma.hip: v_mfma_f32_32x32x16_bf16, LDS-DMA ring) — and eve
 
 Weights are rounded to bf16 once (`qd_pack_weights_bf16`, tile order); accumulation, bias, residual adds, GroupNorm
 statistics and swish are fp32.  The result therefore differs from the fp32 reference by bf16 operand rounding only;
-tests/test_first_stage.py states the bound.  There is no fallback: without the library or a GPU this raises.
+tests/test_first_stage_hip.py states the bound (and runs this wiring on CPU against tests/abi_emulator.py).  There is no
+fallback: without the library or a GPU the first launch wrapper raises.
 """
 import torch
 import torch.nn.functional as F
@@ -114,9 +115,7 @@ class HipDecoder:
     @torch.no_grad()
     def __call__(self, z):
         """z: fp32 [B, z_channels, h, w] on the GPU (after post_quant_conv) -> fp32 [B, out_ch, H, W] (NCHW view of NHWC rows)"""
-        if not z.is_cuda:
-            raise hip.HipEngineError("HipDecoder: the latents must live in GPU memory (no host path)")
-        d, dev = self.dec, z.device
+        d, dev = self.dec, z.device             # (host tensors: the first launch wrapper raises — there is no host path)
         B, zc, H, W = z.shape
         if B * H * W * 4 ** (d.num_resolutions - 1) * max(d.ch, 8) * 4 >= 1 << 32:
             raise hip.HipEngineError("HipDecoder: batch too large for 32-bit row offsets; decode in chunks (decode_first_stage does)")

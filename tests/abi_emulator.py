@@ -332,9 +332,80 @@ def splitk_ws_bytes(c):
     return 0
 
 
+# ---- first-stage decoder entry points (include/qdiff_hip.h "First-stage decoder"; qdiff.hip wrappers of the same names) ----
+
+def pack_weights_bf16(w):
+    """fp32 OIHW -> bf16 in the tile order of qd_pack_weights_bf16: per (tap, 32-channel K-step, 32-output-channel tile)
+    2 KB as [k-half (16 ch)][lane-half (8 ch)][n % 32][8 bf16]; returned as the uint8 buffer the kernel would read."""
+    w = w.detach().float()
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    Cout, Cin = w.shape[0], w.shape[1]
+    taps = w.shape[2] * w.shape[3]
+    cpad = (Cin + 7) // 8 * 8
+    nst, ntl = (cpad + 31) // 32, (Cout + 31) // 32
+    buf = torch.zeros(taps * nst * ntl * 1024, dtype=torch.int16)
+    bits = w.reshape(Cout, Cin, taps).bfloat16().view(torch.int16)
+    n, c, t = torch.meshgrid(torch.arange(Cout), torch.arange(Cin), torch.arange(taps), indexing="ij")
+    off = ((t * nst + c // 32) * ntl + n // 32) * 1024 + (((c % 32) // 8) * 32 + n % 32) * 8 + c % 8
+    buf[off.reshape(-1)] = bits.reshape(-1)
+    return buf.view(torch.uint8)
+
+
+def _unpack_weights_bf16(wt, Cout, cpad, taps):
+    nst, ntl = (cpad + 31) // 32, (Cout + 31) // 32
+    buf = wt.view(torch.int16)
+    n, c, t = torch.meshgrid(torch.arange(Cout), torch.arange(cpad), torch.arange(taps), indexing="ij")
+    off = ((t * nst + c // 32) * ntl + n // 32) * 1024 + (((c % 32) // 8) * 32 + n % 32) * 8 + c % 8
+    return buf[off.reshape(-1)].view(torch.bfloat16).float().reshape(Cout, cpad, taps)
+
+
+def conv2d_bf16(x, wt, bias, out, B, H, W, Cin_pad, Cout, k=3, pad=1, residual=None, gn_part=None, upsample2x=False):
+    """out[m][n] = sum_k x w + bias[n] (+ residual[m][n]); exact bf16 products, fp32 accumulation (here: fp64, rounded once);
+    x rows are at half resolution when upsample2x (nearest-2x folded into the gather)."""
+    assert x.dtype == torch.bfloat16 and out.dtype in (torch.float32, torch.bfloat16)
+    hin, win = (H // 2, W // 2) if upsample2x else (H, W)
+    w = _unpack_weights_bf16(wt, Cout, Cin_pad, k * k).reshape(Cout, Cin_pad, k, k)
+    xi = x[:, :Cin_pad].double().reshape(B, hin, win, Cin_pad).permute(0, 3, 1, 2)
+    if upsample2x:
+        xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+    y = F.conv2d(xi, w.double(), None if bias is None else bias.double(), padding=pad).permute(0, 2, 3, 1).reshape(B * H * W, Cout)
+    if residual is not None:
+        assert residual.dtype == out.dtype
+        y = y + residual.double()
+    y = y.float()
+    if gn_part is not None:
+        v = y.double().reshape(B, H * W // 128, 128, Cout)
+        gn_part.copy_(torch.stack([v.sum(2), (v * v).sum(2)], dim=-1).float())
+    out.copy_(y.to(out.dtype))
+
+
+def groupnorm_silu_bf16(x, B, S, C, groups, eps, gamma, beta, silu, out, ws, part=None):
+    """GroupNorm (+ swish) of fp32 rows -> bf16 rows; statistics from `part` ([B][chunks][C][2] sums / sums of squares) when
+    the producer supplied them.  y = x * a + sh with a = rstd * gamma, sh = beta - mean * a (the kernel's float order)."""
+    v = x[:, :C].reshape(B, S, C)
+    if part is not None:
+        s, q = part[..., 0].double().sum(1), part[..., 1].double().sum(1)            # [B, C]
+    else:
+        s, q = v.double().sum(1), (v.double() ** 2).sum(1)
+    cpg = C // groups
+    n = float(S * cpg)
+    mean = s.reshape(B, groups, cpg).sum(-1) / n
+    var = (q.reshape(B, groups, cpg).sum(-1) / n - mean * mean).clamp_min(0.0)
+    rstd = (1.0 / torch.sqrt(var + eps)).float().repeat_interleave(cpg, dim=1)       # [B, C]
+    fmean = mean.float().repeat_interleave(cpg, dim=1)
+    a = rstd * (gamma.float() if gamma is not None else 1.0)
+    sh = (beta.float() if beta is not None else 0.0) - fmean * a
+    y = v.float() * a[:, None, :] + sh[:, None, :]
+    if silu:
+        y = y * (1.0 / (1.0 + torch.exp(-y)))
+    out.copy_(y.reshape(B * S, C).to(torch.bfloat16))
+
+
 def install(monkeypatch):
     """Replace qdiff.hip's device entry points by the emulation (CPU tensors only)."""
     from qdiff import hip
     for name in ("make_qparams", "quantize_act", "pack_weights", "pack_weights_t4", "pack_weights_t8", "conv2d_i8", "groupnorm_ws_bytes", "groupnorm_silu_quant",
-                 "layernorm_quant", "geglu_quant", "quantize_heads", "attn_i8", "splitk_ws_bytes", "bmm_qk_i8", "bmm_pv_i8", "temb_mlp"):
+                 "layernorm_quant", "geglu_quant", "quantize_heads", "attn_i8", "splitk_ws_bytes", "bmm_qk_i8", "bmm_pv_i8", "temb_mlp",
+                 "pack_weights_bf16", "conv2d_bf16", "groupnorm_silu_bf16"):
         monkeypatch.setattr(hip, name, globals()[name])

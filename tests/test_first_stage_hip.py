@@ -34,6 +34,40 @@ def test_hip_engine_has_no_host_path():
         fs.decode_first_stage(m, fx["kl_tiny"]["z"], 1.0, engine="cuda")
 
 
+def test_hip_decoder_host_logic_on_the_abi_emulator(monkeypatch):
+    """HipDecoder's wiring (layouts, residuals, statistics hand-over, upsample fold, fused q | k | v, chunking) on CPU: the
+    launch wrappers are replaced by tests/abi_emulator.py — the header's contract for the four first-stage entry points
+    restated in torch, tile-ordered bf16 weights included — and the result is held against the REFERENCE golden at the bf16
+    bound of the GPU test."""
+    import abi_emulator
+    from qdiff.arch import first_stage as fs
+    abi_emulator.install(monkeypatch)
+    fx = load_fixture("first_stage.pt")
+    for name, kind in (("kl_tiny", "kl"), ("vq_tiny", "vq")):
+        case = fx[name]
+        m = _build(case, kind)
+        out = fs.decode_first_stage(m, case["z"], 1.0, force_not_quantize=True, engine="hip")
+        assert out.shape == case["out"].shape and out.dtype == torch.float32
+        err = (out - case["out"]).abs().max().item() / case["out"].abs().max().item()
+        assert err <= DECODER_TOL, (name, err)
+        two = fs.decode_first_stage(m, torch.cat([case["z"], case["z"]]), 1.0, force_not_quantize=True, engine="hip",
+                                    max_activation_bytes=fs.largest_activation_bytes(m.decoder, 8, 8) * case["z"].shape[0])
+        assert torch.equal(two[:out.shape[0]], out) and torch.equal(two[out.shape[0]:], out)
+
+
+def test_emulated_bf16_weight_layout_round_trips():
+    """the emulator's packer is the header's layout (the GPU test holds the kernel's packer against the same formula)"""
+    import abi_emulator
+    g = torch.Generator().manual_seed(1)
+    for Cout, Cin, k in ((70, 20, 3), (3, 128, 3), (96, 64, 1)):
+        w = torch.randn(Cout, Cin, k, k, generator=g)
+        wt = abi_emulator.pack_weights_bf16(w)
+        cpad = (Cin + 7) // 8 * 8
+        assert wt.numel() == k * k * ((cpad + 31) // 32) * ((Cout + 31) // 32) * 2048
+        back = abi_emulator._unpack_weights_bf16(wt, Cout, cpad, k * k)
+        assert torch.equal(back[:, :Cin], w.bfloat16().float().reshape(Cout, Cin, k * k)) and float(back[:, Cin:].abs().sum()) == 0
+
+
 def _bits(t):
     return t.contiguous().view(torch.int16).cpu().numpy().astype(np.uint16)
 
