@@ -120,5 +120,7 @@ def test_decode_chunks_large_batches():
     assert per_image == 64 * 32 * 32 * 4
     sd, _ = fs.sd_v1_first_stage()
     assert fs.largest_activation_bytes(sd.decoder, 64, 64) == 256 * 512 * 512 * 4      # 8 images = 2^31 bytes: chunks of 4
+    beds, _ = fs.lsun_beds_first_stage()
+    assert fs.largest_activation_bytes(beds.decoder, 64, 64) == 256 * 256 * 256 * 4    # 32 images = 2^31 bytes: chunks of 16
     parts = fs.decode_first_stage(m, z, 1.0, max_activation_bytes=2 * per_image)   # chunks of 2
     assert parts.shape == whole.shape and torch.equal(parts, whole)
