@@ -258,38 +258,87 @@ def cpu_baseline(qnn, qspec, kind, cfg, k=2):
     return dt, best, {str(n): round(v, 2) for n, v in sweep.items()}
 
 
-def first_stage_decode_ms(kind, n, dev, k=3):
-    """Latents -> images for the n images of one sampler batch (qdiff/arch/first_stage.py; not part of the denoising metric:
-    reported so that the end-to-end cost of an image is visible next to the 51 / 200 UNet evaluations it follows)."""
+DECODE_LEGS = {"fp32": (None, None), "bf16_autocast": (torch.bfloat16, None), "hip": (None, "hip")}
+
+
+def decode_leg(kind, n, leg, dev, k=3):
+    """ONE engine of the first-stage decode (child process of first_stage_decode): latents -> uint8 images for the n images
+    of a sampler batch (qdiff/arch/first_stage.py; reference ldm/models/autoencoder.py:330-333 + the scripts' clamp / scale).
+    The distance from the fp32 library decode is taken on the first latent only (one image: no chunking involved)."""
     from qdiff import synthetic
     from qdiff.arch import first_stage as fs
     m, scale = {"sd": fs.sd_v1_first_stage, "ldm": fs.lsun_beds_first_stage, "churches": fs.lsun_churches_first_stage}[kind]()
     synthetic.load_synthetic_weights(m, seed=0)
     m = m.to(dev).eval()
     z = torch.randn({"sd": (n, 4, 64, 64), "ldm": (n, 3, 64, 64), "churches": (n, 4, 32, 32)}[kind], device=dev)
-    res = {}
-    ref = None
-    for name, dt, eng in (("fp32", None, None), ("bf16_autocast", torch.bfloat16, None), ("hip_bf16", None, "hip")):
-        out = fs.decode_first_stage(m, z, scale, autocast_dtype=dt, engine=eng).float()
-        if ref is None:
-            ref = out
-        else:   # distance of the reduced-precision decoders from the fp32 library decode of the same latents
-            res[name + "_max_err_of_range"] = float(f"{((out - ref).abs().max() / ref.abs().max()).item():.3e}")
-        del out
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(k):
-            img = fs.decode_first_stage(m, z, scale, autocast_dtype=dt, to_uint8=True, engine=eng)
-        torch.cuda.synchronize()
-        res[name + "_ms_per_image"] = round((time.perf_counter() - t0) * 1000.0 / k / n, 3)
-    res["images"] = n
+    dt, eng = DECODE_LEGS[leg]
+    res = {"leg": leg, "images": n}
+    if leg != "fp32":
+        ref = fs.decode_first_stage(m, z[:1], scale).float()
+        out = fs.decode_first_stage(m, z[:1], scale, autocast_dtype=dt, engine=eng).float()
+        res["max_err_of_range_vs_fp32_library"] = float(f"{((out - ref).abs().max() / ref.abs().max()).item():.3e}")
+        del ref, out
+    img = fs.decode_first_stage(m, z, scale, autocast_dtype=dt, to_uint8=True, engine=eng)       # warm-up (packing, MIOpen find)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        img = fs.decode_first_stage(m, z, scale, autocast_dtype=dt, to_uint8=True, engine=eng)
+    torch.cuda.synchronize()
+    res["ms_per_image"] = round((time.perf_counter() - t0) * 1000.0 / k / n, 3)
     res["output"] = list(img.shape)
     return res
 
 
+def _child(argv, cap_s, tag):
+    """Run `bench.py <argv>` as a child process with a time cap; return its last JSON line or a record of how it ended.
+    The name of what is about to run goes to stderr BEFORE it starts, so that a GPU fault names its leg."""
+    import subprocess
+    print(f"[bench] child: {tag} ...", file=sys.stderr, flush=True)
+    t0 = time.time()
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True, timeout=cap_s, env=env)
+    except subprocess.TimeoutExpired:
+        print(f"[bench] child: {tag} hit its {cap_s} s cap", file=sys.stderr, flush=True)
+        return {"error": f"time cap {cap_s} s"}
+    dt = round(time.time() - t0, 1)
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        print(f"[bench] child: {tag} FAILED rc={r.returncode}\n{r.stderr[-2000:]}", file=sys.stderr, flush=True)
+        return {"error": f"rc {r.returncode}", "stderr_tail": r.stderr[-300:], "wall_s": dt}
+    print(f"[bench] child: {tag} ok in {dt} s", file=sys.stderr, flush=True)
+    d = json.loads(lines[-1])
+    d["wall_s"] = dt
+    return d
+
+
+def first_stage_decode(kind, n, legs=("fp32", "bf16_autocast", "hip"), cap_s=300):
+    """First-stage decode of the n images of one sampler batch, every engine in its OWN child process (a fault in one — round
+    3's library decode at exactly 2^31 bytes per activation — names itself and loses nothing else).  Not part of the denoising
+    metric: reported so that the end-to-end cost of an image is visible next to the 51 / 200 UNet evaluations it follows."""
+    return {leg: _child(["--decode-leg", leg, "--model", kind, "--images-per-gpu", str(n)], cap_s, f"first-stage decode, {leg}, {n} latents")
+            for leg in legs}
+
+
+def extra_lines(a):
+    """BASELINE.json configs 2 / 3 (CIFAR-10 W8A8, LDM-4 W4A8) and the first-stage decode on this package's own kernels, as
+    extra keys of the headline line: short runs in child processes with a time cap, started AFTER the headline numbers are
+    computed, so that nothing here can lose them."""
+    out = {}
+    common = ["--no-cpu-baseline", "--no-denominators", "--no-extras", "--steps", "10", "--warmup", "2"]
+    for kind, n in (("cifar", 64), ("ldm", 64)):
+        d = _child(["--model", kind, "--images-per-gpu", str(n)] + common, 240, f"{kind} line")
+        out[kind] = d if "error" in d else {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "wall_s") if k in d} | \
+            {"workload": d["config"]["workload"], "igemm_frac": d.get("roofline", {}).get("frac")}
+    out["first_stage_decode_sd"] = first_stage_decode("sd", a.images_per_gpu, legs=("hip",), cap_s=240)["hip"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: WORLD_SIZE when launched by torch.distributed.run, else 1")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--images-per-gpu", type=int, default=8, help="n images per GPU (UNet batch 2n with CFG)")
@@ -297,13 +346,26 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-denominators", action="store_true", help="skip the fp32 / fake-quant GPU denominators")
-    ap.add_argument("--decode", action="store_true", help="also time the first-stage decode of the image batch (sd / ldm / churches; extra field)")
+    ap.add_argument("--decode", action="store_true", help="also time the first-stage decode of the image batch, all three engines, "
+                    "each in its own child process (sd / ldm / churches; extra field)")
+    ap.add_argument("--decode-leg", default=None, choices=sorted(DECODE_LEGS), help="(child mode) time ONE decode engine and print its JSON line")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cifar / ldm / first-stage-decode child runs of the default SD line")
     ap.add_argument("--stream", default=None, choices=["fp32", "fp16"],
                     help="storage type of the inter-kernel activations (default: QDIFF_STREAM or fp32); fp16 = the precision the "
                          "reference scripts run at (--precision autocast); compute stays int8 MFMA / fp32 epilogues")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only (gloo, no GPU): prove that `python bench.py --gpus N` becomes N ranks; used by tests")
     a = ap.parse_args()
+    if a.gpus is None:                                  # `torchrun --nproc-per-node N bench.py` without --gpus: N ranks
+        a.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+
+    if a.decode_leg:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X")
+        print(f"[bench] decode leg {a.decode_leg}: {a.images_per_gpu} {a.model} latents", file=sys.stderr, flush=True)
+        with torch.no_grad():
+            print(json.dumps(decode_leg(a.model, a.images_per_gpu, a.decode_leg, torch.device("cuda", 0))))
+        return
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become N ranks of one node, one process per GPU (the driver's own command line,
@@ -490,7 +552,9 @@ def main():
                                                              f"{torch.get_num_threads()} threads): {dt:.1f} s each; extrapolated to {evals} evaluations x "
                                                              f"{2 if guide != 1.0 else 1} samples per image"}
         if a.decode and kind in ("sd", "ldm", "churches"):
-            out["first_stage_decode"] = first_stage_decode_ms(kind, n, dev)
+            out["first_stage_decode"] = first_stage_decode(kind, n)
+        if kind == "sd" and world == 1 and not a.no_extras:
+            out["other_configs"] = extra_lines(a)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

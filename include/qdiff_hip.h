@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 17
+#define QD_ABI_VERSION 18
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -312,17 +312,31 @@ int qd_geglu_quant(const void* h, int h_dtype, int64_t M, int F, int64_t ldh,
  *           consumes it (to_out[0], quant_block.py:221 -> quant_layer.py:256) and stored as its int8 input rows
  *           out8[b*T+t][ldo8] (K1 semantics; H*d must already be that Linear's padded input width).
  *     q_asym: 0 when zq' == 0 (symmetric q quantiser), else 1: the kernel then restores the per-key term
- *           -zq' * sum_d k'[j][d] with a constant-operand MFMA.  qsum / ksum are ignored (may be NULL; kept
- *           for source compatibility): the per-query terms -zk'*qsum_i + d*zq'*zk' are constant along a
- *           softmax row and cancel exactly.
+ *           -zq' * sum_d k'[j][d].  qsum is ignored (may be NULL): the per-query terms -zk'*qsum_i + d*zq'*zk' are
+ *           constant along a softmax row and cancel exactly.
+ *     kterm (ABI 18; the slot that used to be `ksum`): NULL, or the table qd_attn_keyterm wrote for THIS k operand and
+ *           THIS prm.  Head dims with qd_attn_uses_keyterm(d, q_asym) == 1 (d < 64, d % 32 != 0: SD's 4096-token level)
+ *           then seed the score accumulators from the table instead of issuing constant-operand MFMAs (2 of the 4
+ *           score MFMAs of a 32x32 tile carried no data); results are bit-identical with and without it.  Other head
+ *           dims ignore it.
+ *     qd_attn_keyterm: kterm[bh][j] = 0x4B400000 - zq' * sum_{c < dpad} k[bh][j][c]  (int32 [BH][Spad], dpad 32 or 64; pad
+ *           bytes of k are zero).  One pass over the K operand; recompute whenever k or prm[1] changes — a cross-attention
+ *           whose context is constant over a sampling run computes it once (quant_block.py:193-195 recomputes k per step).
+ *     qd_attn_config: process-wide launcher knobs, -1 = leave unchanged.  pipe_mode 0 = register-fed kernel everywhere,
+ *           2 = LDS-staged kernel where it pays (default), 3 = LDS-staged wherever eligible; xcd 0/1 = XCD-aware block
+ *           order; ktab 0 = ignore kterm (constant-operand MFMAs, A/B runs).  Initial values: QD_ATTN_PIPE / QD_ATTN_XCD /
+ *           QD_ATTN_KTAB, read once.
  * ------------------------------------------------------------------------------------------ */
 int qd_quantize_heads(const void* x, int x_dtype, int B, int T, int H, int d,
                       int64_t sb, int64_t st, int64_t sh, int64_t sd, float prescale,
                       const float* qparams, int qmin, int qmax, int off, int transpose,
                       int8_t* out, int32_t* rsum, int Tpad, int dpad, void* stream);
 
+int qd_attn_uses_keyterm(int d, int q_asym);
+int qd_attn_keyterm(const int8_t* k, int BH, int Spad, int dpad, const float* prm, int32_t* kterm, void* stream);
+void qd_attn_config(int pipe_mode, int xcd, int ktab);
 int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt,
-               const int32_t* qsum, const int32_t* ksum, const int32_t* vsum,
+               const int32_t* qsum, const int32_t* kterm, const int32_t* vsum,
                int BH, int H, int T, int S, int d, int Tpad, int Spad, int dpad,
                const float* prm, int wbits, int wmin, int wmax, int q_asym,
                float* out, int64_t ldo,

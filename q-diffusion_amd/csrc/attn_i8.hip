@@ -26,7 +26,8 @@ struct AttnK {
     const int8_t* k;
     const int8_t* vt;
     const int32_t* qsum;
-    const int32_t* ksum;
+    const int32_t* kterm;     // lean / LDS-staged kernels, KT == 2: [BH][Spad] accumulator seeds 0x4B400000 - zq' * sum_d k'[j][d]
+                              // (qd_attn_keyterm); NULL: the per-key term comes from constant-operand MFMAs (KT == 1)
     const int32_t* vsum;
     const float* prm;
     float* out;
@@ -302,24 +303,65 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_k
 }
 
 // ---- lean variant (head dims that are NOT a multiple of 32 and < 64: Stable Diffusion's 4096-token, d = 40 level) -----
-// Same mathematics, ~25 % fewer VALU instructions per score.  The 32x32 score tile costs VALU time, not matrix time, so:
-//   * no int->float converts: the MFMA accumulator starts at 0x4B400000 - rowmax (the bit pattern of 1.5*2^23, minus the
-//     integer row maximum), so its bits ARE the float 1.5*2^23 + (s - max), exactly, as long as |s - max| < 2^22 — the
-//     launcher guarantees that from d and the operand ranges (d * 128 * 256 * 2 < 2^22 <=> d < 64).  One packed FMA maps
-//     it to the log2 domain: fma(F, cs2, -fl(1.5*2^23*cs2)) = cs2*(s - max) + eps with ONE rounding; eps (the rounding of
-//     the constant) is the same for every score of both sweeps, i.e. a common factor 2^eps that cancels in e / sum(e);
+// Same mathematics, ~25 % fewer VALU instructions per score and (round 4) half the score MFMAs.  The 32x32 score tile costs
+// VALU AND matrix time (the two pipes of a SIMD do not overlap in this instruction mix, profiles/r03_attn_ablation.md), so:
+//   * no int->float converts and no per-tile accumulator initialisation: the MFMA accumulator starts at the bit pattern of
+//     1.5*2^23 plus an INTEGER, so its bits ARE the float 1.5*2^23 + s, exactly, as long as |s| < 2^22 — the launcher
+//     guarantees that from d and the operand ranges (d * 255 * 128 < 2^22 <=> d < 64).  The row maximum m is NOT subtracted
+//     in the accumulator (round 3 did: a per-lane seed, which ties the seed to the lane) but in the constant of the one
+//     packed FMA that maps the score to the log2 domain: x = fma(F, cs2, nc(m)), nc(m) = -fl((1.5*2^23 + m) * cs2).  The FMA
+//     is exact inside, so x = cs2*(s - m) + eps(m) with ONE rounding; eps(m), the rounding error of nc(m), is an exactly
+//     representable float (computed as fma(1.5*2^23 + m, cs2, nc(m))) common to every score of the row: the normaliser is
+//     corrected by 2^(eps(m_sweep2) - eps(m_sweep1)), see attn_rowref / attn_finish_stats;
+//   * the per-KEY zero-point term -zq' * sum_d k'[j][d] is therefore free (KT == 2): the seed of accumulator register r is
+//     0x4B400000 - zq'*ksum[key(r)], the same for every lane of a half-wave, read as four 16-byte words per tile from a
+//     table that qd_attn_keyterm builds once per K operand — no constant-operand MFMAs (round 3: 2 of the 4 score MFMAs of
+//     a tile carried no data), no VALU.  KT == 1 keeps the constant-operand MFMAs for callers without a table (bit-identical
+//     results: the accumulators hold the same integers); KT == 0: symmetric q, no term;
 //   * sweep 1 does not maintain a running maximum in the float domain (16 accumulator re-initialisations, a rescale and
-//     an extra exp2 per tile): it accumulates sum(exp2(cs2*(s - m0))) against the maximum m0 of the FIRST tile and tracks
-//     the integer maximum with v_max3_i32 only.  fp32 has the exponent range for that (the relative precision of a
-//     floating-point sum does not depend on the common scale) unless the maximum rises by more than 64 octaves, which
-//     is detected (wave-uniform) and answered by one more pass against the true maximum;
+//     an extra exp2 per tile): it accumulates sum(exp2(cs2*(s - m0))) against the maximum m0 of the FIRST tile (taken over
+//     both half-waves, so both halves of a query row share one reference and one eps) and tracks the integer maximum with
+//     v_max3_i32 only.  fp32 has the exponent range for that (the relative precision of a floating-point sum does not
+//     depend on the common scale) unless the maximum rises by more than 64 octaves, which is detected (wave-uniform) and
+//     answered by one more pass against the true maximum;
 //   * rounding to the probability grid is folded into the normalising FMA: fma(e, inv, ubias + 1.5*2^23);
 //   * the sums of the probability codes (needed for the v zero point) come out of the P.V MFMA itself: the lane that
 //     holds V^T row `d` (a padding row: d is not a multiple of 32) reads a constant row of ones instead, so column d
 //     of the output tile is sum_j code_j — no v_dot4 in the loop.
 __device__ __attribute__((aligned(16))) int qd_ones16[4] = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
 
-template <int DT, bool P16, bool ASYM>
+constexpr float QD_MAGIC  = 12582912.f;                        // 1.5 * 2^23
+constexpr int   QD_MAGICI = 0x4B400000;                        // its bit pattern
+
+struct AttnRowRef { float nc, eps; };                          // x = fma(F, cs2, nc);  eps = (1.5*2^23 + m)*cs2 + nc, exactly
+__device__ __forceinline__ AttnRowRef attn_rowref(int m, float cs2) {
+#pragma clang fp contract(off)
+    const float fm = QD_MAGIC + (float)m;                      // exact: |m| < 2^22
+    AttnRowRef r;
+    r.nc = -(fm * cs2);
+    r.eps = __builtin_fmaf(fm, cs2, r.nc);                     // the rounding error of a product is a float
+    return r;
+}
+// End of sweep 1 (shared by the lean and the LDS-staged kernel so that both evaluate the SAME float expressions): `l` = this
+// half-wave's sum of exp2(cs2*(s - m0) + eps0), `mxn` = how far this half's maximum lies above m0 (may be negative: m0 is the
+// maximum of tile 0 over BOTH halves).  Returns the row maximum mi, the reference of sweep 2, and 1 / (normaliser * dw) such
+// that e2 * inv = p / dw for e2 = exp2(fma(F, cs2, ref2.nc)).
+struct AttnNorm { int mi; AttnRowRef ref; float inv, emax; };
+__device__ __forceinline__ AttnNorm attn_finish_stats(float l, int mxn, int m0, const AttnRowRef& ref0, float cs2, float dw) {
+#pragma clang fp contract(off)
+    AttnNorm n;
+    const float lo = __shfl_xor(l, 32);
+    const int mx = max(mxn, __shfl_xor(mxn, 32));               // >= 0: the half that supplied m0 has mxn >= 0
+    n.mi = m0 + mx;
+    n.ref = attn_rowref(n.mi, cs2);
+    const float lt = l + lo;                                    // both halves are sums against the same m0 (and the same eps0)
+    const float ls = lt * __builtin_amdgcn_exp2f((n.ref.eps - ref0.eps) - (float)mx * cs2);   // = 2^eps(mi) * sum 2^(cs2*(s - mi))
+    n.inv = 1.0f / (ls * dw);
+    n.emax = __builtin_amdgcn_exp2f(n.ref.eps);                 // e2 of the row maximum
+    return n;
+}
+
+template <int DT, bool P16, int KT>
 __device__ __forceinline__ void attn_lean_body(const AttnK& p) {
     // a*b+c written as such stays unfused: hipcc's default -ffp-contract=fast lets the optimiser fuse (or not) depending on the
     // surrounding code, and the lean and the LDS-staged bodies must produce the same normaliser bit for bit
@@ -338,17 +380,16 @@ __device__ __forceinline__ void attn_lean_body(const AttnK& p) {
     const int izpw = (int)zpw;
     const float urange = p.wmax - p.wmin;
     const float ubias = zpw - p.wmin;
-    constexpr float MAGIC = 12582912.f;
-    constexpr int   MAGICI = 0x4B400000;
-    constexpr int   MASKED = -(1 << 30);
-    const float nc0 = -(MAGIC * cs2);                             // the (rounded) constant both sweeps subtract
+    constexpr float MAGIC = QD_MAGIC;
+    constexpr int   MAGICI = QD_MAGICI;
 
     v4i qf[DT];
     const int8_t* qrow = p.q + ((long)bh * p.Tpad + q0 + frow) * p.dpad + half * 16;
 #pragma unroll
     for (int kk = 0; kk < DT; ++kk) qf[kk] = *reinterpret_cast<const v4i*>(qrow + kk * 32);
     const int8_t* kbase = p.k + (long)bh * p.Spad * p.dpad + (long)frow * p.dpad + half * 16;
-    const int c1 = nzq > 127 ? 64 : nzq, c2 = nzq - c1;
+    const int32_t* tbase = KT == 2 ? p.kterm + (long)bh * p.Spad + half * 4 : nullptr;
+    const int c1 = nzq > 127 ? 64 : nzq, c2 = nzq - c1;           // KT == 1: -zq' in [-127, 128] as one or two int8 constants
     const int c1w = (c1 & 0xff) * 0x01010101, c2w = (c2 & 0xff) * 0x01010101;
     const v4i c1v = {c1w, c1w, c1w, c1w}, c2v = {c2w, c2w, c2w, c2w};
     const int ntile = p.Spad >> 5;
@@ -359,49 +400,67 @@ __device__ __forceinline__ void attn_lean_body(const AttnK& p) {
 #pragma unroll
         for (int kk = 0; kk < DT; ++kk) kf[kk] = *reinterpret_cast<const v4i*>(kp + kk * 32);
     };
-    // acc[4g+e] = init + score of key jt*32 + e + 8g + 4*half (per-query constants dropped)
-    auto scores = [&](const v4i (&kf)[DT], int init, v16i& acc) __attribute__((always_inline)) {
+    // seeds of the 16 accumulator registers of this lane for tile jt: register 4g+e <-> key jt*32 + e + 8g + 4*half
+    auto load_t = [&](int jt, v16i& ti) __attribute__((always_inline)) {
+        if (KT == 2) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = init;
+            for (int g = 0; g < 4; ++g) {
+                const v4i w = *reinterpret_cast<const v4i*>(tbase + jt * 32 + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ti[4 * g + e] = w[e];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ti[r] = MAGICI;
+        }
+    };
+    // acc[4g+e] = 0x4B400000 + (score of key jt*32 + e + 8g + 4*half), per-query constants dropped
+    auto scores = [&](const v4i (&kf)[DT], const v16i& ti, v16i& acc) __attribute__((always_inline)) {
+        acc = ti;
 #pragma unroll
         for (int kk = 0; kk < DT; ++kk) {
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], qf[kk], acc, 0, 0, 0);
-            if (ASYM) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], c1v, acc, 0, 0, 0);
+            if (KT == 1) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], c1v, acc, 0, 0, 0);
         }
-        if (ASYM && c2 != 0) {
+        if (KT == 1 && c2 != 0) {                                  // wave-uniform, only when zq' == -128
 #pragma unroll
             for (int kk = 0; kk < DT; ++kk) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], c2v, acc, 0, 0, 0);
         }
     };
     auto key_ok = [&](int jt, int r) __attribute__((always_inline)) { return jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half < p.S; };
-    const v2f cs2v = {cs2, cs2}, nc0v = {nc0, nc0};
+    const v2f cs2v = {cs2, cs2};
 
     // ---- sweep 1 ----------------------------------------------------------------------------------------------------
-    int m0, mx = 0;
-    float l = 0.f;
+    AttnNorm nrm;
     {
         v4i kf[DT], kfn[DT];
+        v16i ti;
         load_k(0, kf);
+        load_t(0, ti);
+        int m0;
         {
             v16i acc;
-            scores(kf, 0, acc);
-            if (tail_tile == 0) {
+            scores(kf, ti, acc);
+            m0 = 0;                                               // raw accumulators are > 0; 0 = masked
 #pragma unroll
-                for (int r = 0; r < 16; ++r) if (!key_ok(0, r)) acc[r] = MASKED;
-            }
-            m0 = acc[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m0 = max(m0, acc[r]);
+            for (int r = 0; r < 16; ++r) m0 = max(m0, (tail_tile == 0 && !key_ok(0, r)) ? 0 : acc[r]);
+            m0 -= MAGICI;
+            m0 = max(m0, __shfl_xor(m0, 32));                     // one reference for both halves of the query row
         }
+        float l = 0.f;
+        int mxn = 0;
+        AttnRowRef ref0;
         for (int pass = 0; pass < 2; ++pass) {
-            const int init = MAGICI - m0;
+            ref0 = attn_rowref(m0, cs2);
+            const v2f ncv = {ref0.nc, ref0.nc};
             int mxa = 0;                                          // max of the raw accumulators (all > 0: 0 is "masked")
             v2f a2 = {0.f, 0.f};
             auto s1_tile = [&](int jt, auto tail_tag) __attribute__((always_inline)) {
                 constexpr bool tail = decltype(tail_tag)::value;
                 if (jt + 1 < ntile) load_k(jt + 1, kfn);
                 v16i acc;
-                scores(kf, init, acc);
+                scores(kf, ti, acc);
+                if (KT == 2 && jt + 1 < ntile) load_t(jt + 1, ti);
                 if (tail) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) if (!key_ok(jt, r)) acc[r] = 0;
@@ -410,7 +469,7 @@ __device__ __forceinline__ void attn_lean_body(const AttnK& p) {
                 for (int r = 0; r < 16; r += 2) {
                     mxa = max(max(mxa, acc[r]), acc[r + 1]);              // v_max3_i32
                     const v2f F = {__int_as_float(acc[r]), __int_as_float(acc[r + 1])};
-                    const v2f x = __builtin_elementwise_fma(F, cs2v, nc0v);
+                    const v2f x = __builtin_elementwise_fma(F, cs2v, ncv);
                     v2f e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
                     if (tail) {
                         if (acc[r] == 0) e.x = 0.f;
@@ -426,24 +485,18 @@ __device__ __forceinline__ void attn_lean_body(const AttnK& p) {
             for (int jt = 0; jt < tail_tile; ++jt) s1_tile(jt, std::false_type{});
             if (tail_tile < ntile) s1_tile(tail_tile, std::true_type{});
             l = a2.x + a2.y;
-            mx = mxa ? mxa - MAGICI : 0;                          // how far the row maximum lies above m0 (>= 0: tile 0 is in the
-                                                                  // loop); a lane without any valid key keeps m0 = MASKED, l = 0
-            if (!__any((float)mx * cs2 > 64.f)) break;
-            m0 += mx;                                             // (rare) start again against the true maximum
+            mxn = mxa ? mxa - MAGICI - m0 : 0;                    // this half's maximum relative to m0; a half without any valid key: 0, l = 0
+            const int mxm = max(mxn, __shfl_xor(mxn, 32));
+            if (!__any((float)mxm * cs2 > 64.f)) break;
+            m0 += mxm;                                            // (rare) start again against the true maximum (the same in both halves)
             load_k(0, kf);
+            load_t(0, ti);
         }
+        nrm = attn_finish_stats(l, mxn, m0, ref0, cs2, dw);
     }
-    int mi = m0 + mx;
-    l *= __builtin_amdgcn_exp2f(-(float)mx * cs2);                // normaliser relative to this half's maximum
-    {
-        const int mo = __shfl_xor(mi, 32);
-        const float lo = __shfl_xor(l, 32);
-        const int mf = max(mi, mo);
-        l = l * __builtin_amdgcn_exp2f((float)(mi - mf) * cs2) + lo * __builtin_amdgcn_exp2f((float)(mo - mf) * cs2);
-        mi = mf;
-    }
-    const float inv = 1.0f / (l * dw);
-    const float emax = __builtin_amdgcn_exp2f(__builtin_fmaf(MAGIC, cs2, nc0));   // e of the row maximum (2^eps)
+    const int mi = nrm.mi;
+    const float inv = nrm.inv, emax = nrm.emax;
+    (void)mi;
 
     // ---- sweep 2 ----------------------------------------------------------------------------------------------------
     v16i ol[DT], oh[P16 ? DT : 1];
@@ -465,8 +518,10 @@ __device__ __forceinline__ void attn_lean_body(const AttnK& p) {
     }
     {
         v4i kf[DT], kfn[DT];
+        v16i ti;
         load_k(0, kf);
-        const int init = MAGICI - mi;
+        load_t(0, ti);
+        const v2f ncv = {nrm.ref.nc, nrm.ref.nc};
         const v2f invv = {inv, inv}, ubv = {ubias, ubias}, magic = {MAGIC, MAGIC}, ubm = {ubias + MAGIC, ubias + MAGIC};
         auto s2_tile = [&](int jt, auto tail_tag, auto clamp_tag) __attribute__((always_inline)) {
             constexpr bool tail = decltype(tail_tag)::value, CLAMP = decltype(clamp_tag)::value;
@@ -475,12 +530,13 @@ __device__ __forceinline__ void attn_lean_body(const AttnK& p) {
             for (int t = 0; t < DT; ++t) vf[t] = *reinterpret_cast<const v4i*>(vp[t] + (long)jt * vstep[t]);
             if (jt + 1 < ntile) load_k(jt + 1, kfn);
             v16i acc;
-            scores(kf, init, acc);
+            scores(kf, ti, acc);
+            if (KT == 2 && jt + 1 < ntile) load_t(jt + 1, ti);
             unsigned ub[16];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const v2f F = {__int_as_float(acc[r]), __int_as_float(acc[r + 1])};
-                const v2f x = __builtin_elementwise_fma(F, cs2v, nc0v);
+                const v2f x = __builtin_elementwise_fma(F, cs2v, ncv);
                 const v2f e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
                 v2f t;
                 if (CLAMP) {
@@ -570,8 +626,8 @@ __device__ __forceinline__ void attn_lean_body(const AttnK& p) {
 #ifndef QD_ATTN_LEAN_OCC
 #define QD_ATTN_LEAN_OCC 3
 #endif
-template <int DT, bool P16, bool ASYM>
-__global__ __launch_bounds__(256, QD_ATTN_LEAN_OCC) void attn_lean_kernel(const AttnK p) { attn_lean_body<DT, P16, ASYM>(p); }
+template <int DT, bool P16, int KT>
+__global__ __launch_bounds__(256, QD_ATTN_LEAN_OCC) void attn_lean_kernel(const AttnK p) { attn_lean_body<DT, P16, KT>(p); }
 
 constexpr int QD_ONES_ROW = 16384;                             // longest padded key axis the LDS-staged kernel takes (bytes of ones)
 struct OnesRow {                                               // constant-initialised: lives in the code object's data segment
@@ -616,14 +672,15 @@ template <int N>
 __device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void attn_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int DT, bool P16, bool ASYM>
+template <int DT, bool P16, int KT>
 __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
     // a*b+c written as such stays unfused: hipcc's default -ffp-contract=fast lets the optimiser fuse (or not) depending on the
     // surrounding code, and the lean and the LDS-staged bodies must produce the same normaliser bit for bit
 #pragma clang fp contract(off)
     constexpr int NST = 4;                                    // ring stages (tiles): jt+1 in use, jt+2 landed / landing, jt+3 issued
     constexpr int KB = 1024 * DT, VB = 1024 * DT;             // K tile: 32 keys x dpad bytes; V^T tile: dpad rows x 32 keys
-    constexpr int STAGE = KB + VB;
+    constexpr int TB = KT == 2 ? 128 : 0;                     // the tile's 32 accumulator seeds (per-key zero-point term, qd_attn_keyterm)
+    constexpr int STAGE = KB + VB + TB;
     __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
     __shared__ int s_flag[1];
     const int lane = threadIdx.x & 63;
@@ -642,12 +699,10 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
     const int izpw = (int)zpw;
     const float urange = p.wmax - p.wmin;
     const float ubias = zpw - p.wmin;
-    constexpr float MAGIC = 12582912.f;
-    constexpr int   MAGICI = 0x4B400000;
-    constexpr int   MASKED = -(1 << 30);
-    const float nc0 = -(MAGIC * cs2);
-    if (ASYM && nzq > 127) {                                  // zq' = -128 (block-uniform): the two-constant schedule of the plain body
-        attn_lean_body<DT, P16, ASYM>(p);
+    constexpr float MAGIC = QD_MAGIC;
+    constexpr int   MAGICI = QD_MAGICI;
+    if (KT == 1 && nzq > 127) {                               // zq' = -128 without a key-term table (block-uniform): the two-constant
+        attn_lean_body<DT, P16, KT>(p);                       // schedule of the plain body
         return;
     }
 
@@ -660,12 +715,15 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
     const int ntile = p.Spad >> 5;
     const int nfull = (p.S & 31) ? ntile - 1 : ntile;
 
-    // ---- DMA role of this wave: slot s < DT copies 1 KB of the K tile, DT <= s < 2*DT 1 KB of the V^T tile --------------
+    // ---- DMA role of this wave: slot s < DT copies 1 KB of the K tile, DT <= s < 2*DT 1 KB of the V^T tile; wave 3 also copies
+    // the 128 bytes of accumulator seeds (lanes 0-7, issued BEFORE its V^T copy: vmcnt retires in order, so the uniform
+    // "all but the newest copy" wait below over-waits on wave 3 by one 128-byte copy issued a whole tile earlier) ---------------
     // LDS side is lane-linear (chunk c = slot*64 + lane, 16 B each); the bank swizzle lives in the SOURCE chunk index.
     constexpr int CPRK = 2 * DT;                              // 16-byte chunks per K row (dpad / 16)
-    const bool dma_k = wave < DT, dma_v = wave >= DT && wave < 2 * DT;
+    const bool dma_k = wave < DT, dma_v = wave >= DT && wave < 2 * DT, dma_t = KT == 2 && wave == 3;
     const int8_t* ksrc;                                       // source of this lane's chunk of tile 0
     const int8_t* vsrc;
+    const int32_t* tsrc = KT == 2 ? p.kterm + (long)bh * p.Spad + (lane & 7) * 4 : nullptr;
     {
         const int c = (dma_k ? wave : 0) * 64 + lane;
         const int row = c / CPRK, pos = c % CPRK;
@@ -691,9 +749,10 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
     // issue this wave's DMA for tile `jt` (K always; V only in sweep 2); past the end: tile ntile-1 again (harmless)
     auto issue = [&](int jt, bool with_v) __attribute__((always_inline)) {
         const int j = min(jt, ntile - 1);
-        const unsigned st = lds0 + (unsigned)(jt & (NST - 1)) * STAGE + dma_dst;
-        if (dma_k) attn_glds16(ksrc + (long)j * KB, st);
-        else if (dma_v && with_v) attn_glds16(vsrc + (long)j * 32, st);
+        const unsigned st = lds0 + (unsigned)(jt & (NST - 1)) * STAGE;
+        if (dma_t && lane < 8) attn_glds16(tsrc + (long)j * 32, st + KB + VB);
+        if (dma_k) attn_glds16(ksrc + (long)j * KB, st + dma_dst);
+        else if (dma_v && with_v) attn_glds16(vsrc + (long)j * 32, st + dma_dst);
     };
     auto read_k = [&](int jt, v4i (&kf)[DT]) __attribute__((always_inline)) {
         const unsigned char* sp = smem + (jt & (NST - 1)) * STAGE;
@@ -705,24 +764,33 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
 #pragma unroll
         for (int t = 0; t < DT; ++t) vf[t] = *reinterpret_cast<const v4i*>(sp + voff[t]);
     };
-    constexpr int QKM = DT * (ASYM ? 2 : 1);
+    // seeds of this lane's 16 accumulator registers for tile jt: register 4g+e <-> key e + 8g + 4*half of the tile, i.e. the
+    // 16-byte word 2g + half of the tile's table (two distinct addresses per ds_read_b128: broadcast)
+    auto read_t = [&](int jt, v16i& ti) __attribute__((always_inline)) {
+        if (KT == 2) {
+            const unsigned char* sp = smem + (jt & (NST - 1)) * STAGE + KB + VB + half * 16;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v4i w = *reinterpret_cast<const v4i*>(sp + g * 32);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ti[4 * g + e] = w[e];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ti[r] = MAGICI;
+        }
+    };
     auto qk = [&](const v4i (&kf)[DT], const v16i& initv, v16i& acc) __attribute__((always_inline)) {
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[0], qf[0], initv, 0, 0, 0);
-        if (ASYM) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[0], c1v, acc, 0, 0, 0);
+        if (KT == 1) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[0], c1v, acc, 0, 0, 0);
 #pragma unroll
         for (int kk = 1; kk < DT; ++kk) {
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], qf[kk], acc, 0, 0, 0);
-            if (ASYM) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], c1v, acc, 0, 0, 0);
+            if (KT == 1) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], c1v, acc, 0, 0, 0);
         }
     };
     auto key_ok = [&](int jt, int r) __attribute__((always_inline)) { return jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half < p.S; };
-    auto splat16 = [&](int v) __attribute__((always_inline)) {
-        v16i o;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = v;
-        return o;
-    };
-    const v2f cs2v = {cs2, cs2}, nc0v = {nc0, nc0};
+    const v2f cs2v = {cs2, cs2};
     // start of a sweep: tiles 0 .. NST-2 in flight, tile 0 landed and visible
     auto prologue = [&](bool with_v) __attribute__((always_inline)) {
         __syncthreads();                                      // nobody still reads the ring of the previous sweep / pass
@@ -742,37 +810,39 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
     };
 
     // ---- sweep 1 ----------------------------------------------------------------------------------------------------
-    int m0, mx = 0;
-    float l = 0.f;
+    AttnNorm nrm;
     {
         v4i kf[DT];
-        v16i acc[2];
+        v16i acc[2], ti;
         prologue(false);
         read_k(0, kf);
-        {
-            qk(kf, splat16(0), acc[0]);
-            if (nfull == 0) {
+        read_t(0, ti);
+        qk(kf, ti, acc[0]);
+        int m0 = 0;                                           // raw accumulators are > 0; 0 = masked
 #pragma unroll
-                for (int r = 0; r < 16; ++r) if (!key_ok(0, r)) acc[0][r] = MASKED;
-            }
-            m0 = acc[0][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m0 = max(m0, acc[0][r]);
-        }
+        for (int r = 0; r < 16; ++r) m0 = max(m0, (nfull == 0 && !key_ok(0, r)) ? 0 : acc[0][r]);
+        m0 -= MAGICI;
+        m0 = max(m0, __shfl_xor(m0, 32));                     // one reference for both halves of the query row
+        float l = 0.f;
+        int mxn = 0;
+        AttnRowRef ref0 = attn_rowref(m0, cs2);
         for (int pass = 0; pass < 2; ++pass) {
             if (pass) {
                 prologue(false);
                 read_k(0, kf);
+                read_t(0, ti);
+                qk(kf, ti, acc[0]);
             }
-            const v16i initv = splat16(MAGICI - m0);
+            const AttnRowRef refp = attn_rowref(m0, cs2);
+            const v2f ncv = {refp.nc, refp.nc};
             int mxa = 0;
             v2f a2 = {0.f, 0.f};
-            qk(kf, initv, acc[0]);
             auto s1_iter = [&](int jt, auto par_tag, auto tail_tag) __attribute__((always_inline)) {
                 constexpr int C = decltype(par_tag)::value, N = 1 - C;
                 constexpr bool tail = decltype(tail_tag)::value;
                 step_sync(jt, false);
                 read_k(jt + 1, kf);
+                read_t(jt + 1, ti);
                 if (tail) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) if (!key_ok(jt, r)) acc[C][r] = 0;
@@ -781,7 +851,7 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
                 for (int r = 0; r < 16; r += 2) {
                     mxa = max(max(mxa, acc[C][r]), acc[C][r + 1]);
                     const v2f F = {__int_as_float(acc[C][r]), __int_as_float(acc[C][r + 1])};
-                    const v2f x = __builtin_elementwise_fma(F, cs2v, nc0v);
+                    const v2f x = __builtin_elementwise_fma(F, cs2v, ncv);
                     v2f e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
                     if (tail) {
                         if (acc[C][r] == 0) e.x = 0.f;
@@ -790,7 +860,7 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
                     a2 += e;
                 }
                 __builtin_amdgcn_sched_barrier(0);            // the chain stays behind the statistics of tile jt, back to back
-                qk(kf, initv, acc[N]);
+                qk(kf, ti, acc[N]);
                 __builtin_amdgcn_sched_barrier(0);
             };
             int jt = 0;
@@ -805,11 +875,12 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
             } else if (jt < ntile) {
                 s1_iter(jt, std::integral_constant<int, 0>{}, std::true_type{});
             }
-            const int mxn = mxa ? mxa - MAGICI : 0;
-            const bool again = (float)mxn * cs2 > 64.f;       // this lane's maximum rose by > 64 octaves over tile 0's
+            const int mxh = mxa ? mxa - MAGICI - m0 : 0;      // this half's maximum relative to m0
+            const int mxm = max(mxh, __shfl_xor(mxh, 32));
+            const bool again = (float)mxm * cs2 > 64.f;       // this row's maximum rose by > 64 octaves over tile 0's
             if (pass == 0) {
                 l = a2.x + a2.y;
-                mx = mxn;
+                mxn = mxh;
                 // the repeat pass runs the ring and the barriers again: the decision is taken for the whole BLOCK; a wave
                 // that did not need it keeps its first-pass statistics (what attn_lean_kernel computes for it)
                 if (threadIdx.x == 0) s_flag[0] = 0;
@@ -818,27 +889,18 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
                 __syncthreads();
                 if (!s_flag[0]) break;
                 if (__any(again)) {                            // this wave repeats against the true maximum
-                    m0 += mx;
-                    mx = 0;
+                    m0 += mxm;
                     l = -1.f;                                  // marker: take the second pass's statistics
                 }
             } else if (l < 0.f) {
                 l = a2.x + a2.y;
-                mx = mxn;
+                mxn = mxh;
+                ref0 = refp;
             }
         }
+        nrm = attn_finish_stats(l, mxn, m0, ref0, cs2, dw);
     }
-    int mi = m0 + mx;
-    l *= __builtin_amdgcn_exp2f(-(float)mx * cs2);
-    {
-        const int mo = __shfl_xor(mi, 32);
-        const float lo = __shfl_xor(l, 32);
-        const int mf = max(mi, mo);
-        l = l * __builtin_amdgcn_exp2f((float)(mi - mf) * cs2) + lo * __builtin_amdgcn_exp2f((float)(mo - mf) * cs2);
-        mi = mf;
-    }
-    const float inv = 1.0f / (l * dw);
-    const float emax = __builtin_amdgcn_exp2f(__builtin_fmaf(MAGIC, cs2, nc0));
+    const float inv = nrm.inv, emax = nrm.emax;
 
     // ---- sweep 2 ----------------------------------------------------------------------------------------------------
     v16i ol[DT], oh[P16 ? DT : 1];
@@ -860,11 +922,13 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
         phi[1] = v4i{0, 0, 0, 0};
 #pragma unroll
         for (int t = 0; t < DT; ++t) vfr[1][t] = v4i{0, 0, 0, 0};
-        const v16i initv = splat16(MAGICI - mi);
+        v16i ti;
+        const v2f ncv = {nrm.ref.nc, nrm.ref.nc};
         const v2f invv = {inv, inv}, ubv = {ubias, ubias}, magic = {MAGIC, MAGIC}, ubm = {ubias + MAGIC, ubias + MAGIC};
         prologue(true);
         read_k(0, kf);
-        qk(kf, initv, acc[0]);
+        read_t(0, ti);
+        qk(kf, ti, acc[0]);
         // iteration jt: V^T fragments of tile jt and K fragments of tile jt+1 from the ring; the P.V MFMAs of tile jt-1
         // (operand set N, independent accumulators) spread between the probability chain of tile jt (accumulator set C ->
         // operand set C); the score chain of tile jt+1 back to back at the end
@@ -875,6 +939,7 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
             step_sync(jt, true);
             read_v(jt, vfr[C]);
             read_k(jt + 1, kf);
+            read_t(jt + 1, ti);
             unsigned ub[16];
 #pragma unroll
             for (int m = 0; m < NPV; ++m) {
@@ -885,7 +950,7 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
                 for (int sidx = (8 * m) / NPV; sidx < (8 * (m + 1)) / NPV; ++sidx) {
                     const int r = 2 * sidx;
                     const v2f F = {__int_as_float(acc[C][r]), __int_as_float(acc[C][r + 1])};
-                    const v2f x = __builtin_elementwise_fma(F, cs2v, nc0v);
+                    const v2f x = __builtin_elementwise_fma(F, cs2v, ncv);
                     const v2f e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
                     v2f t2;
                     if (CLAMP) {
@@ -912,7 +977,7 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            qk(kf, initv, acc[N]);
+            qk(kf, ti, acc[N]);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto run = [&](auto clamp_tag, auto hi_tag) __attribute__((always_inline)) {
@@ -990,24 +1055,40 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
     QD_FAST_DISPATCH(oqp.fast, epi);
 }
 
+// kt: 0 = symmetric q (no per-key term), 1 = constant-operand MFMAs, 2 = key-term table (AttnK::kterm)
 template <int DT>
-int launch_lds(const AttnK& k, bool p16, bool asym, hipStream_t st) {
+int launch_lds(const AttnK& k, bool p16, int kt, hipStream_t st) {
     dim3 grid((unsigned)(k.gx * k.BH));
-    if (p16 && asym) hipLaunchKernelGGL((attn_lds_kernel<DT, true, true>), grid, dim3(256), 0, st, k);
-    else if (p16) hipLaunchKernelGGL((attn_lds_kernel<DT, true, false>), grid, dim3(256), 0, st, k);
-    else if (asym) hipLaunchKernelGGL((attn_lds_kernel<DT, false, true>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((attn_lds_kernel<DT, false, false>), grid, dim3(256), 0, st, k);
+#define QD_LDS_CASE(P, K) if (p16 == P && kt == K) hipLaunchKernelGGL((attn_lds_kernel<DT, P, K>), grid, dim3(256), 0, st, k);
+    QD_LDS_CASE(true, 0) QD_LDS_CASE(true, 1) QD_LDS_CASE(true, 2) QD_LDS_CASE(false, 0) QD_LDS_CASE(false, 1) QD_LDS_CASE(false, 2)
+#undef QD_LDS_CASE
     return 0;
 }
 
 template <int DT>
-int launch_lean(const AttnK& k, bool p16, bool asym, hipStream_t st) {
+int launch_lean(const AttnK& k, bool p16, int kt, hipStream_t st) {
     dim3 grid((unsigned)(k.gx * k.BH));
-    if (p16 && asym) hipLaunchKernelGGL((attn_lean_kernel<DT, true, true>), grid, dim3(256), 0, st, k);
-    else if (p16) hipLaunchKernelGGL((attn_lean_kernel<DT, true, false>), grid, dim3(256), 0, st, k);
-    else if (asym) hipLaunchKernelGGL((attn_lean_kernel<DT, false, true>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((attn_lean_kernel<DT, false, false>), grid, dim3(256), 0, st, k);
+#define QD_LEAN_CASE(P, K) if (p16 == P && kt == K) hipLaunchKernelGGL((attn_lean_kernel<DT, P, K>), grid, dim3(256), 0, st, k);
+    QD_LEAN_CASE(true, 0) QD_LEAN_CASE(true, 1) QD_LEAN_CASE(true, 2) QD_LEAN_CASE(false, 0) QD_LEAN_CASE(false, 1) QD_LEAN_CASE(false, 2)
+#undef QD_LEAN_CASE
     return 0;
+}
+
+// one thread per 16-byte chunk of a K row: row sums by v_dot4 + a butterfly over the CPR lanes of a row
+template <int CPR>
+__global__ __launch_bounds__(256) void attn_keyterm_kernel(const int8_t* __restrict__ k, int32_t* __restrict__ kterm, const float* __restrict__ prm,
+                                                           long nchunks) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    const int nzq = -(int)prm[1];
+    int s = 0;
+    if (c < nchunks) {
+        const v4i w = *reinterpret_cast<const v4i*>(k + c * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s = __builtin_amdgcn_sdot4(w[i], 0x01010101, s, false);
+    }
+#pragma unroll
+    for (int o = 1; o < CPR; o <<= 1) s += __shfl_xor(s, o);
+    if (c < nchunks && (c % CPR) == 0) kterm[c / CPR] = QD_MAGICI + nzq * s;
 }
 
 template <int DT>
@@ -1022,7 +1103,42 @@ int launch_dt(const AttnK& k, bool p16, bool asym, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt, const int32_t* qsum, const int32_t* ksum,
+// Run-time knobs of the attention launcher: read from the environment ONCE (first call), changed afterwards only through
+// qd_attn_config (tests and A/B runs flip the kernel choice inside one process).
+struct AttnKnobs { int lean, pipe, xcd, ktab; };
+static AttnKnobs& attn_knobs() {
+    static AttnKnobs k = [] {
+        auto env = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
+        return AttnKnobs{env("QD_ATTN_LEAN", 1), env("QD_ATTN_PIPE", 2), env("QD_ATTN_XCD", 1), env("QD_ATTN_KTAB", 1)};
+    }();
+    return k;
+}
+static bool attn_lean_shape(int d) { return attn_knobs().lean != 0 && d < 64 && (d & 31) != 0; }
+
+extern "C" void qd_attn_config(int pipe_mode, int xcd, int ktab) {
+    AttnKnobs& k = attn_knobs();
+    if (pipe_mode >= 0) k.pipe = pipe_mode;
+    if (xcd >= 0) k.xcd = xcd;
+    if (ktab >= 0) k.ktab = ktab;
+}
+
+extern "C" int qd_attn_uses_keyterm(int d, int q_asym) { return (q_asym != 0 && attn_lean_shape(d) && attn_knobs().ktab != 0) ? 1 : 0; }
+
+extern "C" int qd_attn_keyterm(const int8_t* k, int BH, int Spad, int dpad, const float* prm, int32_t* kterm, void* stream) {
+    QD_REQUIRE(k && prm && kterm, "qd_attn_keyterm: null pointer");
+    QD_REQUIRE(BH > 0 && Spad > 0 && Spad % 32 == 0 && (dpad == 32 || dpad == 64), "qd_attn_keyterm: Spad must be a multiple of 32, dpad 32 or 64 (got %d, %d)", Spad, dpad);
+    QD_REQUIRE(qd_aligned(k, 16) && qd_aligned(kterm, 16), "qd_attn_keyterm: operands must be 16-byte aligned");
+    const long nchunks = (long)BH * Spad * (dpad / 16);
+    QD_REQUIRE((nchunks + 255) / 256 < (1L << 31), "qd_attn_keyterm: too many blocks");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((nchunks + 255) / 256));
+    if (dpad == 32) hipLaunchKernelGGL((attn_keyterm_kernel<2>), grid, dim3(256), 0, st, k, kterm, prm, nchunks);
+    else hipLaunchKernelGGL((attn_keyterm_kernel<4>), grid, dim3(256), 0, st, k, kterm, prm, nchunks);
+    QD_LAUNCH_CHECK("qd_attn_keyterm");
+    return 0;
+}
+
+extern "C" int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt, const int32_t* qsum, const int32_t* kterm,
                           const int32_t* vsum, int BH, int H, int T, int S, int d, int Tpad, int Spad, int dpad,
                           const float* prm, int wbits, int wmin, int wmax, int q_asym, float* out, int64_t ldo,
                           int8_t* out8, int64_t ldo8, const float* oq_params, int oq_min, int oq_max, int oq_off, void* stream) {
@@ -1034,28 +1150,25 @@ extern "C" int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt, co
     QD_REQUIRE((long)BH * ((T + 127) / 128) < (1L << 31), "qd_attn_i8: too many blocks");
     QD_REQUIRE(wbits == 8 || wbits == 16, "qd_attn_i8: probability bits must be 8 or 16 (got %d)", wbits);
     QD_REQUIRE(wmax - wmin <= (wbits == 16 ? 65535 : 255), "qd_attn_i8: probability grid [%d,%d] wider than %d bits", wmin, wmax, wbits);
-    QD_REQUIRE(qd_aligned(q, 16) && qd_aligned(k, 16) && qd_aligned(vt, 16), "qd_attn_i8: operands must be 16-byte aligned");
+    QD_REQUIRE(qd_aligned(q, 16) && qd_aligned(k, 16) && qd_aligned(vt, 16) && qd_aligned(kterm, 16), "qd_attn_i8: operands must be 16-byte aligned");
     (void)qsum;                                  // per-query constants cancel in the softmax: never needed
-    (void)ksum;                                  // per-key term: constant-operand MFMA inside the kernel
     const bool asym = q_asym != 0;
-    const char* xcd_env = getenv("QD_ATTN_XCD");
-    AttnK a{q, k, vt, qsum, ksum, vsum, prm, out, (long)ldo, BH, H, T, S, d, Tpad, Spad, dpad, (float)wmin, (float)wmax, wmin,
-            out8, (long)ldo8, oq_params, (float)oq_min, (float)oq_max, oq_off, xcd_env && atoi(xcd_env) == 0 ? 0 : 1, (T + 127) / 128};
+    const AttnKnobs& kn = attn_knobs();
+    AttnK a{q, k, vt, qsum, kterm, vsum, prm, out, (long)ldo, BH, H, T, S, d, Tpad, Spad, dpad, (float)wmin, (float)wmax, wmin,
+            out8, (long)ldo8, oq_params, (float)oq_min, (float)oq_max, oq_off, kn.xcd != 0 ? 1 : 0, (T + 127) / 128};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool p16 = wbits == 16;
-    // lean variant: needs a padding row of V^T (d not a multiple of 32) and |score differences| < 2^22 (d < 64)
-    static const bool lean_ok = !(getenv("QD_ATTN_LEAN") && atoi(getenv("QD_ATTN_LEAN")) == 0);
-    // QD_ATTN_PIPE (read per call: tests flip it inside one process): 2 = LDS-staged kernel wherever it pays (default),
-    // 0 = attn_lean_kernel everywhere (A/B runs and the equality test), 3 = LDS-staged kernel on every eligible shape
-    const char* pipe_env = getenv("QD_ATTN_PIPE");
-    const int pipe_mode = pipe_env ? atoi(pipe_env) : 2;
-    if (lean_ok && d < 64 && (d & 31) != 0) {
+    // lean variant: needs a padding row of V^T (d not a multiple of 32) and |scores| < 2^22 (d < 64)
+    // pipe: 2 = LDS-staged kernel wherever it pays (default), 0 = attn_lean_kernel everywhere (A/B runs and the equality
+    // test), 3 = LDS-staged kernel on every eligible shape
+    if (attn_lean_shape(d)) {
+        const int kt = !asym ? 0 : (kterm && kn.ktab != 0) ? 2 : 1;     // per-key zero-point term: none / constant-operand MFMAs / table
         const bool lds_fits = Spad <= QD_ONES_ROW && (long)Spad * dpad < (1L << 31);
-        if (lds_fits && (pipe_mode == 3 || (pipe_mode == 2 && S >= 512))) {       // short key axes: ring start-up and barriers lose
-            if (dpad == 32) launch_lds<1>(a, p16, asym, st);
-            else launch_lds<2>(a, p16, asym, st);
-        } else if (dpad == 32) launch_lean<1>(a, p16, asym, st);
-        else launch_lean<2>(a, p16, asym, st);
+        if (lds_fits && (kn.pipe == 3 || (kn.pipe == 2 && S >= 512))) {         // short key axes: ring start-up and barriers lose
+            if (dpad == 32) launch_lds<1>(a, p16, kt, st);
+            else launch_lds<2>(a, p16, kt, st);
+        } else if (dpad == 32) launch_lean<1>(a, p16, kt, st);
+        else launch_lean<2>(a, p16, kt, st);
         QD_LAUNCH_CHECK("qd_attn_i8");
         return 0;
     }

@@ -549,8 +549,8 @@ def attention(ap, q, k, v, B, T, S, H, d, q_strides, k_strides, v_strides, out=N
     q8 = torch.empty((BH, Tpad, dpad), dtype=torch.int8, device=dev)
     k8 = torch.empty((BH, Spad, dpad), dtype=torch.int8, device=dev)
     v8 = torch.empty((BH, dpad, Spad), dtype=torch.int8, device=dev)
-    # no q/k row sums: per-query zero-point terms cancel in the softmax, the per-key term is restored by
-    # the attention kernel's constant-operand MFMA
+    # no q/k row sums: per-query zero-point terms cancel in the softmax, the per-key term is restored by the attention
+    # kernel (accumulator seeds from hip.attn_keyterm on the d < 64 kernels, constant-operand MFMAs elsewhere)
     vsum = torch.empty((BH, dpad), dtype=torch.int32, device=dev)
     gq, gk, gv = ap.grids
     hip.quantize_heads(q, B, T, H, d, q_strides, ap.prescale, ap.qparams[0], gq, False, q8, None, Tpad, dpad)
@@ -685,21 +685,23 @@ def heads_from_float(ap, which, x, B, T, H, d, strides, out8, vsum=None):
                        which == 2, out8, vsum if which == 2 else None, pad32(T), pad32(d))
 
 
-def attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d, out=None, out_plan=None):
+def attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d, out=None, out_plan=None, kterm=None):
     """Fused quantised attention on prepared operand bytes; returns merged-head rows out[B*T][H*d] fp32 —
     or, with out_plan (the ConvPlan of the Linear that consumes the output, one segment, input width H*d), that
-    Linear's int8 input rows [B*T][out_plan.ldx], quantised in the attention epilogue."""
+    Linear's int8 input rows [B*T][out_plan.ldx], quantised in the attention epilogue.
+    kterm: the key-term table of THIS k8 (hip.attn_keyterm) when the caller keeps one (static keys); else hip.attn_i8
+    builds it per call where the head dim takes one."""
     if out_plan is not None:
         if len(out_plan.segs) != 1 or out_plan.ldx != H * d:
             raise hip.HipEngineError("attention_codes: out_plan must take exactly the H*d merged-head features")
         out8 = torch.empty((B * T, out_plan.ldx), dtype=torch.int8, device=q8.device)
         hip.attn_i8(q8, k8, v8, vsum, B * H, H, T, S, d, pad32(T), pad32(S), pad32(d), ap.prm, ap.wbits, ap.wmin, ap.wmax,
-                    ap.asym, None, 0, out8=out8, oq_params=out_plan.qparams[0], oq_grid=out_plan.grids[0])
+                    ap.asym, None, 0, out8=out8, oq_params=out_plan.qparams[0], oq_grid=out_plan.grids[0], kterm=kterm)
         return out8
     if out is None:
         out = torch.empty((B * T, H * d), dtype=torch.float32, device=q8.device)
     hip.attn_i8(q8, k8, v8, vsum, B * H, H, T, S, d, pad32(T), pad32(S), pad32(d), ap.prm, ap.wbits, ap.wmin, ap.wmax,
-                ap.asym, out, out.stride(0))
+                ap.asym, out, out.stride(0), kterm=kterm)
     return out
 
 

@@ -64,7 +64,7 @@ EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_make_qparams",
            "qd_pack_weights_t8",
            "qd_conv2d_i8", "qd_conv2d_i8_splitk_ws_bytes",
            "qd_conv2d_i8_acc", "qd_groupnorm_ws_bytes", "qd_groupnorm_silu_quant", "qd_groupnorm_mod_silu_quant", "qd_layernorm_quant",
-           "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8", "qd_bmm_qk_i8", "qd_bmm_pv_i8", "qd_temb_mlp",
+           "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8", "qd_attn_keyterm", "qd_attn_uses_keyterm", "qd_attn_config", "qd_bmm_qk_i8", "qd_bmm_pv_i8", "qd_temb_mlp",
            "qd_fakequant_blocks", "qd_fakequant_fwd", "qd_fakequant_bwd",
            "qd_conv2d_bf16", "qd_pack_weights_bf16_bytes", "qd_pack_weights_bf16", "qd_groupnorm_silu_bf16"]
 
@@ -105,6 +105,10 @@ def load():
                                       vp, vp, i32, i32, vp]
     lib.qd_attn_i8.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp,
                                i64, vp, i64, vp, i32, i32, i32, vp]
+    lib.qd_attn_keyterm.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    lib.qd_attn_uses_keyterm.argtypes = [i32, i32]
+    lib.qd_attn_config.argtypes = [i32, i32, i32]
+    lib.qd_attn_config.restype = None
     lib.qd_temb_mlp.argtypes = [vp, i64, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i64, vp]
     lib.qd_bmm_qk_i8.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i64, i64, vp]
     lib.qd_bmm_pv_i8.argtypes = [vp, i64, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i64, i64, vp]
@@ -117,7 +121,7 @@ def load():
     lib.qd_pack_weights_bf16_bytes.argtypes = [i32, i32, i32]
     lib.qd_pack_weights_bf16.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     lib.qd_groupnorm_silu_bf16.argtypes = [vp, i64, i64, i32, i64, i32, f32, vp, vp, i32, vp, i64, vp, vp, i32, i64, vp]
-    if lib.qd_abi_version() != 17:
+    if lib.qd_abi_version() != 18:
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -432,12 +436,33 @@ def quantize_heads(x, B, T, H, d, strides, prescale, qparams, grid, transpose, o
                                     dpad, _stream()), "qd_quantize_heads")
 
 
+def attn_uses_keyterm(d, q_asym):
+    """The attention launcher takes a key-term table for this head dim (qd_attn_keyterm)."""
+    return bool(load().qd_attn_uses_keyterm(int(d), 1 if q_asym else 0))
+
+
+def attn_keyterm(k, BH, Spad, dpad, prm, kterm=None):
+    """kterm[bh][j] = 0x4B400000 - zq' * sum_c k[bh][j][c]: the score-accumulator seeds of qd_attn_i8 (int32 [BH][Spad])."""
+    if kterm is None:
+        kterm = torch.empty((BH, Spad), dtype=torch.int32, device=k.device)
+    _check(load().qd_attn_keyterm(_ptr(k), BH, Spad, dpad, _ptr(prm), _ptr(kterm), _stream()), "qd_attn_keyterm")
+    return kterm
+
+
+def attn_config(pipe_mode=-1, xcd=-1, ktab=-1):
+    load().qd_attn_config(int(pipe_mode), int(xcd), int(ktab))
+
+
 def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, wmax, q_asym, out, ldo,
-            out8=None, oq_params=None, oq_grid=None):
+            out8=None, oq_params=None, oq_grid=None, kterm=None):
     """q_asym: the q quantiser has a non-zero stored zero point (the kernel restores -zq'*sum_d k' itself).
-    out8 (+ oq_params, oq_grid): write the output as the int8 input rows of the consuming Linear instead of fp32."""
+    out8 (+ oq_params, oq_grid): write the output as the int8 input rows of the consuming Linear instead of fp32.
+    kterm: the table attn_keyterm built for this k operand (a caller with a static k — a prepared cross-attention context —
+    passes its own); None: built here when the head dim takes one."""
     g = oq_grid
-    _check(load().qd_attn_i8(_ptr(q), _ptr(k), _ptr(vt), None, None, _ptr(vsum), BH, H, T, S, d, Tpad, Spad,
+    if kterm is None and attn_uses_keyterm(d, q_asym):
+        kterm = attn_keyterm(k, BH, Spad, dpad, prm)
+    _check(load().qd_attn_i8(_ptr(q), _ptr(k), _ptr(vt), None, _ptr(kterm), _ptr(vsum), BH, H, T, S, d, Tpad, Spad,
                              dpad, _ptr(prm), wbits, wmin, wmax, 1 if q_asym else 0, _ptr(out), ldo,
                              _ptr(out8), out8.stride(0) if out8 is not None else 0, _ptr(_qp(oq_params)),
                              g.qmin if g else 0, g.qmax if g else 0, g.off if g else 0, _stream()), "qd_attn_i8")

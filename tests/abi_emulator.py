@@ -281,8 +281,23 @@ def quantize_heads(x, B, T, H, d, strides, prescale, qparams, grid, transpose, o
             rsum.copy_(buf.sum(1).to(torch.int32))
 
 
+def attn_uses_keyterm(d, q_asym):
+    return bool(q_asym) and d < 64 and d % 32 != 0
+
+
+def attn_keyterm(k, BH, Spad, dpad, prm, kterm=None):
+    """qd_attn_keyterm: accumulator seeds 0x4B400000 - zq' * sum_c k[bh][j][c] (int32 [BH][Spad])."""
+    t = (0x4B400000 - int(float(prm[1])) * k.to(torch.int64).sum(-1)).to(torch.int32)
+    if kterm is None:
+        return t
+    kterm.copy_(t)
+    return kterm
+
+
 def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, wmax, q_asym, out, ldo,
-            out8=None, oq_params=None, oq_grid=None):
+            out8=None, oq_params=None, oq_grid=None, kterm=None):
+    if kterm is not None:        # a caller-supplied table must be the one of THIS k operand and zero point
+        assert torch.equal(kterm, attn_keyterm(k, BH, Spad, dpad, prm)), "stale key-term table"
     cs, zq, zk, dw, zpw, osc, zv = (float(prm[i]) for i in range(7))
     inv = torch.empty(Spad, dtype=torch.long)
     inv[_perm_index(Spad)] = torch.arange(Spad)
@@ -406,6 +421,6 @@ def install(monkeypatch):
     """Replace qdiff.hip's device entry points by the emulation (CPU tensors only)."""
     from qdiff import hip
     for name in ("make_qparams", "quantize_act", "pack_weights", "pack_weights_t4", "pack_weights_t8", "conv2d_i8", "groupnorm_ws_bytes", "groupnorm_silu_quant",
-                 "layernorm_quant", "geglu_quant", "quantize_heads", "attn_i8", "splitk_ws_bytes", "bmm_qk_i8", "bmm_pv_i8", "temb_mlp",
+                 "layernorm_quant", "geglu_quant", "quantize_heads", "attn_i8", "attn_keyterm", "attn_uses_keyterm", "splitk_ws_bytes", "bmm_qk_i8", "bmm_pv_i8", "temb_mlp",
                  "pack_weights_bf16", "conv2d_bf16", "groupnorm_silu_bf16"):
         monkeypatch.setattr(hip, name, globals()[name])

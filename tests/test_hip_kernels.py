@@ -643,7 +643,7 @@ PIPE_CASES = [
 
 
 @pytest.mark.parametrize("case", PIPE_CASES, ids=[c[0] for c in PIPE_CASES])
-def test_attention_lds_equals_lean(cuda, case, monkeypatch):
+def test_attention_lds_equals_lean(cuda, case):
     """attn_lds_kernel (K / V^T tiles staged once per block in LDS by DMA, one-tile-deep software pipeline, hi-byte skip)
     against attn_lean_kernel on the same operands: the arithmetic, the operand order and the summation order are the same, so
     outputs must be BIT-IDENTICAL.  (The lean kernel itself is held to the integer oracle by test_attention_fused.)"""
@@ -674,14 +674,37 @@ def test_attention_lds_equals_lean(cuda, case, monkeypatch):
     vsum = torch.zeros((B * H, dp), dtype=torch.int32, device=cuda)
     for which, (t, L, buf) in enumerate(((q, T, q8), (k, S, k8), (v, S, v8))):
         engine.heads_from_float(ap, which, t.to(cuda), B, L, H, d, (L * C, C, d, 1), buf, vsum)
+    from qdiff import hip
     outs = {}
-    for mode in ("0", "3"):                       # 0: attn_lean_kernel, 3: attn_lds_kernel on every eligible shape
-        monkeypatch.setenv("QD_ATTN_PIPE", mode)
-        o = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d)
+    try:
+        # pipe 0: attn_lean_kernel, 3: attn_lds_kernel on every eligible shape; ktab 1: per-key zero-point term from the
+        # qd_attn_keyterm table (accumulator seeds), 0: from constant-operand MFMAs — the accumulators hold the same integers
+        for mode in (0, 3):
+            for ktab in (1, 0):
+                hip.attn_config(pipe_mode=mode, ktab=ktab)
+                o = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d)
+                torch.cuda.synchronize()
+                outs[(mode, ktab)] = o.clone()
+    finally:
+        hip.attn_config(pipe_mode=2, ktab=1)
+    ref = outs[(0, 1)]
+    assert torch.isfinite(ref).all() and ref.abs().max() > 0
+    for key, o in outs.items():
+        assert torch.equal(ref, o), (key, (ref - o).abs().max().item())
+
+
+def test_attention_keyterm_table(cuda):
+    """qd_attn_keyterm: seeds 0x4B400000 - zq' * (row sums of the stored K bytes), for dpad 64 and 32."""
+    from qdiff import hip
+    g = torch.Generator().manual_seed(5)
+    for BH, Spad, dpad, zq in ((6, 96, 64, -9), (4, 160, 32, -128), (3, 4096, 64, 127)):
+        k8 = torch.randint(-128, 128, (BH, Spad, dpad), dtype=torch.int8, generator=g)
+        prm = torch.zeros(16)
+        prm[1] = float(zq)
+        got = hip.attn_keyterm(k8.to(cuda), BH, Spad, dpad, prm.to(cuda))
         torch.cuda.synchronize()
-        outs[mode] = o.clone()
-    assert torch.isfinite(outs["0"]).all() and outs["0"].abs().max() > 0
-    assert torch.equal(outs["0"], outs["3"]), (outs["0"] - outs["3"]).abs().max().item()
+        want = (0x4B400000 - zq * k8.long().sum(-1)).to(torch.int32)
+        assert torch.equal(got.cpu(), want)
 
 
 @pytest.mark.parametrize("T,N,K", [(128, 320, 320), (256, 640, 640), (512, 320, 1280)])

@@ -45,17 +45,31 @@ def main():
         v8[:, :d, :S] = torch.randint(-128, 128, (BH, d, S), dtype=torch.int8, device=dev, generator=g)
         vsum = v8.int().sum(-1).contiguous()
         out = torch.empty((B * T, H * d), dtype=torch.float32, device=dev)
+        # the key-term table (qd_attn_keyterm) is built OUTSIDE the timed attention calls and timed on its own: per call for a
+        # self-attention, once per sampling run for a prepared cross-attention context
+        from qdiff import hip
+        kterm, kt_us = None, 0.0
+        if hip.attn_uses_keyterm(d, ap.asym):
+            kterm = hip.attn_keyterm(k8, BH, Sp, dp, ap.prm)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                hip.attn_keyterm(k8, BH, Sp, dp, ap.prm, kterm)
+            e1.record()
+            torch.cuda.synchronize()
+            kt_us = e0.elapsed_time(e1) * 1000.0 / iters
         for _ in range(2):
-            engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d, out=out)
+            engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d, out=out, kterm=kterm)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d, out=out)
+            engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d, out=out, kterm=kterm)
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1000.0 / iters
         scores = BH * T * S
-        print(f"{name:32s} BH={BH:4d} T={T:5d} S={S:5d} d={d:4d}  {us:9.1f} us  {scores / us / 1e6:7.3f} T scores/s")
+        print(f"{name:32s} BH={BH:4d} T={T:5d} S={S:5d} d={d:4d}  {us:9.1f} us  {scores / us / 1e6:7.3f} T scores/s"
+              + (f"   (+ key-term table {kt_us:.1f} us)" if kterm is not None else ""))
 
 
 if __name__ == "__main__":

@@ -19,7 +19,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 enum { T_FMA, T_PKFMA, T_EXP, T_MAX3, T_PERM, T_CVT, T_ADDU, T_DOT4, T_MUL24, T_MFMA32_IND, T_MFMA32_DEP, T_MFMA16_IND, T_MFMA16_DEP,
        T_MIX_ATTN1, T_MIX_MFMA_FMA4, T_MIX_MFMA_FMA8, T_MIX_MFMA_EXP4, T_SPLIT_ROLES, T_LDSR128, T_MIX_MFMA_LDS,
-       T_S2_MIX, T_S2_NOEXP, T_S2_NOPK, T_S2_NOPERM, T_S2_ALLFMA, T_S2_VALUONLY, T_S2_MIX_DEP, T_COUNT };
+       T_S2_MIX, T_S2_NOEXP, T_S2_NOPK, T_S2_NOPERM, T_S2_ALLFMA, T_S2_VALUONLY, T_S2_MIX_DEP, T_MFMA32K16_IND, T_MFMA32K16_DEP, T_COUNT };
 
 static const char* NAMES[T_COUNT] = {"v_fma_f32 x32", "v_pk_fma_f32 x32", "v_exp_f32 x32", "v_max3_i32 x32", "v_perm_b32 x32", "v_cvt_f32_i32 x32",
     "v_add_u32 x32", "v_dot4_i32_i8 x32", "v_mul_i32_i24 x32", "mfma_i32_32x32x32_i8 x8 (4 independent acc)", "mfma_i32_32x32x32_i8 x8 (1 dependent acc)",
@@ -27,8 +27,9 @@ static const char* NAMES[T_COUNT] = {"v_fma_f32 x32", "v_pk_fma_f32 x32", "v_exp
     "attention sweep-1 tile: 4 mfma32 (dep) + 8x(max3, pk_fma, 2 exp, pk_add)", "4 mfma32 (ind) + 16 v_fma interleaved", "4 mfma32 (ind) + 32 v_fma interleaved",
     "4 mfma32 (ind) + 16 v_exp interleaved", "waves 0,1: 8 mfma32 only | waves 2,3 (other SIMDs) ... see note", "ds_read_b128 x16", "4 mfma32 (ind) + 8 ds_read_b128",
     "sweep-2 slice x4: mfma(ind) + 2 pk_fma, 2 exp, 3 perm, 2 xor", "  ... exp -> v_fma", "  ... pk_fma -> 2 v_fma", "  ... perm/xor -> v_fma",
-    "  ... every VALU -> v_fma (9 per mfma)", "  ... the VALU mix without the MFMAs", "  ... the mix with a DEPENDENT mfma chain (one accumulator)"};
-static const int NINSTR[T_COUNT] = {32, 32, 32, 32, 32, 32, 32, 32, 32, 8, 8, 8, 8, 4 + 8 * 5, 20, 36, 20, 8, 16, 12, 40, 40, 48, 40, 40, 36, 40};
+    "  ... every VALU -> v_fma (9 per mfma)", "  ... the VALU mix without the MFMAs", "  ... the mix with a DEPENDENT mfma chain (one accumulator)",
+    "mfma_i32_32x32x16_i8 (gfx942 shape, K = 16) x8 (4 independent acc)", "mfma_i32_32x32x16_i8 (gfx942 shape, K = 16) x8 (1 dependent acc)"};
+static const int NINSTR[T_COUNT] = {32, 32, 32, 32, 32, 32, 32, 32, 32, 8, 8, 8, 8, 4 + 8 * 5, 20, 36, 20, 8, 16, 12, 40, 40, 48, 40, 40, 36, 40, 8, 8};
 
 template <int T>
 __global__ __launch_bounds__(256) void bench(long long* out, int seed) {
@@ -83,6 +84,14 @@ __global__ __launch_bounds__(256) void bench(long long* out, int seed) {
         } else if constexpr (T == T_MFMA32_DEP) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[0], 0, 0, 0);
+        } else if constexpr (T == T_MFMA32K16_IND) {
+            const long a8 = ((long)a.x << 32) | (unsigned)a.y, b8 = ((long)b.x << 32) | (unsigned)b.y;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u & 3] = __builtin_amdgcn_mfma_i32_32x32x16_i8(a8, b8, acc[u & 3], 0, 0, 0);
+        } else if constexpr (T == T_MFMA32K16_DEP) {
+            const long a8 = ((long)a.x << 32) | (unsigned)a.y, b8 = ((long)b.x << 32) | (unsigned)b.y;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[0] = __builtin_amdgcn_mfma_i32_32x32x16_i8(a8, b8, acc[0], 0, 0, 0);
         } else if constexpr (T == T_MFMA16_IND) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc4[u & 3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc4[u & 3], 0, 0, 0);
@@ -219,6 +228,7 @@ void run(long long* dout, std::vector<long long>& h) {
 
 int main(int argc, char** argv) {
     const bool only_s2 = argc > 1 && std::string(argv[1]) == "s2";
+    const bool only_mfma = argc > 1 && std::string(argv[1]) == "mfma";
     long long* dout;
     hipMalloc(&dout, sizeof(long long) * (1 + 256 * 3 * 4));
     std::vector<long long> h(1 + 256 * 3 * 4);
@@ -237,6 +247,11 @@ int main(int argc, char** argv) {
         hipMemcpy(h.data(), dout, sizeof(long long) * 5, hipMemcpyDeviceToHost);
         printf("calibration: kernel wall %.1f us, wave ticks %lld -> %.1f ticks/us; %d mfma32 per wave -> %.1f ns per MFMA\n", ms * 1000.0, h[1],
                (double)h[1] / (ms * 1000.0), ITERS * 8, ms * 1e6 / (ITERS * 8));
+    }
+    if (only_mfma) {
+        run<T_MFMA32_IND>(dout, h); run<T_MFMA32_DEP>(dout, h); run<T_MFMA32K16_IND>(dout, h); run<T_MFMA32K16_DEP>(dout, h);
+        run<T_MFMA16_IND>(dout, h); run<T_MFMA16_DEP>(dout, h);
+        return 0;
     }
     if (!only_s2) {
     run<T_FMA>(dout, h); run<T_PKFMA>(dout, h); run<T_EXP>(dout, h); run<T_MAX3>(dout, h); run<T_PERM>(dout, h); run<T_CVT>(dout, h);
