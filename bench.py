@@ -446,12 +446,29 @@ def main():
         return qnn(xx, tt, cc) if cc is not None else qnn(xx, tt.float() if kind == "cifar" else tt)
 
     state = dict(x=x, old=[], i=0)
+    # The conditioning of a sampling run is constant (plms.py:184-187 rebuilds the same torch.cat([uncond, c]) at every step):
+    # build it once and let the model compute its cross-attention K / V^T operands ONCE per run (QuantModel.prepare_context,
+    # QDIFF_CTX_PIN=0 restores the per-evaluation computation).  The one-off cost is measured here and charged to every step
+    # as prepare_ms / evals (one preparation per image batch of `evals` evaluations).
+    ctx2, prepare_ms, ctx_prepared = None, 0.0, False
+    if ctx_shape:
+        ctx2 = torch.cat([uncond, cond])
+        with torch.no_grad():
+            qnn(torch.cat([x] * 2), torch.full((2 * x.shape[0],), 500, device=dev, dtype=torch.long), ctx2)   # plans, packs, graph of the unprepared shape
+            ctx_prepared = bool(qnn.prepare_context(ctx2))
+            if ctx_prepared:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    qnn.prepare_context(ctx2)
+                torch.cuda.synchronize()
+                prepare_ms = 1000.0 * (time.perf_counter() - t0) / 3
 
     def one_step():
         i = state["i"] % len(table)
         index = len(table) - i - 1
         t = torch.full((state["x"].shape[0],), int(table.timesteps[index]), device=dev, dtype=torch.long)
-        e = sampling.guided_eps(unet, state["x"], t, cond, uncond, guide)
+        e = sampling.guided_eps(unet, state["x"], t, cond, uncond, guide, ctx2)
         old = state["old"]
         if kind == "sd" and len(old) >= 3:
             e_prime = (55 * e - 59 * old[-1] + 37 * old[-2] - 9 * old[-3]) / 24
@@ -483,7 +500,7 @@ def main():
         elapsed = float(tt.item())
     assert torch.isfinite(state["x"]).all(), "sampler state diverged"
 
-    ms_per_step = 1000.0 * elapsed / a.steps
+    ms_per_step = 1000.0 * elapsed / a.steps + prepare_ms / evals
     images_per_s = gb / (evals * ms_per_step / 1000.0)
     out = {
         "metric": "denoising images/sec (whole node), SD-v1.4 W4A8 512x512 50-step PLMS" if kind == "sd" else f"denoising images/sec ({kind})",
@@ -491,8 +508,11 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": f"int8xint4->int32 ({stream_name} residual stream)", "data": "synthetic",
         "config": {"workload": f"{kind} UNet eval batch {2 * n if guide != 1.0 else n} per GPU, {evals} evals per image batch, "
-                               f"W{qspec['w_bits']}A8 sm_abit={qspec['sm_abit']}{'' if kind == 'churches' else ' split'}, hip-graph={'off' if a.no_graph else 'on'}",
+                               f"W{qspec['w_bits']}A8 sm_abit={qspec['sm_abit']}{'' if kind == 'churches' else ' split'}, hip-graph={'off' if a.no_graph else 'on'}"
+                               + (f", cross-attention K/V of the run's context prepared once per image batch ({prepare_ms:.2f} ms, charged as /{evals} per step)"
+                                  if ctx_prepared else (", cross-attention K/V recomputed per evaluation" if ctx_shape else "")),
                    "images_per_gpu": n, "global_batch": gb, "single_unet_step_ms": round(ms_per_step, 4),
+                   "context_prepare_ms": round(prepare_ms, 3), "context_prepared": ctx_prepared,
                    "parallelism": f"batch-sharded x{world}, quant-state broadcast {nbytes} B"},
     }
     if rank == 0:
@@ -500,7 +520,7 @@ def main():
         xb = state["x"]
         tb = torch.full((xb.shape[0],), 500, device=dev, dtype=torch.long)
         if guide != 1.0:
-            margs = [torch.cat([xb] * 2), torch.cat([tb] * 2), torch.cat([uncond, cond])]
+            margs = [torch.cat([xb] * 2), torch.cat([tb] * 2), ctx2]
         else:
             margs = [xb, tb.float() if kind == "cifar" else tb]
         measure_igemm(qnn, margs)                      # warm (eager path, caches)

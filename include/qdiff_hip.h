@@ -315,10 +315,10 @@ int qd_geglu_quant(const void* h, int h_dtype, int64_t M, int F, int64_t ldh,
  *           -zq' * sum_d k'[j][d].  qsum is ignored (may be NULL): the per-query terms -zk'*qsum_i + d*zq'*zk' are
  *           constant along a softmax row and cancel exactly.
  *     kterm (ABI 18; the slot that used to be `ksum`): NULL, or the table qd_attn_keyterm wrote for THIS k operand and
- *           THIS prm.  Head dims with qd_attn_uses_keyterm(d, q_asym) == 1 (d < 64, d % 32 != 0: SD's 4096-token level)
+ *           THIS prm.  Shapes with qd_attn_uses_keyterm(d, S, q_asym) == 1 (d < 64, d % 32 != 0, S >= 512: SD's 4096-token level)
  *           then seed the score accumulators from the table instead of issuing constant-operand MFMAs (2 of the 4
- *           score MFMAs of a 32x32 tile carried no data); results are bit-identical with and without it.  Other head
- *           dims ignore it.
+ *           score MFMAs of a 32x32 tile carried no data); results are bit-identical with and without it.  Other shapes
+ *           ignore it.
  *     qd_attn_keyterm: kterm[bh][j] = 0x4B400000 - zq' * sum_{c < dpad} k[bh][j][c]  (int32 [BH][Spad], dpad 32 or 64; pad
  *           bytes of k are zero).  One pass over the K operand; recompute whenever k or prm[1] changes — a cross-attention
  *           whose context is constant over a sampling run computes it once (quant_block.py:193-195 recomputes k per step).
@@ -332,7 +332,7 @@ int qd_quantize_heads(const void* x, int x_dtype, int B, int T, int H, int d,
                       const float* qparams, int qmin, int qmax, int off, int transpose,
                       int8_t* out, int32_t* rsum, int Tpad, int dpad, void* stream);
 
-int qd_attn_uses_keyterm(int d, int q_asym);
+int qd_attn_uses_keyterm(int d, int S, int q_asym);
 int qd_attn_keyterm(const int8_t* k, int BH, int Spad, int dpad, const float* prm, int32_t* kterm, void* stream);
 void qd_attn_config(int pipe_mode, int xcd, int ktab);
 int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt,

@@ -47,6 +47,55 @@ struct AttnK {
                               // K / V — 21 % L2 misses, profiles/r03_pmc_attn.txt)
 };
 
+// Epilogue of all three kernels: I = sum_j (u_j - zpw)(v'_j - zv'), restored exactly from the operand-byte accumulators
+// (ol / oh: lo / hi bytes of the codes against v'), the V^T column sums and the code sums us[r] of the lane's 16 queries;
+// o = float(I) * dw*dv, stored as fp32 rows or as the int8 input rows of the consuming Linear.
+//   * |I| <= 255 * sum_j |u_j - zpw| and sum_j round(p_j / dw) <= 1/dw + S/2: with the softmax quantiser's zero point at 0
+//     (always_zero, quant_block.py:240-252) the TRUE value is below 2^25 however large the individual terms are, so the
+//     restoration runs in wrapping 32-bit arithmetic (exact whenever the result fits, which the bound guarantees) and converts
+//     with v_cvt_f32_i32; the 64-bit form (emulated i64 -> f32 conversion: a third of the epilogue's instructions, and the
+//     epilogue is half of a 77-key cross-attention call) stays for grids where the bound does not hold.  Same value either
+//     way: one correctly rounded conversion of the same integer.
+template <int DT, bool P16>
+__device__ __forceinline__ void attn_write_rows(const AttnK& p, const v16i (&ol)[DT], const v16i (&oh)[P16 ? DT : 1], const int (&us)[16],
+                                                bool hi_live, int bh, int q0, int frow, int half, float dw, float zpw, float oscale, int zv) {
+    const int b = bh / p.H, hh = bh % p.H;
+    const int izpw = (int)zpw;
+    const QP oqp = p.out8 ? qd_load_qp(p.oq) : QP{1.f, 0.f, 1.f, false};
+    const long kconst = (hi_live ? 256L * 128L : 0L) + 128L + (long)p.iwmin - (long)izpw;     // multiplies vsum
+    const float code_sum = (1.0f / dw) * 1.01f + 0.5f * (float)p.S + (float)p.S * fmaxf(0.f, p.wmin - zpw) + 16.f;
+    const bool small = code_sum * 255.f < 2.0e9f;                 // grid-uniform
+    auto epi = [&](auto ft, auto st) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(ft)::value, SMALL = decltype(st)::value;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+        const int dd = t * 32 + frow;
+        const long vs = (dd < p.d) ? p.vsum[(long)bh * p.dpad + dd] : 0;
+        const long ct = kconst * vs + (long)p.S * izpw * zv;      // the column's share
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int il = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int i = q0 + il;
+            if (dd >= p.d || i >= p.T) continue;
+            float o;
+            if (SMALL) {
+                unsigned I = (unsigned)ol[t][r] + (unsigned)ct - (unsigned)zv * (unsigned)us[r];
+                if (P16 && hi_live) I += (unsigned)oh[P16 ? t : 0][r] << 8;
+                o = (float)(int)I * oscale;
+            } else {
+                long I = (long)ol[t][r] + ct - (long)zv * us[r];
+                if (P16 && hi_live) I += 256L * (long)oh[P16 ? t : 0][r];
+                o = (float)I * oscale;
+            }
+            if (p.out8) p.out8[((long)b * p.T + i) * p.ldo8 + hh * p.d + dd] = (int8_t)(qd_code_t<FAST>(o, oqp, p.oqmin, p.oqmax) - p.oqoff);
+            else p.out[((long)b * p.T + i) * p.ldo + hh * p.d + dd] = o;
+        }
+    }
+    };
+    if (small) QD_FAST_DISPATCH(oqp.fast, [&](auto ft) __attribute__((always_inline)) { epi(ft, std::true_type{}); });
+    else QD_FAST_DISPATCH(oqp.fast, [&](auto ft) __attribute__((always_inline)) { epi(ft, std::false_type{}); });
+}
+
 // prm layout (device floats): 0 cs = dq*dk*scale | 1 zq' | 2 zk' | 3 dw | 4 zpw | 5 dw*dv | 6 zv'
 //
 // VALU budget.  The kernel is VALU-bound (every score costs an int->float convert, an exp2 at quarter
@@ -275,31 +324,11 @@ __global__ __launch_bounds__(256, (DT * (P16 ? 2 : 1) <= 6) ? 2 : 1) void attn_k
     nvalid += __shfl_xor(nvalid, 32);
     const int usum = uusum + nvalid * p.iwmin;                     // sum over valid keys of the codes u = uu + wmin
 
-    // ---- epilogue: restore zero points (exact, int64), scale, store merged-head rows ------------
-    const int b = bh / p.H, hh = bh % p.H;
-    const QP oqp = p.out8 ? qd_load_qp(p.oq) : QP{1.f, 0.f, 1.f, false};
-    const long kconst = (P16 ? 256L * 128L : 0L) + 128L + (long)p.iwmin - (long)izpw;  // multiplies vsum
-    auto epi = [&](auto ft) __attribute__((always_inline)) {
-    constexpr bool FAST = decltype(ft)::value;
+    // ---- epilogue: restore zero points (exact integers), scale, store merged-head rows ------------
+    int us[16];
 #pragma unroll
-    for (int t = 0; t < DT; ++t) {
-        const int dd = t * 32 + frow;
-        const long vs = (dd < p.d) ? p.vsum[(long)bh * p.dpad + dd] : 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int il = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int us = __shfl(usum, il);
-            const int i = q0 + il;
-            if (dd >= p.d || i >= p.T) continue;
-            long I = (long)ol[t][r] + kconst * vs - (long)zv * us + (long)p.S * izpw * zv;
-            if (P16) I += 256L * (long)oh[P16 ? t : 0][r];
-            const float o = (float)I * oscale;
-            if (p.out8) p.out8[((long)b * p.T + i) * p.ldo8 + hh * p.d + dd] = (int8_t)(qd_code_t<FAST>(o, oqp, p.oqmin, p.oqmax) - p.oqoff);
-            else p.out[((long)b * p.T + i) * p.ldo + hh * p.d + dd] = o;
-        }
-    }
-    };
-    QD_FAST_DISPATCH(oqp.fast, epi);
+    for (int r = 0; r < 16; ++r) us[r] = __shfl(usum, (r & 3) + 8 * (r >> 2) + 4 * half);
+    attn_write_rows<DT, P16>(p, ol, oh, us, P16, bh, q0, frow, half, dw, zpw, oscale, zv);
 }
 
 // ---- lean variant (head dims that are NOT a multiple of 32 and < 64: Stable Diffusion's 4096-token, d = 40 level) -----
@@ -582,9 +611,6 @@ __device__ __forceinline__ void attn_lean_body(const AttnK& p) {
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------
-    const int b = bh / p.H, hh = bh % p.H;
-    const QP oqp = p.out8 ? qd_load_qp(p.oq) : QP{1.f, 0.f, 1.f, false};
-    const long kconst = (P16 ? 256L * 128L : 0L) + 128L + (long)p.iwmin - (long)izpw;
     // code sums of query il(r, half): column d of the output tile, i.e. register r of lane frow1 + 32*half
     int us[16];
 #pragma unroll
@@ -601,26 +627,7 @@ __device__ __forceinline__ void attn_lean_body(const AttnK& p) {
         // sum over the valid keys of uu = 256*hi + lo from the signed operand bytes, then of u = uu + wmin
         us[r] = sl + 128 * p.S + (P16 ? 256 * (sh + 128 * p.S) : 0) + p.S * p.iwmin;
     }
-    auto epi = [&](auto ft) __attribute__((always_inline)) {
-    constexpr bool FAST = decltype(ft)::value;
-#pragma unroll
-    for (int t = 0; t < DT; ++t) {
-        const int dd = t * 32 + frow;
-        const long vs = (dd < p.d) ? p.vsum[(long)bh * p.dpad + dd] : 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int il = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int i = q0 + il;
-            if (dd >= p.d || i >= p.T) continue;
-            long I = (long)ol[t][r] + kconst * vs - (long)zv * us[r] + (long)p.S * izpw * zv;
-            if (P16) I += 256L * (long)oh[P16 ? t : 0][r];
-            const float o = (float)I * oscale;
-            if (p.out8) p.out8[((long)b * p.T + i) * p.ldo8 + hh * p.d + dd] = (int8_t)(qd_code_t<FAST>(o, oqp, p.oqmin, p.oqmax) - p.oqoff);
-            else p.out[((long)b * p.T + i) * p.ldo + hh * p.d + dd] = o;
-        }
-    }
-    };
-    QD_FAST_DISPATCH(oqp.fast, epi);
+    attn_write_rows<DT, P16>(p, ol, oh, us, P16, bh, q0, frow, half, dw, zpw, oscale, zv);
 }
 
 #ifndef QD_ATTN_LEAN_OCC
@@ -1016,9 +1023,6 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
     if (!live) return;
 
     // ---- epilogue (attn_lean_kernel's, with the 8-bit constants when the hi bytes were provably all zero) --------------
-    const int b = bh / p.H, hh = bh % p.H;
-    const QP oqp = p.out8 ? qd_load_qp(p.oq) : QP{1.f, 0.f, 1.f, false};
-    const long kconst = (hi_live ? 256L * 128L : 0L) + 128L + (long)p.iwmin - (long)izpw;
     int us[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1033,26 +1037,7 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
         if (P16) sh = __shfl(sh, frow1 + 32 * half);
         us[r] = sl + 128 * p.S + (hi_live ? 256 * (sh + 128 * p.S) : 0) + p.S * p.iwmin;
     }
-    auto epi = [&](auto ft) __attribute__((always_inline)) {
-    constexpr bool FAST = decltype(ft)::value;
-#pragma unroll
-    for (int t = 0; t < DT; ++t) {
-        const int dd = t * 32 + frow;
-        const long vs = (dd < p.d) ? p.vsum[(long)bh * p.dpad + dd] : 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int il = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int i = q0 + il;
-            if (dd >= p.d || i >= p.T) continue;
-            long I = (long)ol[t][r] + kconst * vs - (long)zv * us[r] + (long)p.S * izpw * zv;
-            if (hi_live) I += 256L * (long)oh[P16 ? t : 0][r];
-            const float o = (float)I * oscale;
-            if (p.out8) p.out8[((long)b * p.T + i) * p.ldo8 + hh * p.d + dd] = (int8_t)(qd_code_t<FAST>(o, oqp, p.oqmin, p.oqmax) - p.oqoff);
-            else p.out[((long)b * p.T + i) * p.ldo + hh * p.d + dd] = o;
-        }
-    }
-    };
-    QD_FAST_DISPATCH(oqp.fast, epi);
+    attn_write_rows<DT, P16>(p, ol, oh, us, hi_live, bh, q0, frow, half, dw, zpw, oscale, zv);
 }
 
 // kt: 0 = symmetric q (no per-key term), 1 = constant-operand MFMAs, 2 = key-term table (AttnK::kterm)
@@ -1122,7 +1107,13 @@ extern "C" void qd_attn_config(int pipe_mode, int xcd, int ktab) {
     if (ktab >= 0) k.ktab = ktab;
 }
 
-extern "C" int qd_attn_uses_keyterm(int d, int q_asym) { return (q_asym != 0 && attn_lean_shape(d) && attn_knobs().ktab != 0) ? 1 : 0; }
+// the table pays where the LDS-staged kernel runs (thousands of keys); the register-fed kernel on short key axes (the 77
+// context tokens: 3 tiles per sweep, 3 waves per SIMD) keeps the constant-operand MFMAs — it has no registers to spare
+// for 16 seeds per tile and nothing to gain from them; pipe modes 0 / 3 (tests, A/B runs) take a table on every key axis
+extern "C" int qd_attn_uses_keyterm(int d, int S, int q_asym) {
+    const AttnKnobs& k = attn_knobs();
+    return (q_asym != 0 && attn_lean_shape(d) && k.ktab != 0 && (k.pipe != 2 || S >= 512)) ? 1 : 0;
+}
 
 extern "C" int qd_attn_keyterm(const int8_t* k, int BH, int Spad, int dpad, const float* prm, int32_t* kterm, void* stream) {
     QD_REQUIRE(k && prm && kterm, "qd_attn_keyterm: null pointer");
@@ -1162,7 +1153,7 @@ extern "C" int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt, co
     // pipe: 2 = LDS-staged kernel wherever it pays (default), 0 = attn_lean_kernel everywhere (A/B runs and the equality
     // test), 3 = LDS-staged kernel on every eligible shape
     if (attn_lean_shape(d)) {
-        const int kt = !asym ? 0 : (kterm && kn.ktab != 0) ? 2 : 1;     // per-key zero-point term: none / constant-operand MFMAs / table
+        const int kt = !asym ? 0 : (kterm && qd_attn_uses_keyterm(d, S, q_asym)) ? 2 : 1;     // per-key zero-point term: none / constant-operand MFMAs / table
         const bool lds_fits = Spad <= QD_ONES_ROW && (long)Spad * dpad < (1L << 31);
         if (lds_fits && (kn.pipe == 3 || (kn.pipe == 2 && S >= 512))) {         // short key axes: ring start-up and barriers lose
             if (dpad == 32) launch_lds<1>(a, p16, kt, st);

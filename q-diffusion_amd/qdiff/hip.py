@@ -106,7 +106,7 @@ def load():
     lib.qd_attn_i8.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp,
                                i64, vp, i64, vp, i32, i32, i32, vp]
     lib.qd_attn_keyterm.argtypes = [vp, i32, i32, i32, vp, vp, vp]
-    lib.qd_attn_uses_keyterm.argtypes = [i32, i32]
+    lib.qd_attn_uses_keyterm.argtypes = [i32, i32, i32]
     lib.qd_attn_config.argtypes = [i32, i32, i32]
     lib.qd_attn_config.restype = None
     lib.qd_temb_mlp.argtypes = [vp, i64, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i64, vp]
@@ -436,9 +436,9 @@ def quantize_heads(x, B, T, H, d, strides, prescale, qparams, grid, transpose, o
                                     dpad, _stream()), "qd_quantize_heads")
 
 
-def attn_uses_keyterm(d, q_asym):
-    """The attention launcher takes a key-term table for this head dim (qd_attn_keyterm)."""
-    return bool(load().qd_attn_uses_keyterm(int(d), 1 if q_asym else 0))
+def attn_uses_keyterm(d, S, q_asym):
+    """The attention launcher takes a key-term table for this head dim and key count (qd_attn_keyterm)."""
+    return bool(load().qd_attn_uses_keyterm(int(d), int(S), 1 if q_asym else 0))
 
 
 def attn_keyterm(k, BH, Spad, dpad, prm, kterm=None):
@@ -460,7 +460,7 @@ def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, 
     kterm: the table attn_keyterm built for this k operand (a caller with a static k — a prepared cross-attention context —
     passes its own); None: built here when the head dim takes one."""
     g = oq_grid
-    if kterm is None and attn_uses_keyterm(d, q_asym):
+    if kterm is None and attn_uses_keyterm(d, S, q_asym):
         kterm = attn_keyterm(k, BH, Spad, dpad, prm)
     _check(load().qd_attn_i8(_ptr(q), _ptr(k), _ptr(vt), None, _ptr(kterm), _ptr(vsum), BH, H, T, S, d, Tpad, Spad,
                              dpad, _ptr(prm), wbits, wmin, wmax, 1 if q_asym else 0, _ptr(out), ldo,

@@ -80,6 +80,7 @@ class QuantModel(nn.Module):
             elif isinstance(m, QuantResnetBlock) and isinstance(m.temb_proj, QuantModule):
                 group.register(m, m.temb_proj)
         ctx = ContextKV()                # cross-attention keys / values of every transformer block: one side-stream branch
+        self.__dict__["_ctx_kv"] = ctx
         for m in self.model.modules():
             if isinstance(m, QuantBasicTransformerBlock):
                 ctx.register(m)
@@ -231,8 +232,32 @@ class QuantModel(nn.Module):
         ok = ready and self._quant_state == (True, True) and not torch.is_grad_enabled() and not engine.SIMULATE
         engine._EFFECTIVE[0] = engine.STREAM_DTYPE if ok else torch.float32
 
+    def prepare_context(self, context):
+        """Compute the cross-attention K / V^T operands of every transformer block for `context` ONCE; evaluations that are
+        handed this very tensor (same object, not modified in place since) skip the ~150-launch chain of to_k / to_v /
+        head-layout quantisers that the reference repeats in each of the 51 evaluations of a sampling run
+        (quant_block.py:193-195; plms.py:184-187 passes the same `torch.cat([uncond, c])` at every step).  Static input,
+        static weights, static quantisers: the bytes are those the per-evaluation branch produces, bit for bit
+        (tests/test_engine_models.py::test_prepared_context_changes_nothing).  Only in the integer state with every
+        quantiser initialised and no running statistics; returns False (and changes nothing) otherwise or when QDIFF_CTX_PIN=0.
+        Any other context, a changed quant state or re-packed weights fall back to the per-evaluation branch; call again for a
+        new context.  The captured HIP graph of a prepared evaluation reads the pinned buffers and survives re-preparation."""
+        ctx = self.__dict__.get("_ctx_kv")
+        if (ctx is None or not torch.is_tensor(context) or self._quant_state != (True, True) or torch.is_grad_enabled()
+                or engine.SIMULATE or self.model.training):
+            if ctx is not None:
+                ctx.unpin()
+            return False
+        return ctx.pin(context)
+
+    def release_context(self):
+        ctx = self.__dict__.get("_ctx_kv")
+        if ctx is not None:
+            ctx.unpin()
+
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
         self.__dict__["_stream_ready"] = False
+        self.release_context()
         self._quant_state = (bool(weight_quant), bool(act_quant))
         for m in self.model.modules():
             if isinstance(m, (QuantModule, BaseQuantBlock)):
@@ -241,10 +266,12 @@ class QuantModel(nn.Module):
     def forward(self, x, timesteps=None, context=None):
         if self._graphs is not None and not torch.is_grad_enabled() and torch.is_tensor(timesteps) and x.is_cuda:
             from .graph import GraphedUNet, signature
-            key = signature(x, timesteps, context) + (self._quant_state, engine.STREAM_DTYPE)
+            ckv = self.__dict__.get("_ctx_kv")
+            pinned = bool(context is not None and ckv is not None and ckv._pin is not None and ckv.pinned(context, deep=False))
+            key = signature(x, timesteps, context) + (self._quant_state, engine.STREAM_DTYPE, pinned)
             g = self._graphs.get(key)
             if g is None:
-                g = self._graphs[key] = GraphedUNet(self, x, timesteps, context)
+                g = self._graphs[key] = GraphedUNet(self, x, timesteps, context, pinned=pinned)
             return g(x, timesteps, context).to(x.dtype, copy=True)
         y = self.model(x, timesteps, context)
         # an fp16 activation stream ends here: the samplers' update arithmetic runs in the latent's own type
@@ -253,6 +280,7 @@ class QuantModel(nn.Module):
     def invalidate_plans(self):
         """Forget every packed weight / epilogue constant / captured graph (see QuantModule.invalidate)."""
         self.__dict__["_stream_ready"] = False
+        self.release_context()
         for m in self.model.modules():
             if isinstance(m, QuantModule):
                 m.invalidate()
@@ -269,6 +297,7 @@ class QuantModel(nn.Module):
     def set_running_stat(self, running_stat: bool, sm_only=False):
         """reference :71-87"""
         self.__dict__["_stream_ready"] = False
+        self.release_context()
         for m in self.model.modules():
             if isinstance(m, QuantBasicTransformerBlock):
                 names = ("act_quantizer_w",) if sm_only else ("act_quantizer_q", "act_quantizer_k", "act_quantizer_v",

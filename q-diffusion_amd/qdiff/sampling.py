@@ -91,12 +91,26 @@ class StepTable:
 # ------------------------------------------------------------------------------------------------
 # samplers
 # ------------------------------------------------------------------------------------------------
-def guided_eps(unet, x, t, cond, uncond, scale):
-    """Classifier-free guidance on a doubled batch (plms.py:183-190 / ddim.py:176-193)."""
+def guided_eps(unet, x, t, cond, uncond, scale, ctx2=None):
+    """Classifier-free guidance on a doubled batch (plms.py:183-190 / ddim.py:176-193).
+    ctx2: `torch.cat([uncond, cond])` made once by the caller (see guidance_context) instead of at every step."""
     if uncond is None or scale == 1.0:
         return unet(x, t, cond)
-    e_u, e_c = unet(torch.cat([x] * 2), torch.cat([t] * 2), torch.cat([uncond, cond])).chunk(2)
+    e_u, e_c = unet(torch.cat([x] * 2), torch.cat([t] * 2), ctx2 if ctx2 is not None else torch.cat([uncond, cond])).chunk(2)
     return e_u + scale * (e_c - e_u)
+
+
+def guidance_context(unet, cond, uncond, scale):
+    """The conditioning the UNet sees at EVERY step of a sampling run — `torch.cat([uncond, cond])` under classifier-free
+    guidance (plms.py:184-187 rebuilds it per step), else `cond` — built once, and announced to a qdiff.QuantModel
+    (`prepare_context`): its cross-attention K / V^T operands are then computed once per run instead of once per evaluation.
+    Returns the tensor to hand to guided_eps as ctx2 (None when there is no guidance pair)."""
+    ctx2 = None if (uncond is None or scale == 1.0 or cond is None) else torch.cat([uncond, cond])
+    prep = getattr(unet, "prepare_context", None)
+    target = ctx2 if ctx2 is not None else cond
+    if prep is not None and torch.is_tensor(target):
+        prep(target)
+    return ctx2
 
 
 @torch.no_grad()
@@ -108,14 +122,15 @@ def plms_sample(unet, x_T, table, cond=None, uncond=None, scale=1.0, callback=No
     order = np.flip(table.timesteps)
     total = len(order)
     old = []
+    ctx2 = guidance_context(unet, cond, uncond, scale)
     for i, step in enumerate(order):
         index = total - i - 1
         t = torch.full((b,), int(step), device=dev, dtype=torch.long)
-        e = guided_eps(unet, x, t, cond, uncond, scale)
+        e = guided_eps(unet, x, t, cond, uncond, scale, ctx2)
         if len(old) == 0:
             x_euler, _ = table.update(x, e, index)
             t_next = torch.full((b,), int(order[min(i + 1, total - 1)]), device=dev, dtype=torch.long)
-            e_next = guided_eps(unet, x_euler, t_next, cond, uncond, scale)
+            e_next = guided_eps(unet, x_euler, t_next, cond, uncond, scale, ctx2)
             e_prime = (e + e_next) / 2
         elif len(old) == 1:
             e_prime = (3 * e - old[-1]) / 2
@@ -155,6 +170,7 @@ class DevicePLMS:
         self.hist = [torch.zeros_like(x_T) for _ in range(3)]            # e_{k-1}, e_{k-2}, e_{k-3}
         self.use_graph = bool(use_graph) and dev.type == "cuda"
         self.graphs = {}
+        self.ctx2 = guidance_context(unet, cond, uncond, scale)          # the run's conditioning, prepared once
 
     def _coef(self, c):
         return c.index_select(0, self.i).reshape(())
@@ -165,7 +181,7 @@ class DevicePLMS:
 
     def _eps(self, x, ts):
         t = ts.index_select(0, self.i).expand(x.shape[0])
-        return guided_eps(self.unet, x, t, self.cond, self.uncond, self.scale)
+        return guided_eps(self.unet, x, t, self.cond, self.uncond, self.scale, self.ctx2)
 
     def _step(self, nold):
         e = self._eps(self.x, self.ts)
@@ -280,10 +296,11 @@ def dpm_solver_sample(unet, x_T, alphas_cumprod, steps, cond=None, uncond=None, 
     x = x_T
     b, dev = x.shape[0], x.device
     alpha_dev = tb.alpha.to(dev)
+    ctx2 = guidance_context(unet, cond, uncond, scale)
 
     def data_pred(xx, i):
         tt = torch.full((b,), float(tb.t_input[i]), device=dev, dtype=torch.float32)
-        eps = guided_eps(unet, xx, tt, cond, uncond, scale)
+        eps = guided_eps(unet, xx, tt, cond, uncond, scale, ctx2)
         # x0 prediction (dpm_solver.py:386-392); a TENSOR divisor = true fp32 division as in the reference (a Python float
         # would be turned into a reciprocal multiply by the GPU kernel: last-bit differences)
         return (xx - float(tb.sigma[i]) * eps) / alpha_dev[i]
@@ -315,10 +332,11 @@ def ddim_sample(unet, x_T, table, cond=None, uncond=None, scale=1.0, noise_fn=No
     b, dev = x.shape[0], x.device
     order = np.flip(table.timesteps)
     total = len(order)
+    ctx2 = guidance_context(unet, cond, uncond, scale)
     for i, step in enumerate(order):
         index = total - i - 1
         t = torch.full((b,), int(step), device=dev, dtype=torch.long)
-        e = guided_eps(unet, x, t, cond, uncond, scale)
+        e = guided_eps(unet, x, t, cond, uncond, scale, ctx2)
         noise = None
         if table.sigma[index] != 0.0:
             noise = noise_fn(i, x.shape) if noise_fn is not None else torch.randn(x.shape, device=dev)

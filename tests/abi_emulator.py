@@ -281,8 +281,8 @@ def quantize_heads(x, B, T, H, d, strides, prescale, qparams, grid, transpose, o
             rsum.copy_(buf.sum(1).to(torch.int32))
 
 
-def attn_uses_keyterm(d, q_asym):
-    return bool(q_asym) and d < 64 and d % 32 != 0
+def attn_uses_keyterm(d, S, q_asym):
+    return bool(q_asym) and d < 64 and d % 32 != 0 and S >= 512
 
 
 def attn_keyterm(k, BH, Spad, dpad, prm, kterm=None):

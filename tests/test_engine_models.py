@@ -236,6 +236,37 @@ def test_hip_graph_replay_equals_eager(cuda, name):
     assert torch.equal(e1, g1) and torch.equal(e2, g2) and torch.equal(g1, g1b)
 
 
+def test_prepared_context_changes_nothing(cuda):
+    """QuantModel.prepare_context on the GPU: the evaluation of a prepared context (cross-attention K / V^T operands and
+    key-term tables computed once, reference quant_block.py:193-195 recomputes them per evaluation) equals the per-evaluation
+    computation bit for bit — eager and as a HIP graph, for two different contexts, with the graph captured for the first
+    one replayed after re-preparation for the second, and with an unprepared tensor falling back to the ordinary graph."""
+    fx = load_fixture("model_sd_tiny.pt")
+    qnn = _resume(fx, cuda)
+    x, t, c = (a.to(cuda) for a in fixture_inputs(fx, "test"))
+    g = torch.Generator(device=cuda).manual_seed(11)
+    c2 = torch.randn(c.shape, device=cuda, generator=g)
+    x2 = torch.randn(x.shape, device=cuda, generator=g)
+    run = lambda a, cc: qnn(a, t, cc).clone()
+    with torch.no_grad():
+        want = {k: run(*k_args) for k, k_args in (("x,c", (x, c)), ("x2,c", (x2, c)), ("x,c2", (x, c2)), ("x2,c2", (x2, c2)))}
+        assert qnn.prepare_context(c)
+        got_eager = run(x, c)
+        qnn.enable_hip_graphs(True)
+        g1 = run(x, c)                       # captures the prepared evaluation
+        g2 = run(x2, c)                      # replays it
+        u1 = run(x, c2)                      # c2 is not prepared: the ordinary graph (context copied in, chain inside)
+        assert qnn.prepare_context(c2)       # pinned buffers rewritten in place
+        g3 = run(x, c2)                      # the prepared graph again, new operands
+        g4 = run(x2, c2)
+        u2 = run(x2, c)                      # c no longer prepared
+        assert len(qnn._graphs) == 2
+        qnn.enable_hip_graphs(False)
+    torch.cuda.synchronize()
+    assert torch.equal(got_eager, want["x,c"]) and torch.equal(g1, want["x,c"]) and torch.equal(g2, want["x2,c"])
+    assert torch.equal(u1, want["x,c2"]) and torch.equal(g3, want["x,c2"]) and torch.equal(g4, want["x2,c2"]) and torch.equal(u2, want["x2,c"])
+
+
 def test_whole_step_graph_plms_equals_eager_sampler(cuda):
     """One HIP graph per PLMS step (UNet on the CFG batch + guidance + multistep update, DevicePLMS) reproduces the eager
     plms_sample loop bit for bit on a quantised SD-style UNet."""

@@ -468,6 +468,74 @@ def test_running_stat_updates_match_the_simulation_path(emu, name):
     assert moved > 20
 
 
+def test_prepared_context_skips_the_chain_and_changes_nothing(emu, monkeypatch):
+    """QuantModel.prepare_context (cross-attention K / V^T operands once per sampling run instead of once per evaluation;
+    the reference recomputes to_k / to_v of the constant conditioning in every evaluation, quant_block.py:193-195): the
+    evaluation of the pinned tensor issues NO to_k / to_v GEMM and no head-layout quantiser, hands the attention kernel a
+    key-term table that belongs to the pinned keys (the emulator asserts it), and returns the unprepared output bit for bit —
+    for two different contexts; another tensor, an in-place modification, a quant-state flip and QDIFF_CTX_PIN=0 all fall
+    back to the per-evaluation branch."""
+    from qdiff import hip, quant_block as qb, sampling
+    fx = load_fixture("model_sd_tiny.pt")
+    qnn = _resume_cpu(fx)
+    x, t, c = fixture_inputs(fx, "test")
+    g = torch.Generator().manual_seed(3)
+    c2 = torch.randn(c.shape, generator=g)
+    with torch.no_grad():
+        want, want2 = qnn(x, t, c), qnn(x, t, c2)
+    calls = {"heads": 0, "kterm_given": 0}
+    real_qh, real_attn = hip.quantize_heads, hip.attn_i8
+
+    def counting_qh(*a, **kw):
+        calls["heads"] += 1
+        return real_qh(*a, **kw)
+
+    def counting_attn(*a, **kw):
+        calls["kterm_given"] += kw.get("kterm") is not None
+        return real_attn(*a, **kw)
+
+    monkeypatch.setattr(hip, "quantize_heads", counting_qh)
+    monkeypatch.setattr(hip, "attn_i8", counting_attn)
+    # the library takes a table only on long key axes (LDS-staged kernel); here every eligible head dim does, so that the
+    # pinned tables travel through the host code and reach the emulator's staleness check
+    monkeypatch.setattr(hip, "attn_uses_keyterm", lambda d, S, asym: bool(asym) and d < 64 and d % 32 != 0)
+    nblk = sum(isinstance(m, qb.QuantBasicTransformerBlock) for m in qnn.modules())
+    with torch.no_grad():
+        qnn(x, t, c)
+        per_eval = calls["heads"]
+        assert per_eval >= 2 * nblk                       # k and v^T of every cross-attention (+ ragged self-attention operands)
+        assert qnn.prepare_context(c) is True
+        calls.update(heads=0, kterm_given=0)
+        got = qnn(x, t, c)
+        assert calls["heads"] == per_eval - 2 * nblk, calls   # the context chain did not run
+        assert 0 < calls["kterm_given"] <= nblk, calls      # cross-attentions of eligible head dims got their pinned key-term tables
+        assert torch.equal(got, want)
+        assert qnn.prepare_context(c2) is True            # re-preparation for another context
+        assert torch.equal(qnn(x, t, c2), want2)
+        calls["heads"] = 0
+        assert torch.equal(qnn(x, t, c), want) and calls["heads"] == per_eval      # not the pinned tensor: per-evaluation branch
+        c2.add_(0.0)                                      # in-place version bump: the pin no longer vouches for the bytes
+        calls["heads"] = 0
+        assert torch.equal(qnn(x, t, c2), want2) and calls["heads"] == per_eval
+        qnn.prepare_context(c)
+        qnn.set_quant_state(True, True)                   # any state change drops the pin
+        calls["heads"] = 0
+        assert torch.equal(qnn(x, t, c), want) and calls["heads"] == per_eval
+        monkeypatch.setattr(qb, "_CTX_PIN", False)
+        assert qnn.prepare_context(c) is False
+        monkeypatch.setattr(qb, "_CTX_PIN", True)
+        # the samplers announce the run's conditioning themselves
+        table = sampling.StepTable(sampling.ldm_betas(0.00085, 0.0120), 4, eta=0.0)
+        uc = torch.randn(c.shape, generator=g)
+        unet = lambda xx, tt, cc=None: qnn(xx, tt, cc)
+        qnn.release_context()
+        ref = sampling.plms_sample(unet, x, table, cond=c, uncond=uc, scale=3.0)            # a plain callable: nothing to prepare
+        calls["heads"] = 0
+        got = sampling.plms_sample(qnn, x, table, cond=c, uncond=uc, scale=3.0)
+        assert torch.equal(got, ref)
+        assert calls["heads"] == 5 * (per_eval - 2 * nblk) + 2 * nblk, calls                # 4 steps = 5 evaluations, ONE context chain
+
+
 @pytest.mark.parametrize("name", ["cifar_tiny", "ldm_tiny", "sd_tiny", "ldm_updown_tiny"])
 def test_planned_concatenation_is_a_view_and_changes_nothing(emu, name, monkeypatch):
     """Skip concatenations (openaimodel.py:776, ddim diffusion.py:340) planned through engine.CatSlot + the skip

@@ -49,7 +49,7 @@ def main():
         # self-attention, once per sampling run for a prepared cross-attention context
         from qdiff import hip
         kterm, kt_us = None, 0.0
-        if hip.attn_uses_keyterm(d, ap.asym):
+        if hip.attn_uses_keyterm(d, S, ap.asym):
             kterm = hip.attn_keyterm(k8, BH, Sp, dp, ap.prm)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
