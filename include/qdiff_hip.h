@@ -315,11 +315,11 @@ int qd_geglu_quant(const void* h, int h_dtype, int64_t M, int F, int64_t ldh,
  *           -zq' * sum_d k'[j][d].  qsum is ignored (may be NULL): the per-query terms -zk'*qsum_i + d*zq'*zk' are
  *           constant along a softmax row and cancel exactly.
  *     kterm (ABI 18; the slot that used to be `ksum`): NULL, or the table qd_attn_keyterm wrote for THIS k operand and
- *           THIS prm.  Shapes with qd_attn_uses_keyterm(d, S, q_asym) == 1 (d < 64, d % 32 != 0, S >= 512: SD's 4096-token level)
+ *           THIS prm.  Shapes with qd_attn_uses_keyterm(d, S, q_asym) == 1 (d < 96, d % 32 != 0, S >= 512: SD's 4096- and 1024-token levels)
  *           then seed the score accumulators from the table instead of issuing constant-operand MFMAs (2 of the 4
  *           score MFMAs of a 32x32 tile carried no data); results are bit-identical with and without it.  Other shapes
  *           ignore it.
- *     qd_attn_keyterm: kterm[bh][j] = 0x4B400000 - zq' * sum_{c < dpad} k[bh][j][c]  (int32 [BH][Spad], dpad 32 or 64; pad
+ *     qd_attn_keyterm: kterm[bh][j] = 0x4B400000 - zq' * sum_{c < dpad} k[bh][j][c]  (int32 [BH][Spad], dpad 32, 64 or 96; pad
  *           bytes of k are zero).  One pass over the K operand; recompute whenever k or prm[1] changes — a cross-attention
  *           whose context is constant over a sampling run computes it once (quant_block.py:193-195 recomputes k per step).
  *     qd_attn_config: process-wide launcher knobs, -1 = leave unchanged.  pipe_mode 0 = register-fed kernel everywhere,

@@ -634,7 +634,7 @@ __device__ __forceinline__ void attn_lean_body(const AttnK& p) {
 #define QD_ATTN_LEAN_OCC 3
 #endif
 template <int DT, bool P16, int KT>
-__global__ __launch_bounds__(256, QD_ATTN_LEAN_OCC) void attn_lean_kernel(const AttnK p) { attn_lean_body<DT, P16, KT>(p); }
+__global__ __launch_bounds__(256, DT <= 2 ? QD_ATTN_LEAN_OCC : 2) void attn_lean_kernel(const AttnK p) { attn_lean_body<DT, P16, KT>(p); }
 
 constexpr int QD_ONES_ROW = 16384;                             // longest padded key axis the LDS-staged kernel takes (bytes of ones)
 struct OnesRow {                                               // constant-initialised: lives in the code object's data segment
@@ -1040,6 +1040,21 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
     attn_write_rows<DT, P16>(p, ol, oh, us, hi_live, bh, q0, frow, half, dw, zpw, oscale, zv);
 }
 
+// any row length (a multiple of 16 bytes): one thread per K row
+__global__ __launch_bounds__(256) void attn_keyterm_rows_kernel(const int8_t* __restrict__ k, int32_t* __restrict__ kterm, const float* __restrict__ prm,
+                                                                long nrows, int dpad) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrows) return;
+    const int nzq = -(int)prm[1];
+    int s = 0;
+    for (int c = 0; c < dpad; c += 16) {
+        const v4i w = *reinterpret_cast<const v4i*>(k + r * dpad + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s = __builtin_amdgcn_sdot4(w[i], 0x01010101, s, false);
+    }
+    kterm[r] = QD_MAGICI + nzq * s;
+}
+
 // kt: 0 = symmetric q (no per-key term), 1 = constant-operand MFMAs, 2 = key-term table (AttnK::kterm)
 template <int DT>
 int launch_lds(const AttnK& k, bool p16, int kt, hipStream_t st) {
@@ -1098,7 +1113,13 @@ static AttnKnobs& attn_knobs() {
     }();
     return k;
 }
-static bool attn_lean_shape(int d) { return attn_knobs().lean != 0 && d < 64 && (d & 31) != 0; }
+// the lean / LDS-staged kernels: a padding row of V^T for the code sums (d not a multiple of 32), |scores| < 2^22
+// (d * 255 * 128 < 2^22 <=> d <= 128) and at most three 32-byte K slabs per key (round 4: d = 80, SD's 1024-token level,
+// moved over from attn_kernel<3>; QD_ATTN_LEAN=2 keeps it there for A/B runs)
+static bool attn_lean_shape(int d) {
+    const int lean = attn_knobs().lean;
+    return lean != 0 && (d & 31) != 0 && (d < 64 || (d < 96 && lean != 2));
+}
 
 extern "C" void qd_attn_config(int pipe_mode, int xcd, int ktab) {
     AttnKnobs& k = attn_knobs();
@@ -1117,14 +1138,15 @@ extern "C" int qd_attn_uses_keyterm(int d, int S, int q_asym) {
 
 extern "C" int qd_attn_keyterm(const int8_t* k, int BH, int Spad, int dpad, const float* prm, int32_t* kterm, void* stream) {
     QD_REQUIRE(k && prm && kterm, "qd_attn_keyterm: null pointer");
-    QD_REQUIRE(BH > 0 && Spad > 0 && Spad % 32 == 0 && (dpad == 32 || dpad == 64), "qd_attn_keyterm: Spad must be a multiple of 32, dpad 32 or 64 (got %d, %d)", Spad, dpad);
+    QD_REQUIRE(BH > 0 && Spad > 0 && Spad % 32 == 0 && (dpad == 32 || dpad == 64 || dpad == 96), "qd_attn_keyterm: Spad must be a multiple of 32, dpad 32, 64 or 96 (got %d, %d)", Spad, dpad);
     QD_REQUIRE(qd_aligned(k, 16) && qd_aligned(kterm, 16), "qd_attn_keyterm: operands must be 16-byte aligned");
     const long nchunks = (long)BH * Spad * (dpad / 16);
     QD_REQUIRE((nchunks + 255) / 256 < (1L << 31), "qd_attn_keyterm: too many blocks");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((nchunks + 255) / 256));
     if (dpad == 32) hipLaunchKernelGGL((attn_keyterm_kernel<2>), grid, dim3(256), 0, st, k, kterm, prm, nchunks);
-    else hipLaunchKernelGGL((attn_keyterm_kernel<4>), grid, dim3(256), 0, st, k, kterm, prm, nchunks);
+    else if (dpad == 64) hipLaunchKernelGGL((attn_keyterm_kernel<4>), grid, dim3(256), 0, st, k, kterm, prm, nchunks);
+    else hipLaunchKernelGGL(attn_keyterm_rows_kernel, dim3((unsigned)(((long)BH * Spad + 255) / 256)), dim3(256), 0, st, k, kterm, prm, (long)BH * Spad, dpad);
     QD_LAUNCH_CHECK("qd_attn_keyterm");
     return 0;
 }
@@ -1154,12 +1176,13 @@ extern "C" int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt, co
     // test), 3 = LDS-staged kernel on every eligible shape
     if (attn_lean_shape(d)) {
         const int kt = !asym ? 0 : (kterm && qd_attn_uses_keyterm(d, S, q_asym)) ? 2 : 1;     // per-key zero-point term: none / constant-operand MFMAs / table
-        const bool lds_fits = Spad <= QD_ONES_ROW && (long)Spad * dpad < (1L << 31);
+        const bool lds_fits = dpad <= 64 && Spad <= QD_ONES_ROW && (long)Spad * dpad < (1L << 31);
         if (lds_fits && (kn.pipe == 3 || (kn.pipe == 2 && S >= 512))) {         // short key axes: ring start-up and barriers lose
             if (dpad == 32) launch_lds<1>(a, p16, kt, st);
             else launch_lds<2>(a, p16, kt, st);
         } else if (dpad == 32) launch_lean<1>(a, p16, kt, st);
-        else launch_lean<2>(a, p16, kt, st);
+        else if (dpad == 64) launch_lean<2>(a, p16, kt, st);
+        else launch_lean<3>(a, p16, kt, st);
         QD_LAUNCH_CHECK("qd_attn_i8");
         return 0;
     }

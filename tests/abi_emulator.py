@@ -282,7 +282,7 @@ def quantize_heads(x, B, T, H, d, strides, prescale, qparams, grid, transpose, o
 
 
 def attn_uses_keyterm(d, S, q_asym):
-    return bool(q_asym) and d < 64 and d % 32 != 0 and S >= 512
+    return bool(q_asym) and d < 96 and d % 32 != 0 and S >= 512
 
 
 def attn_keyterm(k, BH, Spad, dpad, prm, kterm=None):

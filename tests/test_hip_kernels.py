@@ -510,6 +510,8 @@ ATTN_CASES = [
     # q >= 0: its asymmetric zero point is 0, i.e. the stored zero point is -128 and -zq' = 128 does not fit one signed
     # operand byte (the kernel's two-constant c1/c2 path); ragged T and S exercise the peeled tail tile with it
     ("sd_qpos_zq-128", 2, 8, 200, 77, 40, 16, False, 40 ** -0.5),
+    # SD's 1024-token level on the register-fed lean kernel with three K slabs (d = 80 padded to 96) and the key-term table
+    ("sd_self_d80_1024", 1, 8, 1024, 1024, 80, 16, False, 80 ** -0.5),
 ]
 # LSUN-Churches LDM-8 (8 heads on 192 / 384 / 768 channels: head dims 24 / 48 / 96, 8-bit operands — asymmetric as the
 # README runs this model, one symmetric case — 8-bit probabilities, tokens 1024 .. 4): the lean kernel's 8-bit-probability
@@ -639,6 +641,8 @@ PIPE_CASES = [
     ("zq-128_fallback", 2, 4, 96,  77,   40, 16, False, True,  False),     # -zq' = 128: the unpipelined two-constant body
     ("ragged_T_blocks", 2, 4, 300, 200,  40, 16, False, False, False),     # 3 query blocks per head, the last one with idle waves
     ("octaves_repeat", 1, 2, 256,  512,  40, 16, False, False, "huge"),    # the row maximum rises > 64 octaves after tile 0: repeat pass
+    ("d80_three_slabs", 2, 4, 160, 544,  80, 16, False, False, True),      # dpad 96: register-fed kernel in both modes; table vs constant-operand MFMAs
+    ("d80_zq-128",     1, 4, 96,  77,   80, 16, False, True,  False),
 ]
 
 
@@ -697,7 +701,7 @@ def test_attention_keyterm_table(cuda):
     """qd_attn_keyterm: seeds 0x4B400000 - zq' * (row sums of the stored K bytes), for dpad 64 and 32."""
     from qdiff import hip
     g = torch.Generator().manual_seed(5)
-    for BH, Spad, dpad, zq in ((6, 96, 64, -9), (4, 160, 32, -128), (3, 4096, 64, 127)):
+    for BH, Spad, dpad, zq in ((6, 96, 64, -9), (4, 160, 32, -128), (3, 4096, 64, 127), (5, 1024, 96, -77)):
         k8 = torch.randint(-128, 128, (BH, Spad, dpad), dtype=torch.int8, generator=g)
         prm = torch.zeros(16)
         prm[1] = float(zq)

@@ -108,6 +108,37 @@ def make(name):
           f"{os.path.getsize(path) / 1e3:.0f} KB")
 
 
+def make_split_layer(name="cifar_tiny"):
+    """A SPLIT QuantModule reconstructed as a single LAYER unit by the reference's layer_reconstruction (layer_recon.py:50-58
+    switches soft targets on for `weight_quantizer` only: `weight_quantizer_0.alpha` is given to Adam but never receives a
+    gradient).  The recon walks never reach this case for the shipped models (split layers sit inside block units), so it is
+    driven directly: the first split layer of the model, weight phase only.  Fixture: both alpha tensors after the run and the
+    untrained initialisation of the second one."""
+    spec = MG.MODELS[name]
+    cond = spec["ctx"] is not None
+    wq, aq = MG.quant_params(spec)
+    xs, ts, cs = MG.inputs(spec, N_CAL, seed=300)
+    cali = (xs, ts, cs) if cond else (xs, ts)
+    qnn = QuantModel(MG.build_fp(spec), wq, aq, sm_abit=spec["sm_abit"]).eval()
+    qnn.set_quant_state(True, False)
+    MG.call(qnn, *cali) if cond else MG.call(qnn, xs, ts, None)
+    key, layer = next((k, m) for k, m in qnn.named_modules() if isinstance(m, QuantModule) and m.split != 0)
+    torch.manual_seed(SEED)
+    np.random.seed(SEED)
+    layer_reconstruction(qnn, layer, cali_data=cali, batch_size=BATCH, iters=ITERS_W, weight=0.01, asym=True, b_range=(20, 2),
+                         warmup=0.2, act_quant=False, opt_mode='mse', cond=cond)
+    a0, a1 = layer.weight_quantizer.alpha.detach().clone(), layer.weight_quantizer_0.alpha.detach().clone()
+    fx = dict(name=name, spec=spec, layer=key, split=int(layer.split), n_cal=N_CAL, batch=BATCH, iters_w=ITERS_W, seed=SEED, cal_seed=300,
+              alpha=a0, alpha_0=a1, soft_targets=(bool(layer.weight_quantizer.soft_targets), bool(layer.weight_quantizer_0.soft_targets)),
+              torch_version=torch.__version__)
+    path = os.path.join(MG.OUT, "recon_split_layer.pt")
+    torch.save(fx, path)
+    print(f"[golden] recon_split_layer: {key} split at {layer.split}, soft targets {fx['soft_targets']}, {os.path.getsize(path) / 1e3:.0f} KB")
+
+
 if __name__ == "__main__":
     for n in sys.argv[1:] or ["cifar_tiny", "sd_tiny", "ldm_tiny"]:
-        make(n)
+        if n == "split_layer":
+            make_split_layer()
+        else:
+            make(n)
