@@ -258,7 +258,10 @@ def cpu_baseline(qnn, qspec, kind, cfg, k=2):
     return dt, best, {str(n): round(v, 2) for n, v in sweep.items()}
 
 
-DECODE_LEGS = {"fp32": (None, None), "bf16_autocast": (torch.bfloat16, None), "hip": (None, "hip")}
+# engines of the first-stage decode: library convolutions in fp32 / under fp16 autocast (the reference scripts' mode,
+# txt2img.py:231-236) / under bf16 autocast; this package's MFMA kernels with fp16 operands ("hip", the default) or bf16 operands
+DECODE_LEGS = {"fp32": (None, None), "fp16_autocast": (torch.float16, None), "bf16_autocast": (torch.bfloat16, None),
+               "hip": (None, "hip"), "hip_bf16": (None, "hip_bf16")}
 
 
 def decode_leg(kind, n, leg, dev, k=3):
@@ -314,7 +317,7 @@ def _child(argv, cap_s, tag):
     return d
 
 
-def first_stage_decode(kind, n, legs=("fp32", "bf16_autocast", "hip"), cap_s=300):
+def first_stage_decode(kind, n, legs=("fp32", "fp16_autocast", "hip", "hip_bf16"), cap_s=300):
     """First-stage decode of the n images of one sampler batch, every engine in its OWN child process (a fault in one — round
     3's library decode at exactly 2^31 bytes per activation — names itself and loses nothing else).  Not part of the denoising
     metric: reported so that the end-to-end cost of an image is visible next to the 51 / 200 UNet evaluations it follows."""

@@ -315,7 +315,7 @@ int qd_geglu_quant(const void* h, int h_dtype, int64_t M, int F, int64_t ldh,
  *           -zq' * sum_d k'[j][d].  qsum is ignored (may be NULL): the per-query terms -zk'*qsum_i + d*zq'*zk' are
  *           constant along a softmax row and cancel exactly.
  *     kterm (ABI 18; the slot that used to be `ksum`): NULL, or the table qd_attn_keyterm wrote for THIS k operand and
- *           THIS prm.  Shapes with qd_attn_uses_keyterm(d, S, q_asym) == 1 (d < 96, d % 32 != 0, S >= 512: SD's 4096- and 1024-token levels)
+ *           THIS prm.  Shapes with qd_attn_uses_keyterm(d, S, q_asym) == 1 (d < 64, d % 32 != 0, S >= 512: SD's 4096-token level)
  *           then seed the score accumulators from the table instead of issuing constant-operand MFMAs (2 of the 4
  *           score MFMAs of a 32x32 tile carried no data); results are bit-identical with and without it.  Other shapes
  *           ignore it.
@@ -324,8 +324,9 @@ int qd_geglu_quant(const void* h, int h_dtype, int64_t M, int F, int64_t ldh,
  *           whose context is constant over a sampling run computes it once (quant_block.py:193-195 recomputes k per step).
  *     qd_attn_config: process-wide launcher knobs, -1 = leave unchanged.  pipe_mode 0 = register-fed kernel everywhere,
  *           2 = LDS-staged kernel where it pays (default), 3 = LDS-staged wherever eligible; xcd 0/1 = XCD-aware block
- *           order; ktab 0 = ignore kterm (constant-operand MFMAs, A/B runs).  Initial values: QD_ATTN_PIPE / QD_ATTN_XCD /
- *           QD_ATTN_KTAB, read once.
+ *           order; ktab 0 = ignore kterm (constant-operand MFMAs, A/B runs); lean 0 = attn_kernel for every head dim, 1 = lean /
+ *           LDS-staged kernels for d < 64 (default), 3 = also d = 80 on the lean kernel (measured slower).  Initial values:
+ *           QD_ATTN_PIPE / QD_ATTN_XCD / QD_ATTN_KTAB / QD_ATTN_LEAN, read once.
  * ------------------------------------------------------------------------------------------ */
 int qd_quantize_heads(const void* x, int x_dtype, int B, int T, int H, int d,
                       int64_t sb, int64_t st, int64_t sh, int64_t sd, float prescale,
@@ -334,7 +335,7 @@ int qd_quantize_heads(const void* x, int x_dtype, int B, int T, int H, int d,
 
 int qd_attn_uses_keyterm(int d, int S, int q_asym);
 int qd_attn_keyterm(const int8_t* k, int BH, int Spad, int dpad, const float* prm, int32_t* kterm, void* stream);
-void qd_attn_config(int pipe_mode, int xcd, int ktab);
+void qd_attn_config(int pipe_mode, int xcd, int ktab, int lean);
 int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt,
                const int32_t* qsum, const int32_t* kterm, const int32_t* vsum,
                int BH, int H, int T, int S, int d, int Tpad, int Spad, int dpad,
@@ -394,6 +395,12 @@ int qd_fakequant_bwd(const float* x, const float* gy, int64_t n, const float* de
  *         channels Cin .. clen_pad-1 (clen_pad % 8 == 0 = the descriptor's clen) are zero.  wt: qd_pack_weights_bf16_bytes.
  *     qd_groupnorm_silu_bf16: GroupNorm (+ SiLU) of fp32 rows into bf16 rows (model.py:38-45 `Normalize` / `nonlinearity`
  *         in front of every convolution); ws / part_in / nchunk_in / part_ld as for qd_groupnorm_silu_quant.
+ *
+ *     fp16 operands (ABI 18): the reference decodes under fp16 autocast (scripts/txt2img.py:231-236), i.e. with IEEE halves
+ *     (11 significant bits) where bf16 has 8.  Same kernels, same bytes per K-step, v_mfma_f32_32x32x16_f16 at the same rate:
+ *         qd_pack_weights_h16(..., wbits, ...)     wbits 16 = bf16 (what qd_pack_weights_bf16 does), 17 = fp16
+ *         qd_conv2d_bf16 with desc.wbits = 17      x / w are halves; out_dtype QD_F32 or QD_F16 (residual of that type)
+ *         qd_groupnorm_silu_h16(..., out_dtype, ...)  QD_BF16 or QD_F16 rows
  * ------------------------------------------------------------------------------------------ */
 int qd_conv2d_bf16(const qd_conv_desc* d, void* stream);
 int64_t qd_pack_weights_bf16_bytes(int Cout, int taps, int clen_pad);
@@ -401,6 +408,10 @@ int qd_pack_weights_bf16(const float* w, int Cout, int Cin, int taps, int clen_p
 int qd_groupnorm_silu_bf16(const float* x, int64_t B, int64_t S, int C, int64_t ldx, int groups, float eps,
                            const float* gamma, const float* beta, int apply_silu, void* out, int64_t ldo, void* ws,
                            const float* part_in, int nchunk_in, int64_t part_ld, void* stream);
+int qd_pack_weights_h16(const float* w, int Cout, int Cin, int taps, int clen_pad, int wbits, uint8_t* wt, void* stream);
+int qd_groupnorm_silu_h16(const float* x, int64_t B, int64_t S, int C, int64_t ldx, int groups, float eps,
+                          const float* gamma, const float* beta, int apply_silu, int out_dtype, void* out, int64_t ldo, void* ws,
+                          const float* part_in, int nchunk_in, int64_t part_ld, void* stream);
 
 #ifdef __cplusplus
 }

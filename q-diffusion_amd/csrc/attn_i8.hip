@@ -1113,19 +1113,22 @@ static AttnKnobs& attn_knobs() {
     }();
     return k;
 }
-// the lean / LDS-staged kernels: a padding row of V^T for the code sums (d not a multiple of 32), |scores| < 2^22
-// (d * 255 * 128 < 2^22 <=> d <= 128) and at most three 32-byte K slabs per key (round 4: d = 80, SD's 1024-token level,
-// moved over from attn_kernel<3>; QD_ATTN_LEAN=2 keeps it there for A/B runs)
+// the lean / LDS-staged kernels: a padding row of V^T for the code sums (d not a multiple of 32) and |scores| < 2^22
+// (d * 255 * 128 < 2^22 <=> d <= 128).  Default: d < 64 (SD's 4096-token level).  d = 80 (SD's 1024-token level, three
+// 32-byte K slabs per key) runs on the register-fed lean kernel only with QD_ATTN_LEAN=3: measured SLOWER than
+// attn_kernel<3> (127 vs 113 us per 1024-key self-attention call, profiles/r04_attn_keyterm.md) — without LDS staging the
+// three slabs per key come through the vector-memory path per wave, which costs more than the constant-operand MFMAs saved.
 static bool attn_lean_shape(int d) {
     const int lean = attn_knobs().lean;
-    return lean != 0 && (d & 31) != 0 && (d < 64 || (d < 96 && lean != 2));
+    return lean != 0 && (d & 31) != 0 && (d < 64 || (d < 96 && lean == 3));
 }
 
-extern "C" void qd_attn_config(int pipe_mode, int xcd, int ktab) {
+extern "C" void qd_attn_config(int pipe_mode, int xcd, int ktab, int lean) {
     AttnKnobs& k = attn_knobs();
     if (pipe_mode >= 0) k.pipe = pipe_mode;
     if (xcd >= 0) k.xcd = xcd;
     if (ktab >= 0) k.ktab = ktab;
+    if (lean >= 0) k.lean = lean;
 }
 
 // the table pays where the LDS-staged kernel runs (thousands of keys); the register-fed kernel on short key axes (the 77

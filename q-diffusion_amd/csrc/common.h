@@ -49,6 +49,7 @@ template <> __device__ __forceinline__ float qd_ld<__half>(const __half* p) { re
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 
 // four bf16 <-> four floats through one 8-byte access (first-stage decoder: bf16 activations, fp32 accumulators).
 // bf16 -> fp32 is a 16-bit shift; fp32 -> bf16 rounds to nearest even (v_cvt_pk_bf16_f32 on gfx950).
@@ -69,6 +70,11 @@ __device__ __forceinline__ void qd_st4bf(void* p, const v4f& v) {
 __device__ __forceinline__ float qd_bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
 // four halves <-> four floats through one 8-byte access (fp16 activation streams)
+// two floats -> two IEEE halves in one word (round to nearest even), low half first
+__device__ __forceinline__ unsigned qd_pack2h(float a, float b) {
+    const __half2 h = __floats2half2_rn(a, b);
+    return *reinterpret_cast<const unsigned*>(&h);
+}
 __device__ __forceinline__ v4f qd_ld4h(const __half* p) {
     const uint2 u = *reinterpret_cast<const uint2*>(p);
     const __half2 a = *reinterpret_cast<const __half2*>(&u.x), b = *reinterpret_cast<const __half2*>(&u.y);

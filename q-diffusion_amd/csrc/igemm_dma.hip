@@ -138,9 +138,10 @@ __device__ __forceinline__ constexpr int crow(int r) { return (r & 3) + 8 * (r >
 #endif
 template <int MT, int NT, int WM, int WN, bool SPLIT, int OUT, int WB>
 __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <= 5 ? QD_MT1_OCC : 2)) void igemm_kernel(const ConvD p) {
-    static_assert(WB == 4 || WB == 8 || WB == 16, "weight bits (16 = bf16 mode)");
-    constexpr bool BF = WB == 16;
-    static_assert(!BF || (!SPLIT && (OUT == O_F32 || OUT == O_BF16)), "bf16 mode: one segment, fp32 / bf16 rows");
+    static_assert(WB == 4 || WB == 8 || WB == 16 || WB == 17, "weight bits (16 = bf16 mode, 17 = fp16 mode)");
+    constexpr bool BF = WB >= 16;                 // the floating-point mode (either operand type: same bytes, same loop)
+    constexpr bool FH = WB == 17;                 // ... on IEEE halves (v_mfma_f32_32x32x16_f16) instead of bf16
+    static_assert(!BF || (!SPLIT && (OUT == O_F32 || OUT == (FH ? O_F16 : O_BF16))), "16-bit float mode: one segment, fp32 rows or rows of the operand type");
     static_assert(WM * WN == 4, "four waves per block");
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, NTB = NT * WN;
     constexpr int TB = BF ? 2048 : 256 * WB;      // bytes of one (K-step, 32-channel) weight tile
@@ -477,7 +478,10 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                if constexpr (BF) {
+                if constexpr (FH) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, af[ks][i]), __builtin_bit_cast(v8h, bf),
+                                                                        acc[i][j], 0, 0, 0);
+                } else if constexpr (BF) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, af[ks][i]), __builtin_bit_cast(v8bf, bf),
                                                                          acc[i][j], 0, 0, 0);
                 } else {
@@ -1046,6 +1050,8 @@ int dispatch(ConvD& k, bool split, int out, hipStream_t st, int nsplit = 1) {
     }
     if constexpr (WB == 16) {
         QD_CASE(false, O_F32) QD_CASE(false, O_BF16)
+    } else if constexpr (WB == 17) {
+        QD_CASE(false, O_F32) QD_CASE(false, O_F16)
     } else {
         QD_CASE(false, O_F32)
         QD_CASE(false, O_F16)
@@ -1054,7 +1060,7 @@ int dispatch(ConvD& k, bool split, int out, hipStream_t st, int nsplit = 1) {
         if constexpr (NT == 4 && WB == 4 && WM == 4) { QD_CASE(false, O_GEGLU) }
     }
 #undef QD_CASE
-    qd_set_error("qd_conv2d_%s: unsupported variant split=%d out=%d tile %dx%d", WB == 16 ? "bf16" : "i8", (int)split, out, BM, BN);
+    qd_set_error("qd_conv2d_%s: unsupported variant split=%d out=%d tile %dx%d", WB >= 16 ? "bf16" : "i8", (int)split, out, BM, BN);
     return 1;
 }
 
@@ -1249,10 +1255,11 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
 int run_bf16(const qd_conv_desc* d, void* stream) {
     QD_REQUIRE(d != nullptr, "qd_conv2d_bf16: null descriptor");
     QD_REQUIRE(d->x && d->w && d->out, "qd_conv2d_bf16: null tensor pointer");
-    QD_REQUIRE(d->w_tiled && d->wbits == 16, "qd_conv2d_bf16: weights must come from qd_pack_weights_bf16 (w_tiled = 1, wbits = 16)");
+    QD_REQUIRE(d->w_tiled && (d->wbits == 16 || d->wbits == 17), "qd_conv2d_bf16: weights must come from qd_pack_weights_bf16 / _h16 (w_tiled = 1, wbits = 16: bf16, 17: fp16)");
     QD_REQUIRE(!d->upsample2x || (d->stride == 1 && d->kh * d->kw > 1 && d->H % 2 == 0 && d->W % 2 == 0 && d->pad_t < 8 && d->pad_l < 8),
                "qd_conv2d_bf16: upsample2x needs stride 1, more than one tap, even H and W");
-    QD_REQUIRE(d->out_dtype == QD_F32 || d->out_dtype == QD_BF16, "qd_conv2d_bf16: out_dtype must be f32/bf16");
+    const bool fh = d->wbits == 17;                  // operands are IEEE halves
+    QD_REQUIRE(d->out_dtype == QD_F32 || d->out_dtype == (fh ? QD_F16 : QD_BF16), "qd_conv2d_bf16: out_dtype must be f32 or the operand type");
     QD_REQUIRE(d->nseg == 1 && d->epilogue == QD_EPI_LINEAR && !d->rowbias, "qd_conv2d_bf16: one segment, linear epilogue, no row bias");
     QD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, "qd_conv2d_bf16: bad shape");
     QD_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->kh * d->kw <= 32, "qd_conv2d_bf16: bad kernel/stride (at most 32 taps)");
@@ -1272,7 +1279,7 @@ int run_bf16(const qd_conv_desc* d, void* stream) {
     k.ups = d->upsample2x ? 1 : 0;
     k.ntiles = (d->Cout + 31) / 32;
     k.seg[0] = SegD{g.c0 * 2, g.clen * 2, g.kstep0, (g.clen * 2 + 63) / 64, nullptr, nullptr, nullptr, nullptr, nullptr};
-    const size_t esz = d->out_dtype == QD_BF16 ? 2 : 4;
+    const size_t esz = d->out_dtype == QD_F32 ? 4 : 2;
     k.vec = d->Cout % 4 == 0 && d->ldo % 4 == 0 && qd_aligned(d->out, 4 * esz) &&
             (!d->residual || (d->ldr % 4 == 0 && qd_aligned(d->residual, 4 * esz)));
     if (d->gn_part) {
@@ -1283,13 +1290,18 @@ int run_bf16(const qd_conv_desc* d, void* stream) {
         k.gn_ld = d->gn_ld ? (long)d->gn_ld : (long)d->Cout;
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int N = d->Cout, out = d->out_dtype == QD_BF16 ? O_BF16 : O_F32;
+    const int N = d->Cout, out = d->out_dtype == QD_BF16 ? O_BF16 : d->out_dtype == QD_F16 ? O_F16 : O_F32;
     const long M = k.M;
     static const int force_mt = getenv("QD_BF16_MT") ? atoi(getenv("QD_BF16_MT")) : 0;       // tuning knob: 1 / 2, 0 = heuristic
     const bool mt2 = force_mt ? force_mt == 2 : ((M + 255) / 256) * ((N + 127) / 128) >= 256;
     int rc;
-    if (N > 64) rc = mt2 ? dispatch<2, 4, 4, 1, 16>(k, false, out, st) : dispatch<1, 4, 4, 1, 16>(k, false, out, st);
-    else rc = dispatch<1, 2, 4, 1, 16>(k, false, out, st);
+    if (fh) {
+        if (N > 64) rc = mt2 ? dispatch<2, 4, 4, 1, 17>(k, false, out, st) : dispatch<1, 4, 4, 1, 17>(k, false, out, st);
+        else rc = dispatch<1, 2, 4, 1, 17>(k, false, out, st);
+    } else {
+        if (N > 64) rc = mt2 ? dispatch<2, 4, 4, 1, 16>(k, false, out, st) : dispatch<1, 4, 4, 1, 16>(k, false, out, st);
+        else rc = dispatch<1, 2, 4, 1, 16>(k, false, out, st);
+    }
     if (rc) return rc;
     QD_LAUNCH_CHECK("qd_conv2d_bf16");
     return 0;
@@ -1298,7 +1310,7 @@ int run_bf16(const qd_conv_desc* d, void* stream) {
 // fp32 OIHW (or [N, K] linear) weights -> bf16 (round to nearest even) in the tile order of the bf16 mode: K-step (32
 // channels of one tap) x 32-output-channel tile = 2 KB as [k-half (16 ch)][lane-half (8 ch)][n % 32][8 bf16].
 __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, int clen_pad,
-                                                        uint8_t* __restrict__ wt, int ntiles, int nsteps_tap) {
+                                                        uint8_t* __restrict__ wt, int ntiles, int nsteps_tap, int fh) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)taps * nsteps_tap * ntiles * 128;
     if (gid >= total) return;
@@ -1320,7 +1332,7 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
             const int c = cbase + gq * 2 + e;
             if (n < Cout && c < Cin) f[e] = w[((long)n * Cin + c) * taps + t];
         }
-        pk[gq] = (int)qd_pack2bf(f[0], f[1]);
+        pk[gq] = fh ? (int)qd_pack2h(f[0], f[1]) : (int)qd_pack2bf(f[0], f[1]);
     }
     const long kstep = (long)t * nsteps_tap + cs;
     *reinterpret_cast<v4i*>(wt + (kstep * ntiles + jt) * 2048 + (kh4 * 32 + nn) * 16) = pk;
@@ -1334,7 +1346,13 @@ extern "C" int64_t qd_pack_weights_bf16_bytes(int Cout, int taps, int clen_pad) 
     return (int64_t)taps * ((clen_pad + 31) / 32) * ((Cout + 31) / 32) * 2048;
 }
 
+extern "C" int qd_pack_weights_h16(const float* w, int Cout, int Cin, int taps, int clen_pad, int wbits, uint8_t* wt, void* stream);
 extern "C" int qd_pack_weights_bf16(const float* w, int Cout, int Cin, int taps, int clen_pad, uint8_t* wt, void* stream) {
+    return qd_pack_weights_h16(w, Cout, Cin, taps, clen_pad, 16, wt, stream);
+}
+
+extern "C" int qd_pack_weights_h16(const float* w, int Cout, int Cin, int taps, int clen_pad, int wbits, uint8_t* wt, void* stream) {
+    QD_REQUIRE(wbits == 16 || wbits == 17, "qd_pack_weights_h16: wbits must be 16 (bf16) or 17 (fp16)");
     QD_REQUIRE(w && wt, "qd_pack_weights_bf16: null pointer");
     QD_REQUIRE(Cout > 0 && taps > 0 && Cin > 0, "qd_pack_weights_bf16: bad shape");
     QD_REQUIRE(clen_pad % 8 == 0 && clen_pad >= Cin, "qd_pack_weights_bf16: clen_pad must be a multiple of 8 and >= Cin");
@@ -1342,7 +1360,7 @@ extern "C" int qd_pack_weights_bf16(const float* w, int Cout, int Cin, int taps,
     const int ntiles = (Cout + 31) / 32, nsteps_tap = (clen_pad + 31) / 32;
     const long total = (long)taps * nsteps_tap * ntiles * 128;
     hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       w, Cout, Cin, taps, clen_pad, wt, ntiles, nsteps_tap);
+                       w, Cout, Cin, taps, clen_pad, wt, ntiles, nsteps_tap, wbits == 17 ? 1 : 0);
     QD_LAUNCH_CHECK("qd_pack_weights_bf16");
     return 0;
 }

@@ -381,7 +381,7 @@ void dispatch_ln(int nvl, hipStream_t st, const void* x, long M, int C, long ldx
 // channels of one row (two 16-byte loads, one 16-byte store), same statistics passes and per-(sample, channel) affine.
 __global__ __launch_bounds__(256) void gn_apply_bf16_kernel(const float* __restrict__ x, long rows, long S, int C, long ldx,
                                                             const float* __restrict__ ab, int apply_silu,
-                                                            unsigned short* __restrict__ out, long ldo) {
+                                                            unsigned short* __restrict__ out, long ldo, int fh) {
     const int chunks = C >> 3;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= rows * chunks) return;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void gn_apply_bf16_kernel(const float* __restr
     }
     v4i pk;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) pk[j] = (int)qd_pack2bf(y[2 * j], y[2 * j + 1]);
+    for (int j = 0; j < 4; ++j) pk[j] = fh ? (int)qd_pack2h(y[2 * j], y[2 * j + 1]) : (int)qd_pack2bf(y[2 * j], y[2 * j + 1]);
     *reinterpret_cast<v4i*>(out + row * ldo + c) = pk;
 }
 
@@ -414,9 +414,20 @@ __global__ __launch_bounds__(256) void gn_apply_bf16_kernel(const float* __restr
 // GroupNorm (+ SiLU) of fp32 NHWC rows into bf16 rows: the producer of the bf16 convolutions of the first-stage decoder
 // (reference ldm/modules/diffusionmodules/model.py:38-45 Normalize / nonlinearity in front of every convolution).
 // gamma / beta may be null (x * rstd - mean * rstd).
+extern "C" int qd_groupnorm_silu_h16(const float* x, int64_t B, int64_t S, int C, int64_t ldx, int groups, float eps,
+                                     const float* gamma, const float* beta, int apply_silu, int out_dtype, void* out, int64_t ldo, void* ws,
+                                     const float* part_in, int nchunk_in, int64_t part_ld, void* stream);
 extern "C" int qd_groupnorm_silu_bf16(const float* x, int64_t B, int64_t S, int C, int64_t ldx, int groups, float eps,
                                       const float* gamma, const float* beta, int apply_silu, void* out, int64_t ldo, void* ws,
                                       const float* part_in, int nchunk_in, int64_t part_ld, void* stream) {
+    return qd_groupnorm_silu_h16(x, B, S, C, ldx, groups, eps, gamma, beta, apply_silu, QD_BF16, out, ldo, ws, part_in, nchunk_in, part_ld, stream);
+}
+
+// the same with the output type as a parameter: QD_BF16 or QD_F16 (the reference decodes under fp16 autocast, scripts/txt2img.py:231-236)
+extern "C" int qd_groupnorm_silu_h16(const float* x, int64_t B, int64_t S, int C, int64_t ldx, int groups, float eps,
+                                     const float* gamma, const float* beta, int apply_silu, int out_dtype, void* out, int64_t ldo, void* ws,
+                                     const float* part_in, int nchunk_in, int64_t part_ld, void* stream) {
+    QD_REQUIRE(out_dtype == QD_BF16 || out_dtype == QD_F16, "qd_groupnorm_silu_h16: out_dtype must be bf16 or f16");
     QD_REQUIRE(x && out && ws, "qd_groupnorm_silu_bf16: null pointer");
     QD_REQUIRE(B > 0 && S > 0 && C > 0 && groups > 0 && C % groups == 0 && C % 8 == 0, "qd_groupnorm_silu_bf16: C=%d must be a multiple of 8 and of groups=%d", C, groups);
     QD_REQUIRE(ldx >= C && ldx % 4 == 0 && qd_aligned(x, 16) && ldo >= C && ldo % 8 == 0 && qd_aligned(out, 16), "qd_groupnorm_silu_bf16: rows must be 16-byte aligned");
@@ -436,7 +447,7 @@ extern "C" int qd_groupnorm_silu_bf16(const float* x, int64_t B, int64_t S, int 
         hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, (unsigned)B), dim3(64), 0, st, part_in ? part_in : part, nchunk, ldp, (long)S, C, groups, eps, gamma, beta, ab);
     const long rows = B * S, total = rows * (C / 8);
     hipLaunchKernelGGL(gn_apply_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, rows, (long)S, C, (long)ldx, ab, apply_silu,
-                       reinterpret_cast<unsigned short*>(out), (long)ldo);
+                       reinterpret_cast<unsigned short*>(out), (long)ldo, out_dtype == QD_F16 ? 1 : 0);
     QD_LAUNCH_CHECK("qd_groupnorm_silu_bf16");
     return 0;
 }

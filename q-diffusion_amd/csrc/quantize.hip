@@ -382,6 +382,19 @@ extern "C" int qd_geglu_quant(const void* h, int h_dtype, int64_t M, int F, int6
     return 0;
 }
 
+// Zero-fill as a KERNEL, not hipMemsetAsync: under stream capture the latter becomes a memset node, and two captured
+// evaluations of one model that hold such nodes and are replayed alternately (A, B, A) came back wrong on ROCm 7.2 from
+// the first block with memset nodes on — reproducibly when the captured graph is a single chain (a prepared context leaves
+// no forked branch in it), never with kernel nodes only (tools/probes/pin_dbg6.py, pin_dbg8.py).
+__global__ __launch_bounds__(256) void zero16_kernel(v4i* __restrict__ p, long n16) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) p[i] = v4i{0, 0, 0, 0};
+}
+static void zero_async(void* p, size_t bytes, hipStream_t st) {     // bytes % 16 == 0, p 16-byte aligned (callers check)
+    const long n16 = (long)(bytes / 16);
+    hipLaunchKernelGGL(zero16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<v4i*>(p), n16);
+}
+
 extern "C" int qd_quantize_heads(const void* x, int x_dtype, int B, int T, int H, int d, int64_t sb, int64_t st_,
                                  int64_t sh, int64_t sd, float prescale, const float* qparams, int qmin, int qmax,
                                  int off, int transpose, int8_t* out, int32_t* rsum, int Tpad, int dpad, void* stream) {
@@ -392,9 +405,9 @@ extern "C" int qd_quantize_heads(const void* x, int x_dtype, int B, int T, int H
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (!transpose) {
         QD_REQUIRE(d % 4 == 0 && H <= 256, "qd_quantize_heads: head dim must be a multiple of 4 and H <= 256 (d=%d H=%d)", d, H);
-        hipError_t e1 = hipMemsetAsync(out, 0, (size_t)B * H * Tpad * dpad, st);
-        hipError_t e2 = rsum ? hipMemsetAsync(rsum, 0, sizeof(int32_t) * (size_t)B * H * Tpad, st) : hipSuccess;
-        QD_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, "qd_quantize_heads: memset failed");
+        QD_REQUIRE(!rsum || qd_aligned(rsum, 16), "qd_quantize_heads: rsum must be 16-byte aligned");
+        zero_async(out, (size_t)B * H * Tpad * dpad, st);
+        if (rsum) zero_async(rsum, sizeof(int32_t) * (size_t)B * H * Tpad, st);
         const int gpr = (H * d) / 4;
         int tpb = 1024 / gpr;                                   // ~4 float4 groups per thread
         if (tpb < 1) tpb = 1;
@@ -409,8 +422,8 @@ extern "C" int qd_quantize_heads(const void* x, int x_dtype, int B, int T, int H
     } else {
         QD_REQUIRE((long)B * H < 65536, "qd_quantize_heads: too many heads for grid.y");
         if (rsum) {
-            hipError_t e = hipMemsetAsync(rsum, 0, sizeof(int32_t) * (size_t)B * H * dpad, st);
-            QD_REQUIRE(e == hipSuccess, "qd_quantize_heads: memset failed: %s", hipGetErrorString(e));
+            QD_REQUIRE(qd_aligned(rsum, 16), "qd_quantize_heads: rsum must be 16-byte aligned");
+            zero_async(rsum, sizeof(int32_t) * (size_t)B * H * dpad, st);
         }
         dim3 grid((unsigned)(((dpad + 63) / 64) * (Tpad / 16)), (unsigned)(B * H));
         if (x_dtype == QD_F32)

@@ -286,8 +286,10 @@ def decode_first_stage(first_stage, z, scale_factor=1.0, force_not_quantize=Fals
     Until the end of round 3 the estimate was the output-resolution stream (ch x H_out x W_out), half the true maximum: 8 SD
     latents put exactly 2^31 bytes into the upsampled 256 x 512 x 512 tensor, which the library survived or not depending
     on the allocator state of the process (`bench.py --decode` faulted once in four runs).
-    `engine="hip"`: the `Decoder` runs on this package's bf16 MFMA convolution / GroupNorm kernels (qdiff.first_stage_hip;
-    GPU only, raises without the library) instead of the library convolutions; `autocast_dtype` is then ignored."""
+    `engine="hip"`: the `Decoder` runs on this package's 16-bit-float MFMA convolution / GroupNorm kernels
+    (qdiff.first_stage_hip; GPU only, raises without the library) instead of the library convolutions, with fp16 operands —
+    the reference scripts' precision (txt2img.py:231-236) — or, `engine="hip_bf16"`, with round 3's bf16 operands;
+    `autocast_dtype` is then ignored."""
     per_image = largest_activation_bytes(first_stage.decoder, z.shape[2], z.shape[3])
     chunk = max(1, int(max_activation_bytes // max(per_image, 1)))
     if z.shape[0] > chunk:
@@ -297,10 +299,11 @@ def decode_first_stage(first_stage, z, scale_factor=1.0, force_not_quantize=Fals
     if z.is_cuda:
         z = z.contiguous(memory_format=torch.channels_last)
     kw = dict(force_not_quantize=force_not_quantize) if isinstance(first_stage, VQModelDecoder) else {}
-    if engine == "hip":
+    if engine in ("hip", "hip_fp16", "hip_bf16"):
         from ..first_stage_hip import hip_decoder
         quant = z if (not isinstance(first_stage, VQModelDecoder) or force_not_quantize) else first_stage.quantize(z)
-        x = hip_decoder(first_stage.decoder)(first_stage.post_quant_conv(quant).float())
+        dt = {"hip": None, "hip_fp16": torch.float16, "hip_bf16": torch.bfloat16}[engine]
+        x = hip_decoder(first_stage.decoder, dt)(first_stage.post_quant_conv(quant).float())
     elif engine is not None:
         raise ValueError(f"decode_first_stage: unknown engine {engine!r}")
     elif autocast_dtype is not None and z.is_cuda:

@@ -1,4 +1,10 @@
-"""First-stage decoder on the hand-written bf16 kernels.
+"""First-stage decoder on the hand-written 16-bit-float MFMA kernels.
+
+Operand type (round 4): IEEE fp16 by default — the precision the reference decodes at (scripts/txt2img.py:231-236 run the
+model under fp16 autocast; 11 significant bits against bf16's 8) — on v_mfma_f32_32x32x16_f16, same rate and bytes as the
+bf16 instruction; `QDIFF_DECODER_DTYPE=bf16` (or HipDecoder(dtype=torch.bfloat16)) keeps round 3's bf16 operands.  Below,
+"bf16" in the entry-point names is historical: they take either type.
+
 
 `HipDecoder(decoder)` evaluates a `qdiff.arch.first_stage.Decoder` (the reference's ldm/modules/diffusionmodules/model.py:465-572
 `Decoder.forward`) with every convolution on `qd_conv2d_bf16` — the bf16 mode of the implicit-GEMM kernel the quantised UNet
@@ -20,16 +26,20 @@ statistics and swish are fp32.  The result therefore differs from the fp32 refer
 tests/test_first_stage_hip.py states the bound (and runs this wiring on CPU against tests/abi_emulator.py).  There is no
 fallback: without the library or a GPU the first launch wrapper raises.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
 from . import hip
 
+DEFAULT_DTYPE = torch.bfloat16 if os.environ.get("QDIFF_DECODER_DTYPE", "fp16").lower() in ("bf16", "bfloat16") else torch.float16
+
 
 class _Conv:
-    __slots__ = ("wt", "bias", "cin_pad", "cout", "k", "pad")
+    __slots__ = ("wt", "bias", "cin_pad", "cout", "k", "pad", "stamp")
 
-    def __init__(self, weight, bias, device):
+    def __init__(self, weight, bias, device, dtype):
         w = weight.detach().to(device=device, dtype=torch.float32)
         if w.dim() == 2:
             w = w[:, :, None, None]
@@ -38,36 +48,48 @@ class _Conv:
             raise hip.HipEngineError(f"first-stage convolution {tuple(w.shape)}: only 1x1 / 3x3")
         self.pad = self.k // 2
         self.cin_pad = hip.pad8(cin)
-        self.wt = hip.pack_weights_bf16(w)
+        self.wt = hip.pack_weights_bf16(w, dtype)
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
 class HipDecoder:
-    """Runs `decoder` (qdiff.arch.first_stage.Decoder, eval mode) on the bf16 kernels.  Packed weights are built on first use
-    per device and dropped by `invalidate()` (call it after loading another state dict)."""
+    """Runs `decoder` (qdiff.arch.first_stage.Decoder, eval mode) on the 16-bit-float MFMA kernels.  Packed weights are built on
+    first use per device and re-built when the module's parameters were re-assigned or modified in place since
+    (`load_state_dict` copies in place: the version counter of the parameter moves)."""
 
-    def __init__(self, decoder):
+    def __init__(self, decoder, dtype=None):
         if decoder.give_pre_end or decoder.tanh_out:
             raise hip.HipEngineError("HipDecoder: give_pre_end / tanh_out decoders are not used by the reference's configs")
         self.dec = decoder
+        self.dtype = DEFAULT_DTYPE if dtype is None else dtype
+        if self.dtype not in (torch.float16, torch.bfloat16):
+            raise hip.HipEngineError("HipDecoder: operand type must be float16 or bfloat16")
         self._packs = {}
 
     def invalidate(self):
         self._packs.clear()
 
     # ---- weights ----
+    @staticmethod
+    def _stamp(*params):
+        return tuple((id(p), p._version, p.data_ptr()) for p in params if p is not None)
+
     def _conv(self, dev, key, mod):
         p = self._packs.get((dev, key))
-        if p is None:
-            p = self._packs[(dev, key)] = _Conv(mod.weight, mod.bias, dev)
+        stamp = self._stamp(mod.weight, mod.bias)
+        if p is None or p.stamp != stamp:
+            p = self._packs[(dev, key)] = _Conv(mod.weight, mod.bias, dev, self.dtype)
+            p.stamp = stamp
         return p
 
     def _qkv(self, dev, key, attn):
         p = self._packs.get((dev, key))
-        if p is None:
+        stamp = self._stamp(attn.q.weight, attn.k.weight, attn.v.weight, attn.q.bias, attn.k.bias, attn.v.bias)
+        if p is None or p.stamp != stamp:
             w = torch.cat([attn.q.weight, attn.k.weight, attn.v.weight], dim=0)
             b = torch.cat([attn.q.bias, attn.k.bias, attn.v.bias], dim=0)
-            p = self._packs[(dev, key)] = _Conv(w, b, dev)
+            p = self._packs[(dev, key)] = _Conv(w, b, dev, self.dtype)
+            p.stamp = stamp
         return p
 
     # ---- launches ----
@@ -84,10 +106,9 @@ class HipDecoder:
                         upsample2x=upsample2x)
         return out, part
 
-    @staticmethod
-    def _norm(norm, x, part, B, S, silu):
+    def _norm(self, norm, x, part, B, S, silu):
         C = norm.num_channels
-        out = torch.empty((B * S, C), dtype=torch.bfloat16, device=x.device)
+        out = torch.empty((B * S, C), dtype=self.dtype, device=x.device)
         ws = torch.empty(hip.groupnorm_ws_bytes(B, C, S), dtype=torch.uint8, device=x.device)
         hip.groupnorm_silu_bf16(x, B, S, C, norm.num_groups, norm.eps, norm.weight.detach().float(), norm.bias.detach().float(),
                                 silu, out, ws, part=part)
@@ -101,13 +122,13 @@ class HipDecoder:
         h1, p1 = self._run_conv(self._conv(dev, key + ".conv1", blk.conv1), a, B, H, W)
         b = self._norm(blk.norm2, h1, p1, B, S, True)
         if blk.in_channels != blk.out_channels:
-            x, _ = self._run_conv(self._conv(dev, key + ".nin", blk.nin_shortcut), x.to(torch.bfloat16), B, H, W, stats=False)
+            x, _ = self._run_conv(self._conv(dev, key + ".nin", blk.nin_shortcut), x.to(self.dtype), B, H, W, stats=False)
         return self._run_conv(self._conv(dev, key + ".conv2", blk.conv2), b, B, H, W, residual=x)
 
     def _attn(self, key, att, x, part, B, H, W):
         dev, S, C = x.device, H * W, att.in_channels
         hn = self._norm(att.norm, x, part, B, S, False)
-        qkv, _ = self._run_conv(self._qkv(dev, key + ".qkv", att), hn, B, H, W, out_dtype=torch.bfloat16, stats=False)
+        qkv, _ = self._run_conv(self._qkv(dev, key + ".qkv", att), hn, B, H, W, out_dtype=self.dtype, stats=False)
         q, k, v = (qkv[:, i * C:(i + 1) * C].reshape(B, 1, S, C) for i in range(3))
         o = F.scaled_dot_product_attention(q, k, v, scale=int(C) ** (-0.5)).reshape(B * S, C).contiguous()
         return self._run_conv(self._conv(dev, key + ".proj", att.proj_out), o, B, H, W, residual=x)
@@ -117,10 +138,11 @@ class HipDecoder:
         """z: fp32 [B, z_channels, h, w] on the GPU (after post_quant_conv) -> fp32 [B, out_ch, H, W] (NCHW view of NHWC rows)"""
         d, dev = self.dec, z.device             # (host tensors: the first launch wrapper raises — there is no host path)
         B, zc, H, W = z.shape
-        if B * H * W * 4 ** (d.num_resolutions - 1) * max(d.ch, 8) * 4 >= 1 << 32:
+        from .arch.first_stage import largest_activation_bytes
+        if B * largest_activation_bytes(d, H, W) >= 1 << 32:      # fp32 bytes of the largest tensor of the walk (the last up-sampling level)
             raise hip.HipEngineError("HipDecoder: batch too large for 32-bit row offsets; decode in chunks (decode_first_stage does)")
         cin = self._conv(dev, "conv_in", d.conv_in)
-        x0 = torch.zeros((B * H * W, cin.cin_pad), dtype=torch.bfloat16, device=dev)
+        x0 = torch.zeros((B * H * W, cin.cin_pad), dtype=self.dtype, device=dev)
         x0[:, :zc] = z.permute(0, 2, 3, 1).reshape(B * H * W, zc)
         h, part = self._run_conv(cin, x0, B, H, W)
         h, part = self._resblock("mid.block_1", d.mid.block_1, h, part, B, H, W)
@@ -136,7 +158,7 @@ class HipDecoder:
             if i_level != 0:
                 if stage.upsample.with_conv:
                     H, W = 2 * H, 2 * W
-                    h, part = self._run_conv(self._conv(dev, f"up.{i_level}.upsample", stage.upsample.conv), h.to(torch.bfloat16),
+                    h, part = self._run_conv(self._conv(dev, f"up.{i_level}.upsample", stage.upsample.conv), h.to(self.dtype),
                                              B, H, W, upsample2x=True)
                 else:
                     C = h.shape[1]
@@ -147,10 +169,11 @@ class HipDecoder:
         return out.view(B, H, W, -1).permute(0, 3, 1, 2)
 
 
-def hip_decoder(decoder):
-    """the HipDecoder of a Decoder module (kept on the module, so packed weights are built once)"""
-    hd = decoder.__dict__.get("_hip_decoder")
+def hip_decoder(decoder, dtype=None):
+    """the HipDecoder of a Decoder module for an operand type (kept on the module, so packed weights are built once)"""
+    dtype = DEFAULT_DTYPE if dtype is None else dtype
+    cache = decoder.__dict__.setdefault("_hip_decoder", {})
+    hd = cache.get(dtype)
     if hd is None:
-        hd = HipDecoder(decoder)
-        decoder.__dict__["_hip_decoder"] = hd
+        hd = cache[dtype] = HipDecoder(decoder, dtype)
     return hd

@@ -66,7 +66,8 @@ EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_make_qparams",
            "qd_conv2d_i8_acc", "qd_groupnorm_ws_bytes", "qd_groupnorm_silu_quant", "qd_groupnorm_mod_silu_quant", "qd_layernorm_quant",
            "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8", "qd_attn_keyterm", "qd_attn_uses_keyterm", "qd_attn_config", "qd_bmm_qk_i8", "qd_bmm_pv_i8", "qd_temb_mlp",
            "qd_fakequant_blocks", "qd_fakequant_fwd", "qd_fakequant_bwd",
-           "qd_conv2d_bf16", "qd_pack_weights_bf16_bytes", "qd_pack_weights_bf16", "qd_groupnorm_silu_bf16"]
+           "qd_conv2d_bf16", "qd_pack_weights_bf16_bytes", "qd_pack_weights_bf16", "qd_groupnorm_silu_bf16",
+           "qd_pack_weights_h16", "qd_groupnorm_silu_h16"]
 
 _lib = None
 
@@ -107,7 +108,7 @@ def load():
                                i64, vp, i64, vp, i32, i32, i32, vp]
     lib.qd_attn_keyterm.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     lib.qd_attn_uses_keyterm.argtypes = [i32, i32, i32]
-    lib.qd_attn_config.argtypes = [i32, i32, i32]
+    lib.qd_attn_config.argtypes = [i32, i32, i32, i32]
     lib.qd_attn_config.restype = None
     lib.qd_temb_mlp.argtypes = [vp, i64, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i64, vp]
     lib.qd_bmm_qk_i8.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i64, i64, vp]
@@ -121,6 +122,8 @@ def load():
     lib.qd_pack_weights_bf16_bytes.argtypes = [i32, i32, i32]
     lib.qd_pack_weights_bf16.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     lib.qd_groupnorm_silu_bf16.argtypes = [vp, i64, i64, i32, i64, i32, f32, vp, vp, i32, vp, i64, vp, vp, i32, i64, vp]
+    lib.qd_pack_weights_h16.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.qd_groupnorm_silu_h16.argtypes = [vp, i64, i64, i32, i64, i32, f32, vp, vp, i32, i32, vp, i64, vp, vp, i32, i64, vp]
     if lib.qd_abi_version() != 18:
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
     _lib = lib
@@ -307,22 +310,26 @@ def pad8(n):
     return (n + 7) // 8 * 8
 
 
-def pack_weights_bf16(w):
-    """fp32 [Cout][Cin][kh][kw] (or [Cout][Cin]) -> tile-ordered bf16 bytes for qd_conv2d_bf16 (Cin padded to 8)."""
+def pack_weights_bf16(w, dtype=torch.bfloat16):
+    """fp32 [Cout][Cin][kh][kw] (or [Cout][Cin]) -> tile-ordered bf16 (or fp16) bytes for qd_conv2d_bf16 (Cin padded to 8)."""
+    if dtype not in (torch.bfloat16, torch.float16):
+        raise HipEngineError("pack_weights_bf16: operand type must be bfloat16 or float16")
     w = w.detach().float().contiguous()
     Cout, Cin = w.shape[0], w.shape[1]
     taps = w[0, 0].numel()
     cpad = pad8(Cin)
     wt = torch.zeros(int(load().qd_pack_weights_bf16_bytes(Cout, taps, cpad)), dtype=torch.uint8, device=w.device)
-    _check(load().qd_pack_weights_bf16(_ptr(w, "w"), Cout, Cin, taps, cpad, _ptr(wt), _stream()), "qd_pack_weights_bf16")
+    _check(load().qd_pack_weights_h16(_ptr(w, "w"), Cout, Cin, taps, cpad, 17 if dtype == torch.float16 else 16, _ptr(wt), _stream()),
+           "qd_pack_weights_h16")
     return wt
 
 
 def conv2d_bf16(x, wt, bias, out, B, H, W, Cin_pad, Cout, k=3, pad=1, residual=None, gn_part=None, upsample2x=False):
-    """x: bf16 rows [B*Hin*Win][ldx] (Hin = H/2 when upsample2x, the kernel folds the nearest-2x copy into its gather);
-    out: fp32 or bf16 rows [B*H*W][ldo]; residual: rows of the output's type; stride-1 'same' convolution k x k."""
-    if x.dtype != torch.bfloat16 or out.dtype not in (torch.float32, torch.bfloat16):
-        raise HipEngineError("conv2d_bf16: x must be bf16, out fp32 / bf16")
+    """x: bf16 (or fp16: the weights must have been packed with the same type) rows [B*Hin*Win][ldx] (Hin = H/2 when
+    upsample2x, the kernel folds the nearest-2x copy into its gather); out: fp32 rows or rows of x's type [B*H*W][ldo];
+    residual: rows of the output's type; stride-1 'same' convolution k x k."""
+    if x.dtype not in (torch.bfloat16, torch.float16) or out.dtype not in (torch.float32, x.dtype):
+        raise HipEngineError("conv2d_bf16: x must be bf16 / fp16, out fp32 or x's type")
     if residual is not None and residual.dtype != out.dtype:
         raise HipEngineError("conv2d_bf16: the residual has the type of the output")
     d = ConvDesc()
@@ -332,8 +339,8 @@ def conv2d_bf16(x, wt, bias, out, B, H, W, Cin_pad, Cout, k=3, pad=1, residual=N
     d.B, d.H, d.W, d.Ho, d.Wo, d.Cout = B, H, W, H, W, Cout
     d.kh = d.kw = k
     d.stride, d.pad_t, d.pad_l = 1, pad, pad
-    d.wbits, d.w_tiled, d.epilogue = 16, 1, EPI_LINEAR
-    d.out_dtype = BF16 if out.dtype == torch.bfloat16 else F32
+    d.wbits, d.w_tiled, d.epilogue = (17 if x.dtype == torch.float16 else 16), 1, EPI_LINEAR
+    d.out_dtype = BF16 if out.dtype == torch.bfloat16 else F16 if out.dtype == torch.float16 else F32
     d.gn_part = _ptr(gn_part, "gn_part")
     if gn_part is not None:
         d.gn_ld = part_ld(gn_part)
@@ -344,11 +351,14 @@ def conv2d_bf16(x, wt, bias, out, B, H, W, Cin_pad, Cout, k=3, pad=1, residual=N
 
 
 def groupnorm_silu_bf16(x, B, S, C, groups, eps, gamma, beta, silu, out, ws, part=None):
-    """fp32 rows [B*S][ldx] -> GroupNorm (+ SiLU) -> bf16 rows [B*S][ldo]; part: first-level statistics of the producer."""
+    """fp32 rows [B*S][ldx] -> GroupNorm (+ SiLU) -> bf16 / fp16 rows [B*S][ldo] (the type of `out`); part: first-level
+    statistics of the producer."""
+    if out.dtype not in (torch.bfloat16, torch.float16):
+        raise HipEngineError("groupnorm_silu_bf16: out must be bf16 or fp16 rows")
     nchunk, pld = (part.shape[1], part_ld(part)) if part is not None else (0, 0)
-    _check(load().qd_groupnorm_silu_bf16(_ptr(x, "x"), B, S, C, x.stride(0), groups, float(eps), _ptr(gamma), _ptr(beta),
-                                         1 if silu else 0, _ptr(out, "out"), out.stride(0), _ptr(ws, "ws"), _ptr(part), nchunk,
-                                         pld, _stream()), "qd_groupnorm_silu_bf16")
+    _check(load().qd_groupnorm_silu_h16(_ptr(x, "x"), B, S, C, x.stride(0), groups, float(eps), _ptr(gamma), _ptr(beta),
+                                        1 if silu else 0, BF16 if out.dtype == torch.bfloat16 else F16, _ptr(out, "out"), out.stride(0),
+                                        _ptr(ws, "ws"), _ptr(part), nchunk, pld, _stream()), "qd_groupnorm_silu_h16")
 
 
 def groupnorm_ws_bytes(B, C, S):
@@ -449,8 +459,8 @@ def attn_keyterm(k, BH, Spad, dpad, prm, kterm=None):
     return kterm
 
 
-def attn_config(pipe_mode=-1, xcd=-1, ktab=-1):
-    load().qd_attn_config(int(pipe_mode), int(xcd), int(ktab))
+def attn_config(pipe_mode=-1, xcd=-1, ktab=-1, lean=-1):
+    load().qd_attn_config(int(pipe_mode), int(xcd), int(ktab), int(lean))
 
 
 def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, wmax, q_asym, out, ldo,

@@ -250,6 +250,7 @@ class ContextKV:
         self.members = []
         self._ctx, self._out, self._side, self._joined = None, None, None, True
         self._pin = None
+        self.chain_runs = 0           # how often the to_k / to_v chain was issued (tests: a prepared context must not add to it)
 
     # ---- operands prepared ONCE per sampling run (QuantModel.prepare_context) -------------------------------------------
     # The reference recomputes k = to_k(context), v = to_v(context) in every evaluation (quant_block.py:193-195) although the
@@ -342,6 +343,7 @@ class ContextKV:
 
     def _work(self, context, tag="eval"):
         """The chain itself, on the current stream: {id(blk): (k8, v8^T, vsum, None)} in buffers owned by `tag`."""
+        self.chain_runs += 1
         B, S, Cc = context.shape
         dev = context.device
         # the fp32 row view of the context is made HERE, i.e. on the side stream when there is one: a converted /

@@ -282,7 +282,7 @@ def quantize_heads(x, B, T, H, d, strides, prescale, qparams, grid, transpose, o
 
 
 def attn_uses_keyterm(d, S, q_asym):
-    return bool(q_asym) and d < 96 and d % 32 != 0 and S >= 512
+    return bool(q_asym) and d < 64 and d % 32 != 0 and S >= 512
 
 
 def attn_keyterm(k, BH, Spad, dpad, prm, kterm=None):
@@ -349,9 +349,10 @@ def splitk_ws_bytes(c):
 
 # ---- first-stage decoder entry points (include/qdiff_hip.h "First-stage decoder"; qdiff.hip wrappers of the same names) ----
 
-def pack_weights_bf16(w):
-    """fp32 OIHW -> bf16 in the tile order of qd_pack_weights_bf16: per (tap, 32-channel K-step, 32-output-channel tile)
-    2 KB as [k-half (16 ch)][lane-half (8 ch)][n % 32][8 bf16]; returned as the uint8 buffer the kernel would read."""
+def pack_weights_bf16(w, dtype=torch.bfloat16):
+    """fp32 OIHW -> bf16 (or IEEE halves: qd_pack_weights_h16 with wbits = 17) in the tile order of qd_pack_weights_bf16: per
+    (tap, 32-channel K-step, 32-output-channel tile) 2 KB as [k-half (16 ch)][lane-half (8 ch)][n % 32][8 elements]; returned as
+    the uint8 buffer the kernel would read."""
     w = w.detach().float()
     if w.dim() == 2:
         w = w[:, :, None, None]
@@ -360,27 +361,27 @@ def pack_weights_bf16(w):
     cpad = (Cin + 7) // 8 * 8
     nst, ntl = (cpad + 31) // 32, (Cout + 31) // 32
     buf = torch.zeros(taps * nst * ntl * 1024, dtype=torch.int16)
-    bits = w.reshape(Cout, Cin, taps).bfloat16().view(torch.int16)
+    bits = w.reshape(Cout, Cin, taps).to(dtype).view(torch.int16)
     n, c, t = torch.meshgrid(torch.arange(Cout), torch.arange(Cin), torch.arange(taps), indexing="ij")
     off = ((t * nst + c // 32) * ntl + n // 32) * 1024 + (((c % 32) // 8) * 32 + n % 32) * 8 + c % 8
     buf[off.reshape(-1)] = bits.reshape(-1)
     return buf.view(torch.uint8)
 
 
-def _unpack_weights_bf16(wt, Cout, cpad, taps):
+def _unpack_weights_bf16(wt, Cout, cpad, taps, dtype=torch.bfloat16):
     nst, ntl = (cpad + 31) // 32, (Cout + 31) // 32
     buf = wt.view(torch.int16)
     n, c, t = torch.meshgrid(torch.arange(Cout), torch.arange(cpad), torch.arange(taps), indexing="ij")
     off = ((t * nst + c // 32) * ntl + n // 32) * 1024 + (((c % 32) // 8) * 32 + n % 32) * 8 + c % 8
-    return buf[off.reshape(-1)].view(torch.bfloat16).float().reshape(Cout, cpad, taps)
+    return buf[off.reshape(-1)].view(dtype).float().reshape(Cout, cpad, taps)
 
 
 def conv2d_bf16(x, wt, bias, out, B, H, W, Cin_pad, Cout, k=3, pad=1, residual=None, gn_part=None, upsample2x=False):
     """out[m][n] = sum_k x w + bias[n] (+ residual[m][n]); exact bf16 products, fp32 accumulation (here: fp64, rounded once);
     x rows are at half resolution when upsample2x (nearest-2x folded into the gather)."""
-    assert x.dtype == torch.bfloat16 and out.dtype in (torch.float32, torch.bfloat16)
+    assert x.dtype in (torch.bfloat16, torch.float16) and out.dtype in (torch.float32, x.dtype)
     hin, win = (H // 2, W // 2) if upsample2x else (H, W)
-    w = _unpack_weights_bf16(wt, Cout, Cin_pad, k * k).reshape(Cout, Cin_pad, k, k)
+    w = _unpack_weights_bf16(wt, Cout, Cin_pad, k * k, x.dtype).reshape(Cout, Cin_pad, k, k)
     xi = x[:, :Cin_pad].double().reshape(B, hin, win, Cin_pad).permute(0, 3, 1, 2)
     if upsample2x:
         xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
@@ -414,7 +415,8 @@ def groupnorm_silu_bf16(x, B, S, C, groups, eps, gamma, beta, silu, out, ws, par
     y = v.float() * a[:, None, :] + sh[:, None, :]
     if silu:
         y = y * (1.0 / (1.0 + torch.exp(-y)))
-    out.copy_(y.reshape(B * S, C).to(torch.bfloat16))
+    assert out.dtype in (torch.bfloat16, torch.float16)
+    out.copy_(y.reshape(B * S, C).to(out.dtype))
 
 
 def install(monkeypatch):

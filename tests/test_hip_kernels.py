@@ -558,8 +558,14 @@ def test_attention_fused(cuda, case):
     ns = lambda a: NS(delta=a["delta"], zero_point=a["zero_point"], n_bits=a["n_bits"], sym=a["sym"])
     ap = engine.build_attn_plan(ns(aq_q), ns(aq_k), ns(aq_v), ns(aq_w), scale, pre, cuda)
     C = H * d
-    out = engine.attention(ap, q.to(cuda), k.to(cuda), v.to(cuda), B, T, S, H, d,
-                           (T * C, C, d, 1), (S * C, C, d, 1), (S * C, C, d, 1))
+    from qdiff import hip
+    try:
+        if "d80" in name:
+            hip.attn_config(lean=3)              # opt-in: d = 80 on the register-fed lean kernel with three K slabs
+        out = engine.attention(ap, q.to(cuda), k.to(cuda), v.to(cuda), B, T, S, H, d,
+                               (T * C, C, d, 1), (S * C, C, d, 1), (S * C, C, d, 1))
+    finally:
+        hip.attn_config(lean=1)
     torch.cuda.synchronize()
     got = out.cpu().view(B, T, H, d).permute(0, 2, 1, 3).reshape(B * H, T, d)
     rng = want_int.abs().max().item()
@@ -685,12 +691,12 @@ def test_attention_lds_equals_lean(cuda, case):
         # qd_attn_keyterm table (accumulator seeds), 0: from constant-operand MFMAs — the accumulators hold the same integers
         for mode in (0, 3):
             for ktab in (1, 0):
-                hip.attn_config(pipe_mode=mode, ktab=ktab)
+                hip.attn_config(pipe_mode=mode, ktab=ktab, lean=3 if d >= 64 else 1)
                 o = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d)
                 torch.cuda.synchronize()
                 outs[(mode, ktab)] = o.clone()
     finally:
-        hip.attn_config(pipe_mode=2, ktab=1)
+        hip.attn_config(pipe_mode=2, ktab=1, lean=1)
     ref = outs[(0, 1)]
     assert torch.isfinite(ref).all() and ref.abs().max() > 0
     for key, o in outs.items():
