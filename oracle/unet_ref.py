@@ -25,6 +25,8 @@ class QuantCkpt:
         self.trace = None            # set to a list to record (name, tensor) at block boundaries
         self.blocks = None           # set to a list to record (kind, module path, inputs dict, output) of every block
                                      # (teacher-forced per-block parity: tests/test_block_parity.py)
+        self.sublayers = None        # set to a list to record (kind, module path, inputs dict, output) of the three sub-layers
+                                     # of every transformer block (attn1 / attn2 / ff incl. their residual adds)
 
     def note(self, name, t):
         if self.trace is not None:
@@ -36,6 +38,13 @@ class QuantCkpt:
         if self.blocks is not None:
             keep = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in inputs.items()}
             self.blocks.append((kind, name, keep, out.detach().clone()))
+        return out
+
+    def sub(self, kind, name, out, **inputs):
+        """Record one transformer sub-layer evaluation (input rows BEFORE its LayerNorm, output AFTER the residual add)."""
+        if self.sublayers is not None:
+            keep = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in inputs.items()}
+            self.sublayers.append((kind, name, keep, out.detach().clone()))
         return out
 
     def get(self, name):
@@ -244,10 +253,10 @@ def _cross_attn(Q, p, x, context, heads):
 
 def _transformer_block(Q, p, x, context, heads):
     """QuantBasicTransformerBlock._forward (quant_block.py:263-271) with GEGLU FF (attention.py:37-63)."""
-    x = _cross_attn(Q, p + ".attn1", Q.ln(p + ".norm1", x), None, heads) + x
-    x = _cross_attn(Q, p + ".attn2", Q.ln(p + ".norm2", x), context, heads) + x
+    x = Q.sub("attn1", p, _cross_attn(Q, p + ".attn1", Q.ln(p + ".norm1", x), None, heads) + x, x=x, heads=heads)
+    x = Q.sub("attn2", p, _cross_attn(Q, p + ".attn2", Q.ln(p + ".norm2", x), context, heads) + x, x=x, context=context, heads=heads)
     h = R.geglu(Q.linear(p + ".ff.net.0.proj", Q.ln(p + ".norm3", x)))
-    return Q.linear(p + ".ff.net.2", h) + x
+    return Q.sub("ff", p, Q.linear(p + ".ff.net.2", h) + x, x=x)
 
 
 def _spatial_transformer(Q, p, x, context, heads):

@@ -866,6 +866,10 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
                 if ctx.stride(1) != 1:
                     ctx = ctx.contiguous()
             rows = self._attn_int(self.attn2, rows, B, T, C, self.norm2, ctx if kv is None else rows, S, kv=kv)
+        return self._ff_int(rows, B, T, C, out_plan)
+
+    def _ff_int(self, rows, B, T, C, out_plan=None):
+        """norm3 -> GEGLU projection -> FF output Linear (+ residual rows): the third sub-layer (attention.py:229-231)."""
         proj, ff_out = self.ff.net[0].proj, self.ff.net[-1]
         (h8,) = _ln_to([proj], rows, B * T, C, self.norm3)
         gplan = proj.geglu_plan() if ff_out.act_quantizer.inited else None

@@ -32,10 +32,12 @@ BOUNDS = {
 }
 
 
-def _oracle_blocks(fx):
+def _oracle_blocks(fx, sublayers=False):
     spec = fx["spec"]
     Q = U.QuantCkpt(build_ckpt(fx), spec["w_bits"], spec["a_bits"], spec["a_sym"], spec["sm_abit"])
     Q.blocks = []
+    if sublayers:
+        Q.sublayers = []
     x, t, c = fixture_inputs(fx, "test")
     with torch.no_grad():
         if spec["family"] == "cifar":
@@ -102,10 +104,11 @@ def _oracle_block(Q, fx, kind, path, inp):
     return None
 
 
-def run_block_parity(qnn, fx, dev, sync=None):
-    """Walk the oracle once, teacher-force every engine block; returns (report lines, failure lines)."""
+def run_block_parity(qnn, fx, dev, sync=None, sublayers=False):
+    """Walk the oracle once, teacher-force every engine block; returns (report lines, failure lines).
+    sublayers: also teacher-force the three sub-layers of every transformer block from the same walk (run_sublayer_parity)."""
     name = fx["name"]
-    Q, y_oracle = _oracle_blocks(fx)
+    Q, y_oracle = _oracle_blocks(fx, sublayers=sublayers)
     spec = fx["spec"]
     Q64 = None
     lines, failures = [], []
@@ -166,4 +169,109 @@ def run_block_parity(qnn, fx, dev, sync=None):
         lines.append(f"[{name}] code-flip rate at the first quantiser of the residual blocks: {flips} / {total} = {flips / total:.3e}")
         if flips / total > 2e-5:                                   # measured on the MI355X, round 3: 0 ... 3.9e-6
             failures.append(f"code-flip rate {flips / total:.3e} > 2e-5")
+    if sublayers and Q.sublayers:
+        sl, sf = run_sublayer_parity(qnn, fx, dev, sync=sync, Q=Q)
+        lines += sl
+        failures += sf
+    return lines, failures
+
+
+# ------------------------------------------------------------------------------------------------
+# transformer sub-layers (the SD transformer blocks at 4096 tokens were judged only through the fp64
+# envelope of the whole block; here each of the three sub-layers is teacher-forced from the oracle's recorded input)
+# ------------------------------------------------------------------------------------------------
+# attention OUTPUT (before to_out) vs the exact-integer oracle (integer codes, exact contractions, fp64 softmax), in units of
+# its range: (max fraction of elements beyond 2e-4, max |diff|); the bulk bound is test_attention_fused's
+ATTN_OUT_BOUNDS = (1e-2, 2e-2)
+# fraction of to_out[0]'s int8 input codes that differ from the codes of the exact-integer attention output (a one-step move
+# of a code whose value lay within the attention's float error of a rounding tie).  Measured on the MI355X (round 4,
+# profiles/r04_sublayer_parity_report.txt): <= 4e-3 on every sd_full block
+TO_OUT_FLIP_BOUND = 1e-2
+# sub-layer outputs (after to_out / ff + residual) vs the oracle's fp32 simulation: (max, mean) of |diff| / range — one-step moves
+# of a few codes entering to_out / the FF output Linear, each of which moves a whole output row by <= delta * |w|
+SUB_OUT_BOUNDS = {"attn1": (2e-2, 2e-4), "attn2": (2e-2, 2e-4), "ff": (2e-2, 2e-4)}
+
+
+def run_sublayer_parity(qnn, fx, dev, sync=None, Q=None):
+    """Teacher-force attn1 / attn2 / ff of every transformer block from the ORACLE's sub-layer inputs.  The attention is
+    judged against the exact-integer oracle (R.attention_int on the oracle's own q / k / v projections), the sub-layer output
+    against the oracle's fp32 simulation.  Returns (report lines, failure lines)."""
+    from qdiff import engine
+    name = fx["name"]
+    if Q is None:
+        Q, _ = _oracle_blocks(fx, sublayers=True)
+    lines, failures = [], []
+    worst = {}
+    for kind, path, inp, want in Q.sublayers:
+        blk = qnn.model.get_submodule(path)
+        x = inp["x"]
+        B, T, C = x.shape
+        rows = x.reshape(B * T, C).to(dev).contiguous()
+        with torch.no_grad():
+            if kind == "ff":
+                got = blk._ff_int(rows, B, T, C).float().cpu().reshape(want.shape)
+            else:
+                att, ln, p = (blk.attn1, blk.norm1, path + ".attn1") if kind == "attn1" else (blk.attn2, blk.norm2, path + ".attn2")
+                ctx = inp.get("context")
+                ctx_rows, S = None, T
+                if ctx is not None:
+                    S = ctx.shape[1]
+                    ctx_rows = ctx.reshape(B * S, ctx.shape[2]).float().to(dev).contiguous()
+                rec = {}
+                real = engine.attention_codes
+
+                def spy(ap, q8, k8, v8, vsum, B_, T_, S_, H_, d_, out=None, out_plan=None, kterm=None):
+                    rec["f32"] = real(ap, q8, k8, v8, vsum, B_, T_, S_, H_, d_, kterm=kterm).float().cpu()
+                    r = real(ap, q8, k8, v8, vsum, B_, T_, S_, H_, d_, out=out, out_plan=out_plan, kterm=kterm)
+                    if out_plan is not None:
+                        rec["o8"], rec["off"], rec["width"] = r.cpu(), out_plan.grids[0].off, H_ * d_
+                    return r
+                engine.attention_codes = spy
+                try:
+                    got = blk._attn_int(att, rows, B, T, C, ln, ctx_rows, S).float().cpu().reshape(want.shape)
+                finally:
+                    engine.attention_codes = real
+                # exact-integer oracle of the attention itself, on the oracle's own projections of the same input
+                heads = inp["heads"]
+                xl = Q.ln(path + (".norm1" if kind == "attn1" else ".norm2"), x)
+                src = xl if ctx is None else ctx
+                q, k, v = Q.linear(p + ".to_q", xl), Q.linear(p + ".to_k", src), Q.linear(p + ".to_v", src)
+                sh = lambda t_: t_.reshape(t_.shape[0], t_.shape[1], heads, -1).permute(0, 2, 1, 3).reshape(t_.shape[0] * heads, t_.shape[1], -1)
+                d = q.shape[-1] // heads
+                o_int, _ = R.attention_int(sh(q), sh(k), sh(v), d ** -0.5, Q.act_q(p + ".act_quantizer_q"), Q.act_q(p + ".act_quantizer_k"),
+                                           Q.act_q(p + ".act_quantizer_v"), Q.act_q(p + ".act_quantizer_w", n_bits=Q.sm_abit))
+                o_int = o_int.reshape(B, heads, T, d).permute(0, 2, 1, 3).reshape(B * T, heads * d)
+                rng_a = o_int.abs().max().item()
+                da = (rec["f32"].double() - o_int).abs()
+                fa, ma = (da > 2e-4 * rng_a).float().mean().item(), da.max().item() / rng_a
+                w = worst.setdefault(kind + " attention output vs exact-integer oracle", [0, 0.0, 0.0])
+                w[0], w[1], w[2] = w[0] + 1, max(w[1], fa), max(w[2], ma)
+                if fa > ATTN_OUT_BOUNDS[0] or ma > ATTN_OUT_BOUNDS[1]:
+                    failures.append(f"{kind} {path}: attention output vs exact-integer oracle: {fa:.3e} of elements beyond 2e-4*range "
+                                    f"(bound {ATTN_OUT_BOUNDS[0]}), max {ma:.3e} (bound {ATTN_OUT_BOUNDS[1]})")
+                if "o8" in rec:
+                    aq = Q.act_q(p + ".to_out.0.act_quantizer")
+                    ref_codes = R.uaq_codes(o_int.float(), aq["delta"], aq["zero_point"], aq["n_bits"], aq["sym"]) - rec["off"]
+                    flips = (rec["o8"][:, :rec["width"]].long() != ref_codes.long()).float().mean().item()
+                    w = worst.setdefault(kind + " to_out code flips", [0, 0.0, 0.0])
+                    w[0], w[1] = w[0] + 1, max(w[1], flips)
+                    if flips > TO_OUT_FLIP_BOUND:
+                        failures.append(f"{kind} {path}: {flips:.3e} of to_out's input codes differ from the exact-integer attention's (bound {TO_OUT_FLIP_BOUND})")
+        rng = want.abs().max().item()
+        d_ = (got - want).abs()
+        mx, mean = d_.max().item() / rng, d_.mean().item() / rng
+        w = worst.setdefault(kind + " sub-layer output vs fp32 oracle", [0, 0.0, 0.0])
+        w[0], w[1], w[2] = w[0] + 1, max(w[1], mx), max(w[2], mean)
+        bx, bm = SUB_OUT_BOUNDS[kind]
+        if mx > bx or mean > bm:
+            failures.append(f"{kind} {path}: sub-layer output vs fp32 oracle max {mx:.3e} (bound {bx}), mean {mean:.3e} (bound {bm})")
+    if sync is not None:
+        sync()
+    for k, (n, a, b) in sorted(worst.items()):
+        if "flips" in k:
+            lines.append(f"[{name}] {k:52s} x{n:3d}: worst flip rate {a:.3e}")
+        elif "exact-integer" in k:
+            lines.append(f"[{name}] {k:52s} x{n:3d}: worst fraction beyond 2e-4*range {a:.3e}, worst max {b:.3e} of range")
+        else:
+            lines.append(f"[{name}] {k:52s} x{n:3d}: worst max {a:.3e}, worst mean {b:.3e} of range")
     return lines, failures

@@ -395,6 +395,18 @@ def test_blocks_teacher_forced_on_emulator(emu, name):
     assert not failures, "\n".join(failures)
 
 
+def test_transformer_sublayers_teacher_forced_on_emulator(emu):
+    """The sub-layer harness of tests/test_block_parity.py (attn1 / attn2 / ff of every transformer block fed the oracle's
+    sub-layer input; the attention judged against the exact-integer oracle, the to_out code flips counted) on the ABI
+    emulator, sd_tiny."""
+    from block_parity_util import run_sublayer_parity
+    fx = load_fixture("model_sd_tiny.pt")
+    qnn = _resume_cpu(fx)
+    lines, failures = run_sublayer_parity(qnn, fx, torch.device("cpu"))
+    print("\n" + "\n".join(lines))
+    assert len(lines) >= 5 and not failures, "\n".join(failures)
+
+
 def test_churches_unet_on_emulator(emu):
     """LSUN-Churches LDM-8 at its real shapes (models/ldm/lsun_churches256/config.yaml: 4 x 32 x 32 latents, 35 residual
     blocks that all modulate their second norm, 4 + 4 of them resampling, 21 eight-head attention blocks with head dims
