@@ -286,6 +286,15 @@ STREAM_DTYPE = torch.float16 if os.environ.get("QDIFF_STREAM", "fp32").lower() i
 # (tests, micro-benchmarks) gets STREAM_DTYPE.
 _EFFECTIVE = [None]
 
+# Bumped by every change of a quantisation switch or quantiser state below QuantModel's own entry points
+# (QuantModule / BaseQuantBlock.set_quant_state, set_running_stat, a quantiser dropping its initialisation): QuantModel re-validates
+# its cached "every layer is on the integer path" verdict when the counter has moved.
+STATE_GENERATION = [0]
+
+
+def bump_state():
+    STATE_GENERATION[0] += 1
+
 
 def stream_dtype():
     return _EFFECTIVE[0] if _EFFECTIVE[0] is not None else STREAM_DTYPE
@@ -627,6 +636,15 @@ def begin_evaluation(model_key=None):
         if mk == model_key and st["used"]:
             st["arena"][:st["used"]].zero_()
             st["clean"] = {id(v) for v in st["views"].values() if v.untyped_storage().data_ptr() == st["arena"].untyped_storage().data_ptr()}
+
+
+def release_model(model_key):
+    """Drop the V-sum arena(s) of a QuantModel that is gone (weakref.finalize of the model): its 4 MB device arena and the
+    bookkeeping that a recycled id() would otherwise inherit."""
+    for k in [k for k in _VSUM if k[1] == model_key]:
+        del _VSUM[k]
+    if _VSUM_OWNER[0] == model_key:
+        _VSUM_OWNER[0] = None
 
 
 def _vsum_prepare(vsum):

@@ -89,6 +89,13 @@ class UniformAffineQuantizer(nn.Module):
     first tensor seen follow reference quant_layer.py:36-200.
     """
 
+    def __setattr__(self, name, value):
+        # a quantiser that (re-)enters data-dependent initialisation or range tracking takes its layer off the integer path:
+        # QuantModel's cached "whole model on the integer path" verdict must be re-validated (engine.STATE_GENERATION)
+        if name in ("inited", "running_stat"):
+            engine.bump_state()
+        super().__setattr__(name, value)
+
     def __init__(self, n_bits: int = 8, symmetric: bool = False, channel_wise: bool = False,
                  scale_method: str = 'max', leaf_param: bool = False, always_zero: bool = False):
         super().__init__()
@@ -329,6 +336,7 @@ class QuantModule(nn.Module):
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
         self.use_weight_quant = weight_quant
         self.use_act_quant = act_quant
+        engine.bump_state()
 
     def set_split(self):
         self.weight_quantizer_0 = UniformAffineQuantizer(**self.weight_quant_params)
@@ -336,6 +344,7 @@ class QuantModule(nn.Module):
             self.act_quantizer_0 = UniformAffineQuantizer(**self.act_quant_params)
 
     def set_running_stat(self, running_stat: bool):
+        engine.bump_state()
         if self.act_quant_mode == 'qdiff':
             self.act_quantizer.running_stat = running_stat
             if self.split != 0:

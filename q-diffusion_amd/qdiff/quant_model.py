@@ -42,6 +42,8 @@ class QuantModel(nn.Module):
         self._fuse_time_embedding()
         self._graphs = None
         self._quant_state = (False, False)
+        import weakref
+        weakref.finalize(self, engine.release_model, id(self))      # the per-model V-sum arena dies with the model
 
     def quant_module_refactor(self, module: nn.Module, weight_quant_params: dict = {}, act_quant_params: dict = {}):
         """Conv2d / Conv1d / Linear -> QuantModule, recursively (reference :25-43)."""
@@ -91,7 +93,9 @@ class QuantModel(nn.Module):
                                                              self._select_stream(),
                                                              ctx.start(_a[2]) if _qb._CTX_FORK == "start" and len(_a) > 2 and torch.is_tensor(_a[2])
                                                              else None) and None)
-        self.model.register_forward_hook(lambda _m, _a, _o: ctx.finish(), always_call=True)
+        # end of the evaluation: the context branch is joined, and the stream type in force goes back to "unset" (code that
+        # drives kernels directly afterwards gets engine.STREAM_DTYPE, not this model's verdict)
+        self.model.register_forward_hook(lambda _m, _a, _o: (ctx.finish(), engine._EFFECTIVE.__setitem__(0, None)) and None, always_call=True)
         te = getattr(self.model, "time_embed", None)
         if (isinstance(te, nn.Sequential) and len(te) == 3 and isinstance(te[0], QuantModule) and isinstance(te[2], QuantModule)
                 and isinstance(te[1], nn.SiLU)):
@@ -215,7 +219,7 @@ class QuantModel(nn.Module):
         if engine.STREAM_DTYPE == torch.float32:
             engine._EFFECTIVE[0] = None
             return
-        ready = self.__dict__.get("_stream_ready", False)
+        ready = self.__dict__.get("_stream_ready", False) and self.__dict__.get("_stream_ready_gen") == engine.STATE_GENERATION[0]
         if not ready and self._quant_state == (True, True) and not torch.is_grad_enabled() and not engine.SIMULATE and not self.model.training:
             ready = True
             for m in self.model.modules():
@@ -229,6 +233,7 @@ class QuantModel(nn.Module):
                         ready = False
                         break
             self.__dict__["_stream_ready"] = ready
+            self.__dict__["_stream_ready_gen"] = engine.STATE_GENERATION[0]
         ok = ready and self._quant_state == (True, True) and not torch.is_grad_enabled() and not engine.SIMULATE
         engine._EFFECTIVE[0] = engine.STREAM_DTYPE if ok else torch.float32
 
