@@ -33,6 +33,9 @@ import torch.nn.functional as F
 
 from . import hip
 
+# QDIFF_DECODER_GRAPH=0: issue the ~150 launches of a decode one by one instead of replaying them as one HIP graph per
+# (latent shape, weights) — the A/B knob of the replay
+USE_GRAPH = os.environ.get("QDIFF_DECODER_GRAPH", "1") != "0"
 DEFAULT_DTYPE = torch.bfloat16 if os.environ.get("QDIFF_DECODER_DTYPE", "fp16").lower() in ("bf16", "bfloat16") else torch.float16
 
 
@@ -65,9 +68,11 @@ class HipDecoder:
         if self.dtype not in (torch.float16, torch.bfloat16):
             raise hip.HipEngineError("HipDecoder: operand type must be float16 or bfloat16")
         self._packs = {}
+        self._graphs = {}
 
     def invalidate(self):
         self._packs.clear()
+        self._graphs.clear()
 
     # ---- weights ----
     @staticmethod
@@ -135,6 +140,33 @@ class HipDecoder:
 
     @torch.no_grad()
     def __call__(self, z):
+        """z: fp32 [B, z_channels, h, w] on the GPU (after post_quant_conv) -> fp32 [B, out_ch, H, W].
+        On the GPU the walk is captured once per (latent shape, state of the weights) and replayed as one HIP graph
+        (reference: one `Decoder.forward` per batch, model.py:538-572; here ~150 launches of a few microseconds to tens of
+        milliseconds — the replay removes the host from between them)."""
+        if not (USE_GRAPH and z.is_cuda) or torch.cuda.is_current_stream_capturing():
+            return self._walk(z)
+        key = (z.device, tuple(z.shape), z.dtype, self._stamp(*self.dec.parameters()))
+        g = self._graphs.get(key)
+        if g is None:
+            zs = z.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._walk(zs)                  # packs, allocator, library attention heuristics: outside the capture
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._walk(zs)
+            if len(self._graphs) >= 4:          # a few batch shapes at most (full chunks + a ragged last one)
+                self._graphs.clear()
+            g = self._graphs[key] = (graph, zs, out)
+        graph, zs, out = g
+        zs.copy_(z)
+        graph.replay()
+        return out.clone()                      # the static output belongs to the graph: the next replay overwrites it
+
+    def _walk(self, z):
         """z: fp32 [B, z_channels, h, w] on the GPU (after post_quant_conv) -> fp32 [B, out_ch, H, W] (NCHW view of NHWC rows)"""
         d, dev = self.dec, z.device             # (host tensors: the first launch wrapper raises — there is no host path)
         B, zc, H, W = z.shape

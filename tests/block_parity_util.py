@@ -182,14 +182,16 @@ def run_block_parity(qnn, fx, dev, sync=None, sublayers=False):
 # ------------------------------------------------------------------------------------------------
 # attention OUTPUT (before to_out) vs the exact-integer oracle (integer codes, exact contractions, fp64 softmax), in units of
 # its range: (max fraction of elements beyond 2e-4, max |diff|); the bulk bound is test_attention_fused's
-ATTN_OUT_BOUNDS = (1e-2, 2e-2)
+# measured on the MI355X, round 4 (profiles/r04_sublayer_parity_report.txt), worst of the 16 sd_full blocks: 2.1e-3 / 4.0e-3
+ATTN_OUT_BOUNDS = (5e-3, 1e-2)
 # fraction of to_out[0]'s int8 input codes that differ from the codes of the exact-integer attention output (a one-step move
 # of a code whose value lay within the attention's float error of a rounding tie).  Measured on the MI355X (round 4,
-# profiles/r04_sublayer_parity_report.txt): <= 4e-3 on every sd_full block
-TO_OUT_FLIP_BOUND = 1e-2
+# profiles/r04_sublayer_parity_report.txt): <= 6.6e-4 on every sd_full block (sd_tiny: 4.9e-4)
+TO_OUT_FLIP_BOUND = 2e-3
 # sub-layer outputs (after to_out / ff + residual) vs the oracle's fp32 simulation: (max, mean) of |diff| / range — one-step moves
 # of a few codes entering to_out / the FF output Linear, each of which moves a whole output row by <= delta * |w|
-SUB_OUT_BOUNDS = {"attn1": (2e-2, 2e-4), "attn2": (2e-2, 2e-4), "ff": (2e-2, 2e-4)}
+# measured worst (sd_full): attn1 1.8e-3 / 2.5e-5, attn2 2.2e-3 / 1.5e-5, ff 7.0e-3 / 2.1e-6
+SUB_OUT_BOUNDS = {"attn1": (5e-3, 6e-5), "attn2": (5e-3, 4e-5), "ff": (1.5e-2, 1e-5)}
 
 
 def run_sublayer_parity(qnn, fx, dev, sync=None, Q=None):

@@ -288,3 +288,32 @@ def test_hip_decoder_sd_shape_smoke(cuda):
     ref2 = fs.decode_first_stage(m, z, 1.0)
     out2 = fs.decode_first_stage(m, z, 1.0, engine="hip")
     assert (out2 - ref2).abs().max().item() / ref2.abs().max().item() <= DECODER_TOL[torch.float16]
+
+
+@pytest.mark.gpu
+def test_hip_decoder_graph_replay_equals_eager(cuda, monkeypatch):
+    """HipDecoder replays its walk as one HIP graph per (latent shape, weights): bit-identical to the launch-by-launch walk,
+    for other latents than the captured ones, in chunks (the static output is copied out before the next replay), and
+    re-captured after the weights changed."""
+    from qdiff import first_stage_hip as fh, synthetic
+    from qdiff.arch import first_stage as fs
+    fx = load_fixture("first_stage.pt")
+    case = fx["kl_tiny"]
+    m = _build(case, "kl").to(cuda)
+    g = torch.Generator().manual_seed(21)
+    zs = [case["z"].to(cuda), torch.randn(case["z"].shape, generator=g).to(cuda)]
+    big = torch.cat(zs + zs[:1])
+    monkeypatch.setattr(fh, "USE_GRAPH", False)
+    want = [fs.decode_first_stage(m, z, 1.0, engine="hip").clone() for z in zs]
+    monkeypatch.setattr(fh, "USE_GRAPH", True)
+    got = [fs.decode_first_stage(m, z, 1.0, engine="hip").clone() for z in zs + zs]
+    assert all(torch.equal(a, b) for a, b in zip(got, want + want))
+    chunked = fs.decode_first_stage(m, big, 1.0, engine="hip", max_activation_bytes=fs.largest_activation_bytes(m.decoder, 8, 8) * zs[0].shape[0])
+    assert torch.equal(chunked, torch.cat(want + want[:1]))
+    hd = fh.hip_decoder(m.decoder)
+    assert len(hd._graphs) == 1
+    m.load_state_dict({k: synthetic.tensor_for(k, v.shape, seed=5) for k, v in m.state_dict().items()})
+    monkeypatch.setattr(fh, "USE_GRAPH", False)
+    want2 = fs.decode_first_stage(m, zs[0], 1.0, engine="hip").clone()
+    monkeypatch.setattr(fh, "USE_GRAPH", True)
+    assert torch.equal(fs.decode_first_stage(m, zs[0], 1.0, engine="hip"), want2) and not torch.equal(want2, want[0])
