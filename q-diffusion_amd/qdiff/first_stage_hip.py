@@ -33,9 +33,10 @@ import torch.nn.functional as F
 
 from . import hip
 
-# QDIFF_DECODER_GRAPH=0: issue the ~150 launches of a decode one by one instead of replaying them as one HIP graph per
-# (latent shape, weights) — the A/B knob of the replay
-USE_GRAPH = os.environ.get("QDIFF_DECODER_GRAPH", "1") != "0"
+# QDIFF_DECODER_GRAPH=1: replay the ~150 launches of a decode as ONE HIP graph per (latent shape, weights) instead of issuing
+# them one by one.  Off by default: measured no gain (3.97 ms vs 3.99 ms per image, gpurun_out/r04_c6: the decode is
+# GPU-bound, its launches are tens of microseconds to milliseconds long) and it pins a private memory pool per shape.
+USE_GRAPH = os.environ.get("QDIFF_DECODER_GRAPH", "0") == "1"
 DEFAULT_DTYPE = torch.bfloat16 if os.environ.get("QDIFF_DECODER_DTYPE", "fp16").lower() in ("bf16", "bfloat16") else torch.float16
 
 
@@ -141,9 +142,8 @@ class HipDecoder:
     @torch.no_grad()
     def __call__(self, z):
         """z: fp32 [B, z_channels, h, w] on the GPU (after post_quant_conv) -> fp32 [B, out_ch, H, W].
-        On the GPU the walk is captured once per (latent shape, state of the weights) and replayed as one HIP graph
-        (reference: one `Decoder.forward` per batch, model.py:538-572; here ~150 launches of a few microseconds to tens of
-        milliseconds — the replay removes the host from between them)."""
+        With QDIFF_DECODER_GRAPH=1 the walk is captured once per (latent shape, state of the weights) and replayed as one HIP
+        graph (reference: one `Decoder.forward` per batch, model.py:538-572); bit-identical, measured no faster."""
         if not (USE_GRAPH and z.is_cuda) or torch.cuda.is_current_stream_capturing():
             return self._walk(z)
         key = (z.device, tuple(z.shape), z.dtype, self._stamp(*self.dec.parameters()))

@@ -1,0 +1,34 @@
+#!/bin/bash
+# GPU box: round-4 closing run — the whole GPU suite, smoke, the driver's bench command (headline + cifar / ldm / decode child
+# runs), the full cifar / ldm lines, first-stage decode of every engine, steady-state breakdown + timeline of the graph-replayed
+# evaluation (context prepared), kernel-trace stats of the bench command, HBM traffic PMC passes, attention PMC passes.
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/r04f; mkdir -p $out
+timeout 1700 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $out/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1; tail -2 $out/smoke.log
+timeout 900 python bench.py > $out/bench_sd.json 2> $out/bench_sd.err; echo "bench rc=$?"; tail -c 700 $out/bench_sd.json; echo
+for m in cifar ldm; do timeout 600 python bench.py --model $m --images-per-gpu 64 > $out/bench_$m.json 2> $out/bench_$m.err; echo "bench $m rc=$?"; done
+timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-denominators --no-extras --decode 2> $out/bench_decode.err | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(d['first_stage_decode']))" | tee $out/decode_legs.json
+# steady-state graph-replayed evaluation
+timeout 600 rocprofv3 --kernel-trace -d $out -o evb -- python tools/eval_breakdown.py run sd 8 3 graph pin > $out/evb.log 2>&1
+db=$(find $out -name 'evb_results.db' | head -1)
+python tools/eval_breakdown.py join $db 3 > $out/sd_eval_breakdown_graph.txt; head -12 $out/sd_eval_breakdown_graph.txt | cut -c1-150
+python tools/eval_breakdown.py timeline $db 3 $out/sd_eval_timeline.tsv
+# kernel-trace stats of the bench command itself
+timeout 600 rocprofv3 --kernel-trace -d $out -o kt -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-denominators --no-extras > $out/kt.log 2>&1
+python tools/rocpd_stats.py $(find $out -name 'kt_results.db' | head -1) --md > $out/sd_bench_kernel_stats.md 2>&1; head -8 $out/sd_bench_kernel_stats.md | cut -c1-150
+find $out -name '*.db' -delete
+# HBM traffic (separate PMC passes, no other tracing domains)
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_hbm -o pmc_$c -- python tools/eval_breakdown.py run sd 8 2 pin > $out/pmc_$c.log 2>&1
+done
+QD_COMMIT=$QD_COMMIT python tools/pmc_eval_traffic.py $out/pmc_hbm 2 $out/sd_igemm_hbm_traffic.json | cut -c1-400
+# attention counters (flat rows, LDS-staged kernel with the key-term table)
+A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE"
+B="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_WAVES"
+for set in A B; do
+  ctr=$([ $set = A ] && echo "$A" || echo "$B")
+  timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_attn -o pmc_attn_$set -- python tools/bench_attn.py 3 "sd self 64x64" > $out/pmc_attn_$set.log 2>&1
+done
+python tools/pmc_table.py $out/pmc_attn attn > $out/pmc_attn_table.txt 2>&1; head -40 $out/pmc_attn_table.txt
+find $out -name '*.csv' -size +2M -delete; find $out -name '*.db' -delete
