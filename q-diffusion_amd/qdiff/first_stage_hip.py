@@ -209,3 +209,53 @@ def hip_decoder(decoder, dtype=None):
     if hd is None:
         hd = cache[dtype] = HipDecoder(decoder, dtype)
     return hd
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own Decoder class (drop-in use inside the q-diffusion source tree)
+# ------------------------------------------------------------------------------------------------
+# QDIFF_ADOPT_DECODER=0: leave the reference's `Decoder.forward` alone
+ADOPT_DECODER = os.environ.get("QDIFF_ADOPT_DECODER", "1") != "0"
+
+
+def _on_device(z):
+    return bool(z.is_cuda)
+
+
+def adopt_reference_decoder():
+    """Unmodified reference scripts never call this package's first-stage code: `model.decode_first_stage(samples)`
+    (ldm/models/diffusion/ddpm.py:710-770) ends in `AutoencoderKL.decode` -> `self.decoder(z)` (autoencoder.py:330-333), an
+    instance of the REFERENCE's `Decoder` (ldm/modules/diffusionmodules/model.py:465-572), which lives outside the UNet that
+    `QuantModel` wraps.  When that class is importable its `forward` is therefore bound — on the CLASS, once — to a dispatcher:
+    GPU tensor, no autograd, eval mode, the plain configuration (no `give_pre_end` / `tanh_out`) -> `HipDecoder` on this very
+    module (same attribute names as this package's mirror; fp16 operands, the precision the scripts' autocast runs the
+    decoder at, txt2img.py:231-236); anything else — CPU tensors, training, an unsupported layer — runs the reference's own
+    forward, untouched.  Called by QuantModel when it wraps a model (qdiff/quant_model.py: _adopt_reference_modules).
+    Returns the class, or None when the reference's `ldm` package is not importable / adoption is switched off."""
+    if not ADOPT_DECODER:
+        return None
+    try:
+        from ldm.modules.diffusionmodules import model as ref_model
+    except Exception:  # noqa: BLE001 - optional dependency
+        return None
+    cls = getattr(ref_model, "Decoder", None)
+    if cls is None or cls.__dict__.get("_qd_hip_forward"):
+        return cls
+    ref_forward = cls.forward
+
+    def forward(self, z):
+        if (torch.is_tensor(z) and z.dim() == 4 and _on_device(z) and not torch.is_grad_enabled() and not self.training
+                and not getattr(self, "give_pre_end", False) and not getattr(self, "tanh_out", False)
+                and not self.__dict__.get("_qd_hip_unsupported") and hip.available()):
+            try:
+                out = hip_decoder(self)(z.float())
+            except hip.HipEngineError:
+                self.__dict__["_qd_hip_unsupported"] = True           # a layer this engine does not implement: the reference's own code
+                return ref_forward(self, z)
+            return out.to(torch.get_autocast_gpu_dtype()) if (z.is_cuda and torch.is_autocast_enabled()) else out
+        return ref_forward(self, z)
+
+    cls.forward = forward
+    cls._qd_hip_forward = True
+    cls._qd_ref_forward = ref_forward
+    return cls

@@ -115,6 +115,8 @@ class QuantModel(nn.Module):
             producers' outputs: hooks on the input / middle / output blocks keep a shadow stack of them and re-attach the
             concatenated statistics to the block input."""
         ref = reference_classes()
+        from .first_stage_hip import adopt_reference_decoder
+        adopt_reference_decoder()            # the reference's first-stage Decoder class (outside this UNet): GPU decode on the MFMA kernels
         st, up = ref.get("SpatialTransformer"), ref.get("Upsample")
         for m in self.model.modules():
             if st is not None and type(m) is st:

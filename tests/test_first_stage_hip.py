@@ -91,7 +91,19 @@ for name in ("kl_tiny", "vq_tiny"):
     with torch.no_grad():
         same = torch.equal(dec(pq(c["z"])), c["out"])
         out = HipDecoder(dec)(pq(c["z"]))
-    res[name] = dict(cls=type(dec).__module__, golden_reproduced=bool(same),
+    # the class-level adoption QuantModel performs: CPU tensors keep the reference's own forward (bit for bit); with the device
+    # predicate forced (launch wrappers are the emulator's) the adopted forward IS the HipDecoder walk
+    from qdiff import first_stage_hip as fh
+    assert fh.adopt_reference_decoder() is Decoder and Decoder.__dict__.get("_qd_hip_forward")
+    with torch.no_grad():
+        still_same = torch.equal(dec(pq(c["z"])), c["out"])
+        fh._on_device, hip.available = (lambda z: True), (lambda: True)
+        adopted = dec(pq(c["z"]))
+        fh._on_device = lambda z: bool(z.is_cuda)
+    with torch.enable_grad():
+        grad_path = dec(pq(c["z"]))
+    res[name] = dict(cls=type(dec).__module__, golden_reproduced=bool(same), adopted_cpu_untouched=bool(still_same),
+                     adopted_equals_hipdecoder=bool(torch.equal(adopted, out)), grad_path_is_reference=bool(torch.equal(grad_path.detach(), c["out"])),
                      err=((out - c["out"]).abs().max() / c["out"].abs().max()).item())
 print("RESULT " + json.dumps(res))
 """
@@ -110,6 +122,7 @@ def test_hip_decoder_drives_the_reference_decoder_class():
     res = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
     for name, v in res.items():
         assert v["cls"] == "ldm.modules.diffusionmodules.model" and v["golden_reproduced"], (name, v)
+        assert v["adopted_cpu_untouched"] and v["adopted_equals_hipdecoder"] and v["grad_path_is_reference"], (name, v)
         assert v["err"] <= DECODER_TOL[torch.float16], (name, v)
 
 
@@ -317,3 +330,65 @@ def test_hip_decoder_graph_replay_equals_eager(cuda, monkeypatch):
     want2 = fs.decode_first_stage(m, zs[0], 1.0, engine="hip").clone()
     monkeypatch.setattr(fh, "USE_GRAPH", True)
     assert torch.equal(fs.decode_first_stage(m, zs[0], 1.0, engine="hip"), want2) and not torch.equal(want2, want[0])
+
+
+@pytest.mark.gpu
+def test_foreign_decoder_class_is_adopted_on_the_gpu(cuda, monkeypatch):
+    """VERDICT r03 missing #4 (call site), as far as a box without the reference tree allows: a `Decoder` class found under
+    `ldm.modules.diffusionmodules.model` — a stand-in: a distinct subclass of this package's mirror whose own forward counts its
+    calls — is adopted when a QuantModel is built: on the GPU, without autograd, `decoder(z)` runs the HipDecoder walk (the
+    foreign forward is never entered, the MFMA convolution wrapper is) and lands inside the fp16 bound of the REFERENCE golden;
+    under autograd and on host tensors the foreign class's own forward runs."""
+    import sys
+    import types
+    import qdiff
+    from qdiff import first_stage_hip as fh, hip
+    from qdiff.arch import ddim_unet, first_stage as fs
+    calls = {"foreign": 0, "conv": 0}
+
+    class Decoder(fs.Decoder):
+        def forward(self, z):
+            calls["foreign"] += 1
+            return fs.Decoder.forward(self, z)
+    Decoder.__module__ = "foreign"
+    mod = types.ModuleType("ldm.modules.diffusionmodules.model")
+    mod.Decoder = Decoder
+    pk = {"ldm": types.ModuleType("ldm"), "ldm.modules": types.ModuleType("ldm.modules"),
+          "ldm.modules.diffusionmodules": types.ModuleType("ldm.modules.diffusionmodules"), "ldm.modules.diffusionmodules.model": mod}
+    pk["ldm"].modules = pk["ldm.modules"]
+    pk["ldm.modules"].diffusionmodules = pk["ldm.modules.diffusionmodules"]
+    pk["ldm.modules.diffusionmodules"].model = mod
+    for k, v in pk.items():
+        monkeypatch.setitem(sys.modules, k, v)
+    real_conv = hip.conv2d_bf16
+
+    def counting_conv(*a, **k):
+        calls["conv"] += 1
+        return real_conv(*a, **k)
+    monkeypatch.setattr(hip, "conv2d_bf16", counting_conv)
+    fx = load_fixture("first_stage.pt")
+    case = fx["kl_tiny"]
+    m = _build(case, "kl")
+    dec = Decoder(**case["dd"]).eval()
+    dec.load_state_dict(m.decoder.state_dict())
+    dec = dec.to(cuda)
+    # building ANY QuantModel adopts the class (the scripts build LatentDiffusion first, then wrap its UNet)
+    wq = dict(n_bits=8, channel_wise=True, scale_method="max")
+    aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True, symmetric=True)
+    qdiff.QuantModel(ddim_unet.Model(ddim_unet.cifar10_config(split_shortcut=True)), wq, aq)
+    assert Decoder.__dict__.get("_qd_hip_forward")
+    z = m.post_quant_conv(case["z"]).detach().to(cuda)
+    with torch.no_grad():
+        out = dec(z)
+    torch.cuda.synchronize()
+    assert calls["foreign"] == 0 and calls["conv"] > 20
+    err = (out.float().cpu() - case["out"]).abs().max().item() / case["out"].abs().max().item()
+    assert out.dtype == torch.float32 and err <= DECODER_TOL[torch.float16], err
+    with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+        assert dec(z).dtype == torch.float16 and calls["foreign"] == 0
+    with torch.enable_grad():
+        ref = dec(z)                                     # autograd on: the foreign class's own forward
+    assert calls["foreign"] == 1 and (ref.detach().cpu() - case["out"]).abs().max().item() <= 1e-4 * case["out"].abs().max().item()
+    with torch.no_grad():
+        dec.cpu()(z.cpu())                               # host tensors: its own forward again
+    assert calls["foreign"] == 2
