@@ -3,7 +3,7 @@
 # runs), the full cifar / ldm lines, first-stage decode of every engine, steady-state breakdown + timeline of the graph-replayed
 # evaluation (context prepared), kernel-trace stats of the bench command, HBM traffic PMC passes, attention PMC passes.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/r04f; mkdir -p $out
+out=gpurun_out/${QD_OUT:-r04f}; mkdir -p $out
 timeout 1700 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1; tail -2 $out/smoke.log
 timeout 900 python bench.py > $out/bench_sd.json 2> $out/bench_sd.err; echo "bench rc=$?"; tail -c 700 $out/bench_sd.json; echo
