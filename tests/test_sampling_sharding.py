@@ -142,7 +142,11 @@ def _worker(rank, world, port, gb, out_dir):
     freed = all(m.weight.numel() == 0 for m in qnn.modules() if isinstance(m, qdiff.QuantModule))
     blocks = [m for m in qnn.modules() if isinstance(m, qdiff.quant_block.QuantBasicTransformerBlock)]
     geglu = [b.ff.net[0].proj.geglu_plan() is not None for b in blocks]
-    torch.save(dict(y=y, nbytes=nbytes, freed=freed, geglu=geglu), os.path.join(out_dir, f"model_{rank}.pt"))
+    # the run's conditioning prepared once (QuantModel.prepare_context) on EVERY rank — on rank 1 from the packed state alone,
+    # its fp32 weights are gone: same output as the per-evaluation computation
+    with torch.no_grad():
+        prepared = bool(qnn.prepare_context(c)) and torch.equal(qnn(x, t, c), y)
+    torch.save(dict(y=y, nbytes=nbytes, freed=freed, geglu=geglu, prepared=prepared), os.path.join(out_dir, f"model_{rank}.pt"))
     # --- sharded sampling --------------------------------------------------------------------------
     table = sampling.StepTable(sampling.ldm_betas(0.00085, 0.012), 10, eta=0.0)
     shape = (gb, 4, 8, 8)
@@ -181,6 +185,7 @@ def test_sharded_sampling_two_ranks_gloo(tmp_path, gb):
     assert m0["nbytes"] == m1["nbytes"] > 100_000
     assert torch.equal(m0["y"], m1["y"]) and torch.isfinite(m0["y"]).all()
     assert m1["freed"] and not m0["freed"]
+    assert m0["prepared"] and m1["prepared"]
     # every transformer block of the RECEIVER runs the fused GEGLU projection, with or without a prior forward on rank 0,
     # and the arena has the same size both ways
     assert len(m1["geglu"]) > 0 and all(m1["geglu"]) and all(m0["geglu"])
