@@ -222,12 +222,6 @@ _CTX_FORK = os.environ.get("QDIFF_CTX_FORK", "start")
 # QDIFF_CTX_PIN=0: QuantModel.prepare_context becomes a no-op, i.e. the cross-attention K / V^T operands are recomputed by
 # every evaluation as the reference does (quant_block.py:193-195) — the A/B knob of the once-per-sampling-run computation
 _CTX_PIN = os.environ.get("QDIFF_CTX_PIN", "1") != "0"
-# QDIFF_QKV_FORK: the k / v projections of a self-attention whose launches cannot fill the chip on their own (SD levels 2-3:
-# 256 blocks of one projection on 256 CUs) run on two side streams next to the q projection — parallel branches of the captured
-# graph, joined in front of the attention kernel.  "0" = one after the other (rounds 1-3).
-_QKV_FORK = os.environ.get("QDIFF_QKV_FORK", "0") != "0"
-_QKV_FORK_MAX_MN = 16384 * 640          # rows x width of one projection up to which the fork pays (level 1 has 2-4 blocks per CU already)
-_QKV_STREAMS = {}
 _FUSE_SKIP_QUANT = os.environ.get("QDIFF_FUSE_SKIP_QUANT", "1") != "0"     # A/B knob: skip-connection rows from the GroupNorm pass
 CAT_SLOTS = os.environ.get("QDIFF_CAT_SLOTS", "1") != "0"         # A/B knob: planned skip-concatenation buffers (engine.CatSlot)
 
@@ -840,27 +834,10 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
             y = mod.forward_codes(codes, 1, 1, B * n_tok) if codes is not None else _linear_rows(mod, ctx_rows)
             engine.heads_from_float(ap, which, y, B, n_tok, h, d, (n_tok * inner, inner, d, 1), buf, vsum)
 
-        fork = (_QKV_FORK and kv is None and ctx_rows is None and rows.is_cuda and B * T * inner <= _QKV_FORK_MAX_MN
-                and all(engine.heads_fusable(m.conv_plan(), T, h) for m in (att.to_q, att.to_k, att.to_v)))
-        if fork:
-            # three launches of <= 256 blocks each: side by side instead of one after the other.  The operands are persistent
-            # buffers and the int8 rows were allocated on the main stream, which waits for both branches before it goes on
-            main = torch.cuda.current_stream()
-            sk, sv = _QKV_STREAMS.get(rows.device) or _QKV_STREAMS.setdefault(rows.device, (torch.cuda.Stream(rows.device), torch.cuda.Stream(rows.device)))
-            sk.wait_stream(main)
-            sv.wait_stream(main)
-            with torch.cuda.stream(sk):
-                operand(att.to_k, xk, 1, S, k8)
-            with torch.cuda.stream(sv):
-                operand(att.to_v, xv, 2, S, v8)
-            operand(att.to_q, xq, 0, T, q8)
-            main.wait_stream(sk)
-            main.wait_stream(sv)
-        else:
-            operand(att.to_q, xq, 0, T, q8)
-            if kv is None:
-                operand(att.to_k, xk, 1, S, k8)
-                operand(att.to_v, xv, 2, S, v8)
+        operand(att.to_q, xq, 0, T, q8)
+        if kv is None:
+            operand(att.to_k, xk, 1, S, k8)
+            operand(att.to_v, xv, 2, S, v8)
         if pre_attention is not None:
             pre_attention()                     # the next launch on this stream is the attention kernel
         out_lin = att.to_out[0]
