@@ -50,8 +50,10 @@ def main(path, subs):
                 if g(c) is not None:
                     print(f"    {'-> ' + c + ' / WAVE_CYCLES':34s} {d[c] / d['SQ_WAVE_CYCLES']:18.3f}")
         if g("SQ_VALU_MFMA_BUSY_CYCLES") is not None and g("GRBM_GUI_ACTIVE"):
-            # MFMA_BUSY counts cycles summed over SIMDs (4 per CU, 256 CUs); GUI_ACTIVE = kernel cycles
-            print(f"    {'-> MFMA busy (of 1024 SIMDs)':34s} {d['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * d['GRBM_GUI_ACTIVE']):18.3f}")
+            # MFMA_BUSY counts cycles summed over SIMDs (4 per CU, 256 CUs).  rocprofv3 (ROCm 7.2) reports GRBM_GUI_ACTIVE summed
+            # over the 8 XCDs (a 0.95 ms kernel reads 16.5 M = 8 x 2.06 M cycles): kernel cycles = GUI_ACTIVE / 8
+            print(f"    {'-> MFMA busy (of 1024 SIMDs)':34s} {d['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * d['GRBM_GUI_ACTIVE'] / 8.0):18.3f}"
+                  f"   (kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs)")
         if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and d["TCC_HIT_sum"] + d["TCC_MISS_sum"] > 0:
             print(f"    {'-> L2 hit rate':34s} {d['TCC_HIT_sum'] / (d['TCC_HIT_sum'] + d['TCC_MISS_sum']):18.3f}")
         if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"):
