@@ -7,7 +7,7 @@ Compiles csrc/<file> of <rev> and of the working tree for gfx950 with the flags 
 (`--save-temps`-free: `-S --cuda-device-only`), splits the device assembly into functions and compares the instruction
 streams symbol by symbol (labels renumbered, comments and debug directives dropped).  Used at the end of a round whose
 last commits could not be run on a GPU: a default-path kernel whose instruction stream is IDENTICAL to the last
-GPU-verified revision needs no new verification; only the listed ones do (tools/r03_first_call.sh).
+GPU-verified revision needs no new verification; only the listed ones do.
 Objects go to q-diffusion_amd/build/isa_diff/ (git-ignored)."""
 import os
 import re
