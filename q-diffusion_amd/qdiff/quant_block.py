@@ -824,6 +824,9 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
         kterm = None
         if kv is not None:
             k8, v8, vsum, kterm = kv
+            if k8.shape[0] != B * h or v8.shape[0] != B * h:
+                # prepared / branch operands of another batch size (a prepared context handed to a latent batch it was not made for)
+                raise engine.hip.HipEngineError(f"cross-attention operands were prepared for {k8.shape[0] // h} samples, the latents have {B}")
 
         def operand(mod, codes, which, n_tok, buf):
             # projection -> attention operand bytes: inside the GEMM epilogue when the shape allows it, else

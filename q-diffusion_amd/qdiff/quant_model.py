@@ -251,7 +251,8 @@ class QuantModel(nn.Module):
         new context.  The captured HIP graph of a prepared evaluation reads the pinned buffers and survives re-preparation."""
         ctx = self.__dict__.get("_ctx_kv")
         if (ctx is None or not torch.is_tensor(context) or self._quant_state != (True, True) or torch.is_grad_enabled()
-                or engine.SIMULATE or self.model.training):
+                or engine.SIMULATE or self.model.training
+                or (context.is_cuda and torch.cuda.is_current_stream_capturing())):      # captured launches would not have run yet
             if ctx is not None:
                 ctx.unpin()
             return False

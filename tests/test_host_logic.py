@@ -536,6 +536,11 @@ def test_prepared_context_skips_the_chain_and_changes_nothing(emu, monkeypatch):
         monkeypatch.setattr(qb, "_CTX_PIN", False)
         assert qnn.prepare_context(c) is False
         monkeypatch.setattr(qb, "_CTX_PIN", True)
+        # a prepared context handed to a latent batch it was not made for is refused, not read out of bounds
+        assert qnn.prepare_context(c) is True
+        with pytest.raises(hip.HipEngineError):
+            qnn(torch.cat([x, x]), torch.cat([t, t]), c)
+        qnn.release_context()
         # the samplers announce the run's conditioning themselves
         table = sampling.StepTable(sampling.ldm_betas(0.00085, 0.0120), 4, eta=0.0)
         uc = torch.randn(c.shape, generator=g)
