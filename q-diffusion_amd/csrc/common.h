@@ -89,6 +89,24 @@ __device__ __forceinline__ void qd_st4h(__half* p, const v4f& v) {
     *reinterpret_cast<uint2*>(p) = u;
 }
 
+// eight halves (one 16-byte access) <-> two float quads: the 16-byte lanes of the fp16 activation stream
+__device__ __forceinline__ float2 qd_h2_to_f(int w) {
+    const unsigned u = (unsigned)w;
+    return __half22float2(*reinterpret_cast<const __half2*>(&u));
+}
+__device__ __forceinline__ void qd_h8_to_f(const v4i& u, v4f& lo, v4f& hi) {
+    const float2 a = qd_h2_to_f(u.x), b = qd_h2_to_f(u.y), c = qd_h2_to_f(u.z), d = qd_h2_to_f(u.w);
+    lo = v4f{a.x, a.y, b.x, b.y};
+    hi = v4f{c.x, c.y, d.x, d.y};
+}
+__device__ __forceinline__ void qd_ld8h(const __half* p, float (&v)[8]) {
+    const v4i u = *reinterpret_cast<const v4i*>(p);
+    v4f lo, hi;
+    qd_h8_to_f(u, lo, hi);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+}
+
 // 4 consecutive elements; `vec` = the caller proved 4-element alignment (one 16-/8-byte load)
 template <typename T>
 __device__ __forceinline__ void qd_ld4(const T* p, bool vec, float (&v)[4]) {

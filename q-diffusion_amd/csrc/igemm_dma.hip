@@ -153,8 +153,13 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
     constexpr int PER = NA + NBW;
     constexpr int WCOLS = 32 * NT;                // columns of one wave
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE + 2 * BM * 4 + 4 * BN * 4];
-    int* sRowB = reinterpret_cast<int*>(smem + 3 * STAGE);
+    // The epilogue re-uses the (dead) ring as per-wave transposition tiles + the GroupNorm partials behind them: 4 KB per wave,
+    // 8 KB for the fp16 stream (two MFMA tiles = 64 columns = one 128-byte line of halves per row, see the epilogue)
+    constexpr int TBW = (OUT == O_F16 && !BF) ? 8192 : 4096;
+    constexpr int EPI_BYTES = 4 * TBW + 4 * WCOLS * 8;
+    constexpr int RING = 3 * STAGE > EPI_BYTES ? 3 * STAGE : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RING + 2 * BM * 4 + 4 * BN * 4];
+    int* sRowB = reinterpret_cast<int*>(smem + RING);
     int* sAsum = sRowB + BM;
     // per-output-channel epilogue constants of the LAST segment, fetched at kernel start so that their
     // global-load latency overlaps the prologue DMA instead of serialising in front of the stores
@@ -547,9 +552,22 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
     // (lane = column, 16 rows per lane: conflict-free ds_write_b32), phase 2 reads it back row-major, 16 B per lane:
     // lane -> (row = pass*8 + lane/8, 4 columns from (lane%8)*4); zw * Asum uses the 24-bit multiplier (both factors
     // fit: |zw| <= 128, |Asum - kz| <= 2 * 128 * K < 2^23, checked on the host).
-    unsigned* tb = reinterpret_cast<unsigned*>(smem + wave * 4096);
+    unsigned* tb = reinterpret_cast<unsigned*>(smem + wave * TBW);
     const int rr0 = lane >> 3, c4 = (lane & 7) * 4;
     const int wcol0 = n0 + wn * WCOLS;                 // first global column of this wave
+
+    // Row terms of the zero-point algebra for one 32-row tile: the lane's 16 rows in the C layout are four runs of four
+    // consecutive rows (r = 4g + e <-> row 8g + e + 4*fhalf), i.e. four 16-byte LDS reads instead of sixteen 4-byte ones;
+    // kz * zw[n] moves into the per-channel constant (zc2 = zc - zw * kz), so an element costs one v_mad_i32_i24 and one
+    // subtraction: I = acc - zc2 - zw * Asum (same integers: the host bounds every term, nothing wraps).
+    auto row_terms = [&](int rbase, int (&as)[16]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const v4i t = *reinterpret_cast<const v4i*>(sAsum + rbase + 8 * g4 + 4 * fhalf);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) as[4 * g4 + e] = t[e];
+        }
+    };
 
     if constexpr (OUT == O_GEGLU) {
         // weight rows were packed (value tile, gate tile) interleaved: tiles 2jp / 2jp+1 of this lane hold the value
@@ -623,7 +641,8 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
         for (int j = 0; j < NT; ++j) {
             const int cl = wn * WCOLS + j * 32 + frow;
             const float sc = sScale[cl];
-            const int zc_n = sZc[cl], zw_n = sZw[cl];
+            const int zw_n = sZw[cl];
+            const int zc2 = sZc[cl] - zw_n * kz;
             const float bias_n = sBias[cl];
             const int n4 = wcol0 + j * 32 + c4;        // first of this lane's 4 columns in phase 2
             const bool nok = n4 < p.Cout;
@@ -633,10 +652,12 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int rbase = wrow0 + i * 32;
+                int as[16];
+                row_terms(rbase, as);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rl = crow(r) + 4 * fhalf;
-                    const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rbase + rl] - kz);
+                    const int I = acc[i][j][r] - zc2 - __mul24(zw_n, as[r]);
                     tb[rl * 32 + frow] = __float_as_uint((float)I * sc + bias_n);
                 }
                 v4f rs[4];
@@ -739,12 +760,12 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
     // pass over HBM): per-column partials of the lane's rows -> butterfly over the 8 lanes that share the columns ->
     // fixed-order LDS reduction over the waves of each 128-row chunk -> one {sum, sumsq} pair per (chunk, channel).
     const bool gn = (OUT == O_F32 || OUT == O_F16 || OUT == O_BF16) && p.gnpart != nullptr;   // statistics of the fp32 values (before a 16-bit store)
-    float* sGn = reinterpret_cast<float*>(smem + 4 * 4096);       // [4 waves][WCOLS][2], behind the transposition tiles
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
+    float* sGn = reinterpret_cast<float*>(smem + 4 * TBW);        // [4 waves][WCOLS][2], behind the transposition tiles
+    auto single = [&](const int j) __attribute__((always_inline)) {
         const int cl = wn * WCOLS + j * 32 + frow;
         const float sc = sScale[cl];
-        const int zc_n = sZc[cl], zw_n = sZw[cl];
+        const int zw_n = sZw[cl];
+        const int zc2 = sZc[cl] - zw_n * kz;
         const float bias_n = sBias[cl];
         const int n4 = wcol0 + j * 32 + c4;            // this lane's 4 columns in phase 2
         const bool nok4 = n4 + 3 < p.Cout;             // all four exist (the vector path); else per element
@@ -754,17 +775,19 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
         for (int i = 0; i < MT; ++i) {
             const int rbase = wrow0 + i * 32;
             // phase 1: dequantise in the C layout, park the tile in LDS
+            int as[16];
+            if constexpr (!BF) row_terms(rbase, as);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = crow(r) + 4 * fhalf;
                 if constexpr (INT_OUT) {
-                    const int v = OUT == O_PART ? (int)acc[i][j][r] - __mul24(zw_n, sAsum[rbase + rl])
-                                                : (int)acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rbase + rl] - kz);
+                    const int v = OUT == O_PART ? (int)acc[i][j][r] - __mul24(zw_n, as[r])
+                                                : (int)acc[i][j][r] - zc2 - __mul24(zw_n, as[r]);
                     tb[rl * 32 + frow] = (unsigned)v;
                 } else if constexpr (BF) {
                     tb[rl * 32 + frow] = __float_as_uint((float)acc[i][j][r] + bias_n);
                 } else {
-                    const int I = acc[i][j][r] - zc_n - __mul24(zw_n, sAsum[rbase + rl] - kz);
+                    const int I = acc[i][j][r] - zc2 - __mul24(zw_n, as[r]);
                     float v = (float)I * sc;
                     if (SPLIT) v += facc[SPLIT ? i : 0][SPLIT ? j : 0][r];
                     tb[rl * 32 + frow] = __float_as_uint(v + bias_n);
@@ -883,6 +906,150 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
                 }
             }
         }
+    };
+    // fp16 stream with 8-element-aligned rows (p.vec == 2): TWO MFMA tiles per transposition, i.e. 64 columns = one 128-byte
+    // line of halves per row, and 16 bytes (8 halves) per lane in phase 2 — a store instruction writes eight FULL lines
+    // (1 KB) where the 4-halves-per-lane form writes eight half lines: the store path is paced per request, not per byte
+    // (profiles/r03_igemm_phase_ablation.md), so the half-line form moved half the bytes of the fp32 stream at the fp32
+    // stream's speed.  LDS tile: [32 rows][64 dwords]; a ds_read_b128 group of 16 lanes covers rows (0, 1, 2, 3) x 4 chunks,
+    // so the 16-byte chunk index is XOR-ed with (row & 1): conflict-free reads, and the ds_write_b32 side stays a
+    // permutation of 32 consecutive banks.  Lane -> (row, columns) is the 4-wide form's (row = pass*8 + lane/8), so every
+    // column's GroupNorm partial sum runs over the same rows in the same order: the statistics are bit-identical.
+    auto pair = [&](const int j) __attribute__((always_inline)) {
+        if constexpr (H16_OUT && !BF) {
+        const int cl0 = wn * WCOLS + j * 32 + frow, cl1 = cl0 + 32;
+        const float sc0 = sScale[cl0], sc1 = sScale[cl1];
+        const int zw0 = sZw[cl0], zw1 = sZw[cl1];
+        const int zc0 = sZc[cl0] - zw0 * kz, zc1 = sZc[cl1] - zw1 * kz;
+        const float bias0 = sBias[cl0], bias1 = sBias[cl1];
+        const int k8 = lane & 7, sw = (lane >> 3) & 1;
+        const int n8 = wcol0 + j * 32 + k8 * 8;        // this lane's 8 columns in phase 2
+        const bool nok8 = n8 < p.Cout;                 // Cout % 8 == 0 (host): all eight exist or none
+        const int n8c = nok8 ? n8 : 0;
+        const int rd_lo = ((2 * k8) ^ sw) * 4, rd_hi = ((2 * k8 + 1) ^ sw) * 4;
+        // the row bias (one row per SAMPLE: the timestep-embedding projection) joins in phase 1 when a 32-row tile cannot
+        // straddle two samples: one scalar per lane per tile instead of eight floats per lane per pass; same float order
+        // ((I*scale + bias) + rowbias, then + residual) as the per-row form
+        const bool rb_tile = has_rb && (HoWo & 31) == 0;
+        const int nc0 = wcol0 + j * 32 + frow, nc1 = nc0 + 32;          // this lane's column in phase 1 (clamped for the load)
+        const float* rbp0 = p.rowbias + (nc0 < p.Cout ? nc0 : 0);
+        const float* rbp1 = p.rowbias + (nc1 < p.Cout ? nc1 : 0);
+        float gs[8], gq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int rbase = wrow0 + i * 32;
+            __builtin_amdgcn_sched_barrier(0);         // a tile pair's work stays together: hoisting the next pair's dequantisation above this
+                                                       // pair's row-major pass costs 32 more live registers (the MT = 2 tiles spill)
+            float rbv0 = 0.f, rbv1 = 0.f;
+            if (rb_tile) {
+                const long ro = (long)sRowB[rbase] * p.ldrb;
+                rbv0 = rbp0[ro];
+                rbv1 = rbp1[ro];
+            }
+            int as[16];
+            row_terms(rbase, as);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = crow(r) + 4 * fhalf;
+                const int I0 = acc[i][j][r] - zc0 - __mul24(zw0, as[r]);
+                const int I1 = acc[i][j + 1][r] - zc1 - __mul24(zw1, as[r]);
+                float v0 = (float)I0 * sc0, v1 = (float)I1 * sc1;
+                if (SPLIT) {
+                    v0 += facc[SPLIT ? i : 0][SPLIT ? j : 0][r];
+                    v1 += facc[SPLIT ? i : 0][SPLIT ? j + 1 : 0][r];
+                }
+                v0 += bias0;
+                v1 += bias1;
+                if (rb_tile) { v0 += rbv0; v1 += rbv1; }
+                const int pc = frow ^ ((r & 1) << 2);  // (row & 1) == (r & 1) in the C layout
+                tb[rl * 64 + pc] = __float_as_uint(v0);
+                tb[rl * 64 + 32 + pc] = __float_as_uint(v1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            v4i rs[4];
+            long mrow[4];
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const long m = m0 + rbase + ps * 8 + rr0;
+                mrow[ps] = m < p.M ? m : m0;
+                if (has_res) rs[ps] = *reinterpret_cast<const v4i*>(rh + mrow[ps] * p.ldr + n8c);
+            }
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int rl = ps * 8 + rr0;
+                const bool mok = m0 + rbase + rl < p.M;
+                v4f lo = *reinterpret_cast<const v4f*>(tb + rl * 64 + rd_lo);
+                v4f hi = *reinterpret_cast<const v4f*>(tb + rl * 64 + rd_hi);
+                if (has_rb && !rb_tile) {
+                    const float* src = p.rowbias + (long)sRowB[rbase + rl] * p.ldrb + n8c;
+                    lo += *reinterpret_cast<const v4f*>(src);
+                    hi += *reinterpret_cast<const v4f*>(src + 4);
+                }
+                if (has_res) {
+                    v4f a, b;
+                    qd_h8_to_f(rs[ps], a, b);
+                    lo += a; hi += b;
+                }
+                if (mok && nok8) {
+                    const v4i pk = {(int)qd_pack2h(lo[0], lo[1]), (int)qd_pack2h(lo[2], lo[3]),
+                                    (int)qd_pack2h(hi[0], hi[1]), (int)qd_pack2h(hi[2], hi[3])};
+                    *reinterpret_cast<v4i*>(oh + mrow[ps] * p.ldo + n8) = pk;
+                    if (gn) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            gs[e] += lo[e]; gq[e] += lo[e] * lo[e];
+                            gs[4 + e] += hi[e]; gq[4 + e] += hi[e] * hi[e];
+                        }
+                    }
+                }
+            }
+        }
+        if (gn) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int sh = 8; sh < 64; sh <<= 1) {
+                    gs[e] += __shfl_xor(gs[e], sh);
+                    gq[e] += __shfl_xor(gq[e], sh);
+                }
+            }
+            if (lane < 8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sGn[(wave * WCOLS + j * 32 + k8 * 8 + e) * 2] = gs[e];
+                    sGn[(wave * WCOLS + j * 32 + k8 * 8 + e) * 2 + 1] = gq[e];
+                }
+            }
+        }
+        }
+    };
+    bool lines16 = false;
+    if constexpr (H16_OUT && !BF) lines16 = p.vec == 2;
+    if (lines16) {
+        // tile 0 of this wave starts in the UPPER half of a 128-byte line (n0 / the wave's column offset is an odd multiple
+        // of 32 columns: every other block of the 160-wide tiles, wave column 1 of the 128 x 320 tile): it goes alone and
+        // the pairs start at tile 1, so that every pair is one aligned line (row strides are multiples of 64 columns for
+        // every SD width; where they are not — 224-wide LDM rows — pairs are still 128 contiguous bytes)
+#ifdef QD_F16_NOODD           // measurement-only build: pairs always start at tile 0 (half of the code, pairs of odd blocks straddle two lines)
+        const bool odd = false;
+#else
+        const bool odd = __builtin_amdgcn_readfirstlane((int)((reinterpret_cast<uintptr_t>(oh + (long)m0 * p.ldo + wcol0) >> 6) & 1)) != 0;
+#endif
+        if (odd) {
+            single(0);
+#pragma unroll
+            for (int q = 0; q < (NT - 1) / 2; ++q) pair(1 + 2 * q);
+            if constexpr ((NT - 1) % 2 == 1) single(NT - 1);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NT / 2; ++q) pair(2 * q);
+            if constexpr (NT % 2 == 1) single(NT - 1);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) single(j);
     }
     if (gn) {
         __syncthreads();
@@ -989,6 +1156,42 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const int32_t* __r
     }
 }
 
+// the same pass for fp16 rows with 8-element-aligned strides: thread = 8 consecutive outputs of one row (two 16-byte loads per
+// slice, one 16-byte store instead of eight 2-byte ones).  Same integer sum, same float sequence per element.
+__global__ __launch_bounds__(256) void splitk_finalize_h8_kernel(const int32_t* __restrict__ part, int nsplit, long MN, int Cout, int HoWo,
+                                                                 const float* __restrict__ scale, const int* __restrict__ zc,
+                                                                 const int* __restrict__ zw, const int* __restrict__ zfill,
+                                                                 const float* __restrict__ bias, const float* __restrict__ rowbias, long ldrb,
+                                                                 const __half* __restrict__ residual, long ldr, __half* __restrict__ out, long ldo) {
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (e >= MN) return;
+    const long m = e / Cout;
+    const int  n = (int)(e - m * Cout);
+    int I[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < nsplit; ++s) {
+        const v4i a = *reinterpret_cast<const v4i*>(part + (long)s * MN + e), b = *reinterpret_cast<const v4i*>(part + (long)s * MN + e + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { I[j] += a[j]; I[4 + j] += b[j]; }
+    }
+    const int kz = zfill ? zfill[1] : 0;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int Ij = I[j] - (zc ? zc[n + j] : 0) + (zw ? zw[n + j] : 0) * kz;
+        v[j] = (float)Ij * scale[n + j];
+        v[j] += bias ? bias[n + j] : 0.f;
+        if (rowbias) v[j] += rowbias[(m / HoWo) * ldrb + n + j];
+    }
+    if (residual) {
+        float r[8];
+        qd_ld8h(residual + m * ldr + n, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += r[j];
+    }
+    const v4i pk = {(int)qd_pack2h(v[0], v[1]), (int)qd_pack2h(v[2], v[3]), (int)qd_pack2h(v[4], v[5]), (int)qd_pack2h(v[6], v[7])};
+    *reinterpret_cast<v4i*>(out + m * ldo + n) = pk;
+}
+
 // tile-ordered s8 packer: thread = one 16-byte unit (row n, 16 consecutive K), stored byte = W - 128
 __global__ __launch_bounds__(256) void pack_t8_kernel(const float* __restrict__ w, const float* __restrict__ alpha,
                                                       const float* __restrict__ delta, const float* __restrict__ zp,
@@ -1036,6 +1239,12 @@ __global__ __launch_bounds__(256) void pack_t8_kernel(const float* __restrict__ 
     if (wsum && sum != 0) atomicAdd(&wsum[n], sum);
 }
 
+#ifdef QD_PROBE_INSTANCE
+// measurement / inspection builds (tools/kernel_resources.py --probe): ONE instantiation of the kernel, nothing else — seconds
+// instead of minutes per compile when the shared body is being edited.  -DQD_PROBE_INSTANCE="2,5,2,2,false,1,4"
+template __global__ void igemm_kernel<QD_PROBE_INSTANCE>(const ConvD);
+}  // namespace
+#else
 // tile shapes (MT, NT, WM, WN): block = (32*MT*WM) x (32*NT*WN)
 template <int MT, int NT, int WM, int WN, int WB = 4>
 int dispatch(ConvD& k, bool split, int out, hipStream_t st, int nsplit = 1) {
@@ -1135,6 +1344,12 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
                                       : (d->ldo % 4 == 0 && qd_aligned(d->out, 4 * esz) &&
                                          (!d->residual || (d->ldr % 4 == 0 && qd_aligned(d->residual, 4 * esz))) &&
                                          (!d->rowbias || (d->ld_rowbias % 4 == 0 && qd_aligned(d->rowbias, 16)))));
+    // fp16 rows whose every access may also be a 16-byte (8-half) vector: the full-line epilogue (two MFMA tiles per
+    // transposition, see the kernel); QD_F16_LINES=0 keeps the 4-halves-per-lane form (A/B knob)
+    static const bool f16_lines = !(getenv("QD_F16_LINES") && atoi(getenv("QD_F16_LINES")) == 0);
+    if (k.vec && f16_lines && !iout && d->out_dtype == QD_F16 && d->Cout % 8 == 0 && d->ldo % 8 == 0 && qd_aligned(d->out, 16) &&
+        (!d->residual || (d->ldr % 8 == 0 && qd_aligned(d->residual, 16))))
+        k.vec = 2;
     if (heads) {
         QD_REQUIRE(!iout && d->nseg == 1 && d->oq_params && d->out, "qd_conv2d_i8: heads epilogue needs one segment, oq_params and out");
         QD_REQUIRE(d->oq_max - d->oq_off <= 127 && d->oq_min - d->oq_off >= -128, "qd_conv2d_i8: heads output grid does not fit int8");
@@ -1191,7 +1406,11 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
         const SegD& sg = k.seg[0];
         const long MN = M * N;
         dim3 grid((unsigned)((MN + 255) / 256)), block(256);
-        if (d->out_dtype == QD_F16)
+        if (d->out_dtype == QD_F16 && f16_lines && N % 8 == 0 && d->ldo % 8 == 0 && qd_aligned(k.out, 16) &&
+            (!k.residual || (d->ldr % 8 == 0 && qd_aligned(k.residual, 16))))
+            hipLaunchKernelGGL(splitk_finalize_h8_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), block, 0, st, k.iout, nsplit, MN, N, d->Ho * d->Wo, sg.scale, sg.zc, sg.zw,
+                               sg.zfill, k.bias, k.rowbias, k.ldrb, (const __half*)k.residual, k.ldr, (__half*)k.out, k.ldo);
+        else if (d->out_dtype == QD_F16)
             hipLaunchKernelGGL(splitk_finalize_kernel<__half>, grid, block, 0, st, k.iout, nsplit, MN, N, d->Ho * d->Wo, sg.scale, sg.zc, sg.zw,
                                sg.zfill, k.bias, k.rowbias, k.ldrb, (const __half*)k.residual, k.ldr, (__half*)k.out, k.ldo);
         else
@@ -1409,3 +1628,4 @@ extern "C" int qd_pack_weights_t8(const float* w, const float* alpha, const floa
     QD_LAUNCH_CHECK("qd_pack_weights_t8");
     return 0;
 }
+#endif  // QD_PROBE_INSTANCE

@@ -40,6 +40,34 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
     }
 }
 
+// fp16 stream: thread owns 8 consecutive channels (one 16-byte load per row).  Every channel's sum runs over the same rows in
+// the same order as in the 4-channel form: bit-identical partials.
+__global__ __launch_bounds__(256) void gn_partial_h8_kernel(const __half* __restrict__ x, long S, int C, long ldx,
+                                                            float* __restrict__ part, int nchunk) {
+    const int chunk = blockIdx.x;
+    const long b = blockIdx.y;
+    const int rows = gn_rows(S);
+    const long r0 = (long)chunk * rows;
+    const long r1 = (r0 + rows < S) ? r0 + rows : S;
+    for (int c8 = threadIdx.x; c8 < C / 8; c8 += 256) {
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const __half* p = x + (b * S + r0) * ldx + c8 * 8;
+#pragma unroll 4
+        for (long r = r0; r < r1; ++r, p += ldx) {
+            float v[8];
+            qd_ld8h(p, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s[j] += v[j];
+                q[j] += v[j] * v[j];
+            }
+        }
+        float* dst = part + (((b * nchunk + chunk) * (long)C) + c8 * 8) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(dst + 4 * j) = make_float4(s[2 * j], q[2 * j], s[2 * j + 1], q[2 * j + 1]);
+    }
+}
+
 // finalize: grid (groups, B), 64 threads.  Writes per-(b,c) affine a = rstd*gamma, sh = beta - mean*a.
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, int nchunk, long ldp, long S, int C,
                                                          int groups, float eps, const float* __restrict__ gamma,
@@ -256,6 +284,73 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const float* __restr
     }
 }
 
+// The same pass for the fp16 activation stream: thread = 8 consecutive channels (ONE 16-byte load per row — the 4-channel form
+// reads 8 bytes per lane: half lines, the same request count as the fp32 stream) of U rows, 8 code bytes out per row.  Same
+// arithmetic per element, so the codes are those of gn_apply_kernel<__half> bit for bit.
+template <int U>
+__global__ __launch_bounds__(256) void gn_apply_rows_h8_kernel(const __half* __restrict__ x, long rows, long S, int C, long ldx,
+                                                               const float* __restrict__ ab, int apply_silu,
+                                                               const float* __restrict__ qp, float qmin, float qmax, int off,
+                                                               int8_t* __restrict__ out, long ldo, const RawQ raw) {
+    const int chunks = C >> 3;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (rows / U) * chunks) return;
+    const long rg = gid / chunks;
+    const int c = (int)(gid - rg * chunks) * 8;
+    const long row0 = rg * U;
+    const long b = row0 / S;
+    v4i xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const v4i*>(x + (row0 + u) * ldx + c);
+    float a8[8], s8[8];
+    const float* abp = ab + (b * C + c) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 t = *reinterpret_cast<const float4*>(abp + 4 * j);
+        a8[2 * j] = t.x; s8[2 * j] = t.y; a8[2 * j + 1] = t.z; s8[2 * j + 1] = t.w;
+    }
+    const QP q = qd_load_qp(qp);
+    // segment bounds are multiples of 16 channels (host): a lane's 8 channels share a segment
+    const bool s1 = raw.out && raw.nseg > 1 && c >= raw.c0[1];
+    const int rc0 = s1 ? raw.c0[1] : raw.c0[0], rlen = s1 ? raw.clen[1] : raw.clen[0], roc0 = s1 ? raw.oc0[1] : raw.oc0[0];
+    const bool rawhere = raw.out && c >= rc0 && c < rc0 + rlen;
+    QP rq{1.f, 0.f, 1.f, false};
+    if (rawhere) rq = qd_load_qp(s1 ? raw.qp[1] : raw.qp[0]);
+    const float rmin = s1 ? raw.qmin[1] : raw.qmin[0], rmax = s1 ? raw.qmax[1] : raw.qmax[0];
+    const int roff = s1 ? raw.off[1] : raw.off[0];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        v4f lo, hi;
+        qd_h8_to_f(xv[u], lo, hi);
+        const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const long row = row0 + u;
+        unsigned w0 = 0, w1 = 0;
+        auto body = [&](auto ft) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float y = v[j] * a8[j] + s8[j];
+                if (apply_silu) y = y * (1.0f / (1.0f + expf(-y)));
+                const unsigned cb = (unsigned)((qd_code_t<decltype(ft)::value>(y, q, qmin, qmax) - off) & 0xff) << (8 * (j & 3));
+                if (j < 4) w0 |= cb; else w1 |= cb;
+            }
+        };
+        QD_FAST_DISPATCH(q.fast, body);
+        *reinterpret_cast<uint2*>(out + row * ldo + c) = make_uint2(w0, w1);
+        if (rawhere) {
+            unsigned r0 = 0, r1 = 0;
+            auto rbody = [&](auto ft) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned cb = (unsigned)((qd_code_t<decltype(ft)::value>(v[j], rq, rmin, rmax) - roff) & 0xff) << (8 * (j & 3));
+                    if (j < 4) r0 |= cb; else r1 |= cb;
+                }
+            };
+            QD_FAST_DISPATCH(rq.fast, rbody);
+            *reinterpret_cast<uint2*>(raw.out + row * raw.ldo + roc0 + (c - rc0)) = make_uint2(r0, r1);
+        }
+    }
+}
+
 // LayerNorm: one wave per row, row held in registers (C <= 64*4*MAXV).
 constexpr int LN_MAXV = 6;  // up to 1536 channels
 // NV = float4 chunks per lane (ceil(C/256)), RPW = rows per wave: the loads of RPW rows are issued back to
@@ -353,6 +448,114 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(const T* __restrict__ x, 
     }
     };
     QD_FAST_DISPATCH(qa.fast && (nout < 2 || qb.fast) && (nout < 3 || qc.fast), lnbody);
+}
+
+// fp16 stream: lane = 8 consecutive channels per chunk (one 16-byte load; 8 code bytes per output), NV = chunks per lane
+// (ceil(C / 512)).  Same two-pass statistics per row (sum -> mean, sum of squared deviations -> rstd) with wave butterflies.
+template <int NV, int RPW>
+__global__ __launch_bounds__(256) void ln_quant_h8_kernel(const __half* __restrict__ x, long M, int C, long ldx, float eps,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          int nout, const float* qp0, const float* qp1, const float* qp2,
+                                                          float3 qmin, float3 qmax, int3 off, int8_t* o0, int8_t* o1,
+                                                          int8_t* o2, long ldo) {
+    const int lane = threadIdx.x & 63;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= M) return;
+    const int nv = C >> 3;
+    float v[RPW][NV][8];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const long row = row0 + r < M ? row0 + r : M - 1;
+        const __half* src = x + row * ldx;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int idx = lane + 64 * k;
+            if (idx < nv) qd_ld8h(src + idx * 8, v[r][k]);
+        }
+    }
+    float g[NV][8], bt[NV][8];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = lane + 64 * k;
+        if (idx < nv) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 a = *reinterpret_cast<const float4*>(gamma + idx * 8 + 4 * h), b = *reinterpret_cast<const float4*>(beta + idx * 8 + 4 * h);
+                g[k][4 * h] = a.x; g[k][4 * h + 1] = a.y; g[k][4 * h + 2] = a.z; g[k][4 * h + 3] = a.w;
+                bt[k][4 * h] = b.x; bt[k][4 * h + 1] = b.y; bt[k][4 * h + 2] = b.z; bt[k][4 * h + 3] = b.w;
+            }
+        }
+    }
+    float s[RPW], q[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        s[r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            if (lane + 64 * k < nv) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[r] += v[r][k][j];
+            }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) s[r] += __shfl_xor(s[r], o);
+    float mean[RPW], rstd[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        mean[r] = s[r] / (float)C;
+        q[r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            if (lane + 64 * k < nv) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[r][k][j] - mean[r]; q[r] += d * d; }
+            }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) q[r] += __shfl_xor(q[r], o);
+    const QP qa = qd_load_qp(qp0);
+    const QP qb = nout > 1 ? qd_load_qp(qp1) : QP{1.f, 0.f, 1.f, false};
+    const QP qc = nout > 2 ? qd_load_qp(qp2) : QP{1.f, 0.f, 1.f, false};
+    auto lnbody = [&](auto ft) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(ft)::value;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        rstd[r] = 1.0f / sqrtf(q[r] / (float)C + eps);
+        const long row = row0 + r;
+        if (row >= M) continue;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int idx = lane + 64 * k;
+            if (idx < nv) {
+                unsigned u0[2] = {0, 0}, u1[2] = {0, 0}, u2[2] = {0, 0};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y = (v[r][k][j] - mean[r]) * rstd[r] * g[k][j] + bt[k][j];
+                    u0[j >> 2] |= (unsigned)((qd_code_t<FAST>(y, qa, qmin.x, qmax.x) - off.x) & 0xff) << (8 * (j & 3));
+                    if (nout > 1) u1[j >> 2] |= (unsigned)((qd_code_t<FAST>(y, qb, qmin.y, qmax.y) - off.y) & 0xff) << (8 * (j & 3));
+                    if (nout > 2) u2[j >> 2] |= (unsigned)((qd_code_t<FAST>(y, qc, qmin.z, qmax.z) - off.z) & 0xff) << (8 * (j & 3));
+                }
+                *reinterpret_cast<uint2*>(o0 + row * ldo + idx * 8) = make_uint2(u0[0], u0[1]);
+                if (nout > 1) *reinterpret_cast<uint2*>(o1 + row * ldo + idx * 8) = make_uint2(u1[0], u1[1]);
+                if (nout > 2) *reinterpret_cast<uint2*>(o2 + row * ldo + idx * 8) = make_uint2(u2[0], u2[1]);
+            }
+        }
+    }
+    };
+    QD_FAST_DISPATCH(qa.fast && (nout < 2 || qb.fast) && (nout < 3 || qc.fast), lnbody);
+}
+
+template <int NV>
+void launch_ln_h8(hipStream_t st, const void* x, long M, int C, long ldx, float eps, const float* gamma, const float* beta, int nout,
+                  const float* const* qp, float3 mn, float3 mx, int3 of, int8_t* const* o, long ldo) {
+    constexpr int RPW = NV <= 2 ? 2 : 1;
+    dim3 grid((unsigned)((M + 4 * RPW - 1) / (4 * RPW)));
+    hipLaunchKernelGGL((ln_quant_h8_kernel<NV, RPW>), grid, dim3(256), 0, st, (const __half*)x, M, C, ldx, eps, gamma, beta, nout, qp[0], qp[1],
+                       qp[2], mn, mx, of, o[0], o[1], o[2], ldo);
 }
 
 template <typename T, int NV>
@@ -471,6 +674,9 @@ static int groupnorm_impl(const void* x, int x_dtype, int64_t B, int64_t S, int 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nchunk_own = (int)((S + gn_rows(S) - 1) / gn_rows(S));
     const int vec = qd_aligned(x, x_dtype == QD_F32 ? 16 : 8) && ldx % 4 == 0;
+    // fp16 rows that take 16-byte (8-half) lanes; QD_F16_LINES=0 keeps the 4-halves-per-lane kernels (A/B knob)
+    static const bool f16_lines = !(getenv("QD_F16_LINES") && atoi(getenv("QD_F16_LINES")) == 0);
+    const bool vec8 = f16_lines && x_dtype == QD_F16 && qd_aligned(x, 16) && ldx % 8 == 0;      // C % 16 == 0 is required above
     float* part = reinterpret_cast<float*>(ws);
     float* ab = part + (size_t)B * nchunk_own * C * 2;
     QD_REQUIRE(!part_in || (nchunk_in > 0 && (part_ld == 0 || part_ld >= C)), "qd_groupnorm_silu_quant: part_in needs nchunk_in > 0 and part_ld >= C");
@@ -480,6 +686,8 @@ static int groupnorm_impl(const void* x, int x_dtype, int64_t B, int64_t S, int 
         // first statistics level came with the tensor (written by the producing GEMM's epilogue)
     } else if (x_dtype == QD_F32)
         hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, (const float*)x, (long)S, C, (long)ldx, part, nchunk, vec);
+    else if (vec8)
+        hipLaunchKernelGGL(gn_partial_h8_kernel, dim3(nchunk, (unsigned)B), dim3(256), 0, st, (const __half*)x, (long)S, C, (long)ldx, part, nchunk);
     else
         hipLaunchKernelGGL(gn_partial_kernel<__half>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, (const __half*)x, (long)S, C, (long)ldx, part, nchunk, vec);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, (unsigned)B), dim3(64), 0, st, part_in ? part_in : part, nchunk, ldp, (long)S, C, groups, eps, gamma, beta, ab);
@@ -513,6 +721,13 @@ static int groupnorm_impl(const void* x, int x_dtype, int64_t B, int64_t S, int 
             hipLaunchKernelGGL(gn_apply_rows_kernel<2>, g2, dim3(256), 0, st, (const float*)x, rows, (long)S, C, (long)ldx, ab, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, rq);
         else
             hipLaunchKernelGGL(gn_apply_rows_kernel<4>, g2, dim3(256), 0, st, (const float*)x, rows, (long)S, C, (long)ldx, ab, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, rq);
+        QD_LAUNCH_CHECK("qd_groupnorm_silu_quant");
+        return 0;
+    }
+    if (vec8 && out && !yout && S % 2 == 0) {
+        const long tot = (rows / 2) * (C / 8);
+        hipLaunchKernelGGL(gn_apply_rows_h8_kernel<2>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const __half*)x, rows, (long)S, C, (long)ldx, ab, apply_silu,
+                           qparams, (float)qmin, (float)qmax, off, out, (long)ldo, rq);
         QD_LAUNCH_CHECK("qd_groupnorm_silu_quant");
         return 0;
     }
@@ -568,7 +783,13 @@ extern "C" int qd_layernorm_quant(const void* x, int x_dtype, int64_t M, int C, 
     const int vec = qd_aligned(x, x_dtype == QD_F32 ? 16 : 8) && ldx % 4 == 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nvl = (C / 4 + 63) / 64;
-    if (x_dtype == QD_F32) dispatch_ln<float>(nvl, st, x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, (long)ldo, vec);
+    static const bool f16_lines = !(getenv("QD_F16_LINES") && atoi(getenv("QD_F16_LINES")) == 0);
+    if (f16_lines && x_dtype == QD_F16 && qd_aligned(x, 16) && ldx % 8 == 0 && C % 8 == 0 && C <= 64 * 8 * 3) {
+        const int nv8 = (C / 8 + 63) / 64;
+        if (nv8 == 1) launch_ln_h8<1>(st, x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, (long)ldo);
+        else if (nv8 == 2) launch_ln_h8<2>(st, x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, (long)ldo);
+        else launch_ln_h8<3>(st, x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, (long)ldo);
+    } else if (x_dtype == QD_F32) dispatch_ln<float>(nvl, st, x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, (long)ldo, vec);
     else dispatch_ln<__half>(nvl, st, x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, (long)ldo, vec);
     QD_LAUNCH_CHECK("qd_layernorm_quant");
     return 0;

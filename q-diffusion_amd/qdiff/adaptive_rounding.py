@@ -19,6 +19,22 @@ logger = logging.getLogger(__name__)
 
 
 class AdaRoundQuantizer(nn.Module):
+    # see UniformAffineQuantizer._STATE_ATTRS (resume_cali_model re-attaches delta / zero_point as plain tensors, reference
+    # utils.py:409-417: QuantModel's packed weights, HIP graphs and prepared contexts must notice)
+    _STATE_ATTRS = frozenset(("alpha", "delta", "zero_point", "soft_targets", "round_mode", "n_bits", "n_levels", "sym"))
+
+    def __setattr__(self, name, value):
+        if name in self._STATE_ATTRS:
+            from . import engine
+            engine.bump_state()
+        super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        if name in self._STATE_ATTRS:
+            from . import engine
+            engine.bump_state()
+        super().__delattr__(name)
+
     def __init__(self, uaq: UniformAffineQuantizer, weight_tensor: torch.Tensor, round_mode='learned_round_sigmoid'):
         super().__init__()
         # inherit the uniform quantiser's grid

@@ -80,6 +80,16 @@ def check_act_zero_point(quantizer, grid):
                                  "byte zp - off does not fit int8 (set qdiff.engine.SIMULATE = True for the fp32 simulation)")
 
 
+def tensor_version(t):
+    """In-place version counter of a tensor, or None for an inference tensor (created under torch.inference_mode(): it has no
+    counter — `t._version` raises — and may change in place without a trace, so nothing may rely on identity + version for it;
+    callers compare such tensors by value or treat them as unseen)."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
 def quantizer_key(q):
     """Cheap identity of a quantiser's state: changes whenever delta / zero_point / alpha are
     re-assigned or modified in place (resume_cali_model does both: reference utils.py:397-457)."""
@@ -88,7 +98,7 @@ def quantizer_key(q):
 
     def one(v):
         if torch.is_tensor(v):
-            return (id(v), v._version, v.data_ptr())
+            return (id(v), tensor_version(v), v.data_ptr())
         return v
     return (id(q), one(getattr(q, "delta", None)), one(getattr(q, "zero_point", None)),
             one(getattr(q, "alpha", None)), getattr(q, "n_bits", None), getattr(q, "sym", None))

@@ -31,7 +31,10 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import hip
+from . import engine, hip
+import logging
+
+logger = logging.getLogger(__name__)
 
 # QDIFF_DECODER_GRAPH=1: replay the ~150 launches of a decode as ONE HIP graph per (latent shape, weights) instead of issuing
 # them one by one.  Off by default: measured no gain (3.97 ms vs 3.99 ms per image, gpurun_out/r04_c6: the decode is
@@ -78,7 +81,7 @@ class HipDecoder:
     # ---- weights ----
     @staticmethod
     def _stamp(*params):
-        return tuple((id(p), p._version, p.data_ptr()) for p in params if p is not None)
+        return tuple((id(p), engine.tensor_version(p), p.data_ptr()) for p in params if p is not None)
 
     def _conv(self, dev, key, mod):
         p = self._packs.get((dev, key))
@@ -172,14 +175,18 @@ class HipDecoder:
         B, zc, H, W = z.shape
         from .arch.first_stage import largest_activation_bytes
         if B * largest_activation_bytes(d, H, W) >= 1 << 32:      # fp32 bytes of the largest tensor of the walk (the last up-sampling level)
-            raise hip.HipEngineError("HipDecoder: batch too large for 32-bit row offsets; decode in chunks (decode_first_stage does)")
+            raise HipBatchTooLarge("HipDecoder: batch too large for 32-bit row offsets; decode in chunks (decode_first_stage does)")
         cin = self._conv(dev, "conv_in", d.conv_in)
         x0 = torch.zeros((B * H * W, cin.cin_pad), dtype=self.dtype, device=dev)
         x0[:, :zc] = z.permute(0, 2, 3, 1).reshape(B * H * W, zc)
         h, part = self._run_conv(cin, x0, B, H, W)
         h, part = self._resblock("mid.block_1", d.mid.block_1, h, part, B, H, W)
-        if hasattr(d.mid.attn_1, "proj_out"):
-            h, part = self._attn("mid.attn_1", d.mid.attn_1, h, part, B, H, W)
+        a1 = d.mid.attn_1
+        if all(hasattr(a1, n) for n in ("q", "k", "v", "proj_out", "norm")):      # AttnBlock (attn_type "vanilla")
+            h, part = self._attn("mid.attn_1", a1, h, part, B, H, W)
+        elif not isinstance(a1, torch.nn.Identity):                                # attn_type "none" is nn.Identity; anything else
+            raise hip.HipEngineError(f"HipDecoder: mid-block attention {type(a1).__name__} has no kernel here "
+                                     "(only AttnBlock / Identity, reference model.py:139-150)")
         h, part = self._resblock("mid.block_2", d.mid.block_2, h, part, B, H, W)
         for i_level in reversed(range(d.num_resolutions)):
             stage = d.up[i_level]
@@ -214,8 +221,19 @@ def hip_decoder(decoder, dtype=None):
 # ------------------------------------------------------------------------------------------------
 # the reference's own Decoder class (drop-in use inside the q-diffusion source tree)
 # ------------------------------------------------------------------------------------------------
-# QDIFF_ADOPT_DECODER=0: leave the reference's `Decoder.forward` alone
-ADOPT_DECODER = os.environ.get("QDIFF_ADOPT_DECODER", "1") != "0"
+class HipBatchTooLarge(hip.HipEngineError):
+    """A size limit of ONE call (32-bit row offsets), not a property of the decoder: callers chunk or fall back for that call."""
+
+
+# QDIFF_ADOPT_DECODER: "autocast" (default) — the reference's `Decoder.forward` is served by this package's fp16-operand MFMA
+# kernels only while autocast is active, i.e. where the reference itself already decodes in fp16 (the scripts' default
+# `--precision autocast`, txt2img.py:231-236); an fp32 decode (`--precision full`, the FID runs of sample_diffusion_ldm.py)
+# stays the reference's own fp32 library path, bit for bit.  "always": adopt fp32 decodes too (1e-3 of range from fp32, 7x
+# faster).  "0": never.
+ADOPT_DECODER = os.environ.get("QDIFF_ADOPT_DECODER", "autocast").lower()
+if ADOPT_DECODER in ("1", "on", "true"):
+    ADOPT_DECODER = "autocast"
+_ADOPT_LOGGED = [False]
 
 
 def _on_device(z):
@@ -232,7 +250,7 @@ def adopt_reference_decoder():
     decoder at, txt2img.py:231-236); anything else — CPU tensors, training, an unsupported layer — runs the reference's own
     forward, untouched.  Called by QuantModel when it wraps a model (qdiff/quant_model.py: _adopt_reference_modules).
     Returns the class, or None when the reference's `ldm` package is not importable / adoption is switched off."""
-    if not ADOPT_DECODER:
+    if ADOPT_DECODER in ("0", "off", "false", "no"):
         return None
     try:
         from ldm.modules.diffusionmodules import model as ref_model
@@ -246,12 +264,18 @@ def adopt_reference_decoder():
     def forward(self, z):
         if (torch.is_tensor(z) and z.dim() == 4 and _on_device(z) and not torch.is_grad_enabled() and not self.training
                 and not getattr(self, "give_pre_end", False) and not getattr(self, "tanh_out", False)
-                and not self.__dict__.get("_qd_hip_unsupported") and hip.available()):
+                and not self.__dict__.get("_qd_hip_unsupported") and (ADOPT_DECODER == "always" or (z.is_cuda and torch.is_autocast_enabled()))
+                and hip.available()):
             try:
                 out = hip_decoder(self)(z.float())
+            except HipBatchTooLarge:
+                return ref_forward(self, z)                           # this call only: the next (smaller) batch takes the kernels again
             except hip.HipEngineError:
                 self.__dict__["_qd_hip_unsupported"] = True           # a layer this engine does not implement: the reference's own code
                 return ref_forward(self, z)
+            if not _ADOPT_LOGGED[0]:
+                _ADOPT_LOGGED[0] = True
+                logger.info("first-stage Decoder.forward runs on qdiff's fp16-operand MFMA kernels (QDIFF_ADOPT_DECODER=%s)", ADOPT_DECODER)
             return out.to(torch.get_autocast_gpu_dtype()) if (z.is_cuda and torch.is_autocast_enabled()) else out
         return ref_forward(self, z)
 

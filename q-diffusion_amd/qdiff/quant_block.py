@@ -222,6 +222,10 @@ _CTX_FORK = os.environ.get("QDIFF_CTX_FORK", "start")
 # QDIFF_CTX_PIN=0: QuantModel.prepare_context becomes a no-op, i.e. the cross-attention K / V^T operands are recomputed by
 # every evaluation as the reference does (quant_block.py:193-195) — the A/B knob of the once-per-sampling-run computation
 _CTX_PIN = os.environ.get("QDIFF_CTX_PIN", "1") != "0"
+# prepared contexts kept at a time (ContextKV): >= 1.  QDIFF_CTX_AUTO=0: only explicit QuantModel.prepare_context() prepares
+# (default: QuantModel.forward prepares a context it has not seen — the unmodified reference samplers never announce theirs)
+_CTX_PINS = max(1, int(os.environ.get("QDIFF_CTX_PINS", "2")))
+_CTX_AUTO = os.environ.get("QDIFF_CTX_AUTO", "1") != "0"
 _FUSE_SKIP_QUANT = os.environ.get("QDIFF_FUSE_SKIP_QUANT", "1") != "0"     # A/B knob: skip-connection rows from the GroupNorm pass
 CAT_SLOTS = os.environ.get("QDIFF_CAT_SLOTS", "1") != "0"         # A/B knob: planned skip-concatenation buffers (engine.CatSlot)
 
@@ -249,21 +253,93 @@ class ContextKV:
     def __init__(self):
         self.members = []
         self._ctx, self._out, self._side, self._joined = None, None, None, True
-        self._pin = None
+        self._pins = []               # prepared contexts (dicts, see `pin`), least recently used first; each owns the buffers of its slot
+        self._sel = None              # (entry, context object, owner) in force for the evaluation being issued
+        self._slot_gen = {}           # slot -> how often its buffers were (re)written
+        self.token = lambda: 0        # QuantModel installs its state token: a pin made under another token is stale
         self.chain_runs = 0           # how often the to_k / to_v chain was issued (tests: a prepared context must not add to it)
+        self.value_matches = 0        # prepared contexts recognised by VALUE (a fresh tensor with the pinned bytes)
 
-    # ---- operands prepared ONCE per sampling run (QuantModel.prepare_context) -------------------------------------------
+    # ---- operands prepared ONCE per sampling run (QuantModel.prepare_context, or on first sight: QuantModel.forward) --------
     # The reference recomputes k = to_k(context), v = to_v(context) in every evaluation (quant_block.py:193-195) although the
     # samplers hand it the same conditioning at every step (plms.py:184-187 concatenates the same `uncond, c` each time):
-    # static input, static weights, static quantisers -> static int8 operands.  `pin` runs the chain once into buffers of
-    # its own (k8, v8^T, column sums, and the key-term table of the attention kernel) and `get` hands them out for as long
-    # as the evaluation's context IS that tensor (same object, same in-place version) and the plans the bytes were made
-    # with are still the blocks' current ones; anything else falls back to the per-evaluation branch below.
+    # static input, static weights, static quantisers -> static int8 operands.  `pin` runs the chain once into the buffers of
+    # a SLOT (k8, v8^T, column sums, the key-term table of the attention kernel) and keeps a device copy of the context next
+    # to them; `match` recognises a later context as prepared — the same object with the same in-place version (no device
+    # work), or ANY tensor holding the same bytes (one comparison kernel + one flag read back: the reference's samplers build
+    # a fresh `torch.cat([uncond, c])` per step) — as long as the model's state token is the one the bytes were made under.
+    # QDIFF_CTX_PINS slots (default 2: cond / uncond evaluated separately, two prompts alternating) are kept, least recently
+    # used evicted; an entry LOCKED by a whole-step graph (sampling.DevicePLMS) is never evicted nor rewritten with other bytes.
+    def _live(self):
+        tok = self.token()
+        if any(e["token"] != tok for e in self._pins):
+            self._pins = [e for e in self._pins if e["token"] == tok or e["locked"]]
+        return tok
+
+    def match(self, context, by_value=True):
+        """The entry prepared for `context`, or None.  by_value=False: identity + in-place version only (no device read-back:
+        usable under stream capture)."""
+        if not self._pins or not torch.is_tensor(context):
+            return None
+        tok = self._live()
+        ver = engine.tensor_version(context)                       # None: an inference tensor, identity proves nothing
+        cands = [e for e in reversed(self._pins) if e["token"] == tok and e["shape"] == tuple(context.shape)
+                 and e["dtype"] == context.dtype and e["device"] == context.device]
+        if ver is not None:
+            for e in cands:
+                a = e["alias"].get(id(context))
+                if a is not None and a[0]() is context and a[1] == ver:
+                    return self._touch(e)
+        if not by_value or not cands:
+            return None
+        if context.is_cuda:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            flags = torch.stack([(context == e["copy"]).all() for e in cands]).tolist()      # ONE read-back for all slots
+        else:
+            flags = [torch.equal(context, e["copy"]) for e in cands]
+        for e, same in zip(cands, flags):
+            if same:
+                self.value_matches += 1
+                self._alias(e, context, ver)
+                return self._touch(e)
+        return None
+
+    def _touch(self, e):
+        if self._pins and self._pins[-1] is not e:
+            self._pins.remove(e)
+            self._pins.append(e)
+        return e
+
+    @staticmethod
+    def _alias(e, context, ver):
+        if ver is None:
+            return
+        if len(e["alias"]) > 64:
+            e["alias"].clear()
+        import weakref
+        e["alias"][id(context)] = (weakref.ref(context), ver)
+
     def pin(self, context):
-        self._pin = None
+        """Run the chain for `context` into a slot (the slot of an entry holding the same bytes, else a free one, else the least
+        recently used unlocked one) and select nothing: the next evaluation `match`es.  Returns the entry or None."""
         if not _CTX_PIN or not self._ready(context):
-            return False
-        out = self._work(context, tag="pin")
+            return None
+        tok = self._live()
+        e = self.match(context)
+        if e is not None:
+            slot = e["slot"]
+            self._pins.remove(e)
+        else:
+            used = {p["slot"] for p in self._pins}
+            free = [p for p in self._pins if not p["locked"]]
+            if len(self._pins) >= _CTX_PINS and free:
+                slot = free[0]["slot"]
+                self._pins.remove(free[0])
+            else:
+                slot = next(i for i in range(len(used) + 1) if i not in used)
+        locked = e["locked"] if e is not None else 0
+        out = self._work(context, tag=("pin", slot))
         for blk in self.members:
             att = blk.attn2
             k8, v8, vsum, _ = out[id(blk)]
@@ -272,28 +348,31 @@ class ContextKV:
             ap = blk._attn_plan(att, float(att.scale), 1.0, context.device)
             kterm = None
             if engine.hip.attn_uses_keyterm(d, context.shape[1], ap.asym):
-                kterm = engine.hip.attn_keyterm(k8, k8.shape[0], k8.shape[1], k8.shape[2], ap.prm, self._bufs_for(("pin-kterm", id(blk)) + tuple(k8.shape[:2]),
+                kterm = engine.hip.attn_keyterm(k8, k8.shape[0], k8.shape[1], k8.shape[2], ap.prm, self._bufs_for(("pin-kterm", slot, id(blk)) + tuple(k8.shape[:2]),
                                                 lambda: torch.empty(tuple(k8.shape[:2]), dtype=torch.int32, device=k8.device)))
             out[id(blk)] = (k8, v8, vsum, kterm)
-        self._pin = dict(ctx=context, version=context._version, shape=tuple(context.shape), out=out,
-                         plans={id(blk): self._plan_ids(blk, context.device) for blk in self.members})
-        return True
+        self._slot_gen[slot] = self._slot_gen.get(slot, 0) + 1
+        copy = self._bufs_for(("pin-copy", slot, tuple(context.shape), context.dtype, context.device),
+                              lambda: torch.empty(tuple(context.shape), dtype=context.dtype, device=context.device))
+        copy.copy_(context.detach())
+        e = dict(slot=slot, gen=self._slot_gen[slot], token=tok, copy=copy, shape=tuple(context.shape), dtype=context.dtype,
+                 device=context.device, alias={}, out=out, locked=locked)
+        self._alias(e, context, engine.tensor_version(context))
+        self._pins.append(e)
+        return e
 
     def unpin(self):
-        self._pin = None
+        """Forget every prepared context that no whole-step graph holds (a locked entry stays: its graph reads the buffers)."""
+        self._pins = [e for e in self._pins if e["locked"]]
+        self._sel = None
+
+    def select(self, entry, context, owner="forward"):
+        """The evaluation about to be issued reads `entry`'s operands for `context` (None: the per-evaluation branch)."""
+        self._sel = (entry, context, owner) if entry is not None else None
 
     def pinned(self, context, deep=True):
-        """`context` is the pinned tensor, unmodified; deep: and every plan the bytes were made with is still current
-        (QuantModel drops the pin itself on set_quant_state / invalidate_plans / set_running_stat; the deep check covers
-        code that re-initialises a single block's quantisers or weights behind its back)."""
-        p = self._pin
-        if p is None or context is not p["ctx"] or context._version != p["version"] or tuple(context.shape) != p["shape"]:
-            return False
-        return not deep or all(self._plan_ids(blk, context.device) == p["plans"][id(blk)] for blk in self.members)
-
-    def _plan_ids(self, blk, dev):
-        att = blk.attn2
-        return (id(att.to_k.conv_plan()), id(att.to_v.conv_plan()), id(blk._attn_plan(att, float(att.scale), 1.0, dev)))
+        """`context` is prepared (by identity or by value) under the model's current state token."""
+        return self.match(context) is not None
 
     def _bufs_for(self, key, make):
         bufs = self.__dict__.setdefault("_bufs", {})
@@ -312,10 +391,26 @@ class ContextKV:
             torch.cuda.current_stream().wait_stream(self._side)
         self._ctx, self._out, self._joined = None, None, True
 
+    def begin(self, context, fork):
+        """Forward pre-hook of the wrapped model.  QuantModel.forward has already selected the prepared entry for this very
+        tensor (or none); a DIRECT call of the wrapped model (graph warm-up / capture, tools) selects by identity only — no
+        device read-back here: this may run under stream capture, where only a LOCKED entry is taken (an unlocked one could
+        be rewritten for another prompt while the captured graph keeps reading its buffers)."""
+        sel = self._sel
+        if sel is None or sel[1] is not context:
+            self._sel = None
+            e = self.match(context, by_value=False) if torch.is_tensor(context) else None
+            if e is not None and context.is_cuda and torch.cuda.is_current_stream_capturing() and not e["locked"]:
+                e = None
+            if e is not None:
+                self._sel = (e, context, "hook")
+        if fork and torch.is_tensor(context):
+            self.start(context)
+
     def start(self, context):
-        """Fork the branch for this evaluation's context (no-op for a pinned context, for a context already started, for None,
+        """Fork the branch for this evaluation's context (no-op for a prepared context, for a context already started, for None,
         and whenever `_prepare` finds a module that is not ready for the integer path: `get` then answers None = in-line path)."""
-        if context is not None and self._pin is not None and self.pinned(context):
+        if context is not None and self._sel is not None and self._sel[1] is context:
             return
         if context is not None and self._ctx is not context:
             self._ctx, self._out = context, None
@@ -323,8 +418,9 @@ class ContextKV:
 
     def get(self, blk, context):
         """(k8, v8, vsum, kterm) of blk.attn2 for this context, or None (in-line path)."""
-        if self._pin is not None and self.pinned(context):
-            return self._pin["out"][id(blk)]
+        sel = self._sel
+        if sel is not None and sel[1] is context:
+            return sel[0]["out"][id(blk)]
         self.start(context)
         if self._out is None:
             return None
@@ -393,6 +489,8 @@ class ContextKV:
         if not self._joined and self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
             self._joined = True
+        if self._sel is not None and self._sel[2] == "hook":
+            self._sel = None
 
 
 def time_mlp(lin0, lin1, t_emb, act=F.silu):

@@ -89,12 +89,20 @@ class UniformAffineQuantizer(nn.Module):
     first tensor seen follow reference quant_layer.py:36-200.
     """
 
+    # attributes whose (re-)assignment changes what the integer path bakes into device tensors — or takes the layer off that
+    # path (data-dependent initialisation, range tracking): QuantModel re-validates its cached "whole model on the integer
+    # path, these plans" verdict — and with it its HIP graphs and prepared contexts — when engine.STATE_GENERATION has moved
+    _STATE_ATTRS = frozenset(("inited", "running_stat", "delta", "zero_point", "n_bits", "n_levels", "sym", "always_zero"))
+
     def __setattr__(self, name, value):
-        # a quantiser that (re-)enters data-dependent initialisation or range tracking takes its layer off the integer path:
-        # QuantModel's cached "whole model on the integer path" verdict must be re-validated (engine.STATE_GENERATION)
-        if name in ("inited", "running_stat"):
+        if name in self._STATE_ATTRS:
             engine.bump_state()
         super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        if name in self._STATE_ATTRS:
+            engine.bump_state()
+        super().__delattr__(name)
 
     def __init__(self, n_bits: int = 8, symmetric: bool = False, channel_wise: bool = False,
                  scale_method: str = 'max', leaf_param: bool = False, always_zero: bool = False):
@@ -332,11 +340,24 @@ class QuantModule(nn.Module):
         self._plan, self._plan_key = None, None
         self._wdq, self._wdq_key = None, None
 
+    # see UniformAffineQuantizer._STATE_ATTRS: re-assigned weights / quantiser objects / switches invalidate QuantModel's verdict
+    _STATE_ATTRS = frozenset(("weight", "bias", "split", "disable_act_quant", "act_quant_mode", "use_weight_quant", "use_act_quant",
+                              "weight_quantizer", "weight_quantizer_0", "act_quantizer", "act_quantizer_0"))
+
+    def __setattr__(self, name, value):
+        if name in self._STATE_ATTRS:
+            engine.bump_state()
+        super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        if name in self._STATE_ATTRS:
+            engine.bump_state()
+        super().__delattr__(name)
+
     # -- reference-visible controls -----------------------------------------------------------
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
         self.use_weight_quant = weight_quant
         self.use_act_quant = act_quant
-        engine.bump_state()
 
     def set_split(self):
         self.weight_quantizer_0 = UniformAffineQuantizer(**self.weight_quant_params)
@@ -409,7 +430,7 @@ class QuantModule(nn.Module):
     def dequantized_weight(self):
         """fp32 weight after fake quantisation, cached per quantiser state (weights-only mode)."""
         qs = self._weight_quantizers()
-        key = (tuple(engine.quantizer_key(q) for q in qs), self.weight._version, self.weight.data_ptr(), self.split)
+        key = (tuple(engine.quantizer_key(q) for q in qs), engine.tensor_version(self.weight), self.weight.data_ptr(), self.split)
         if self._wdq_key != key or torch.is_grad_enabled():
             parts = [q(w) for q, w in zip(qs, self._weight_slices())]
             w = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
@@ -424,6 +445,7 @@ class QuantModule(nn.Module):
         quantiser attributes and in-place updates that bump a tensor's version counter
         (optimizer steps, load_state_dict, `p.mul_()` ...); writes through `.data` bypass version
         tracking, so call this (or QuantModel.invalidate_plans()) after such an edit."""
+        engine.bump_state()
         self._pack_key = self._plan_key = self._wdq_key = None
         self.__dict__.pop('_geglu_cache', None)
         self.__dict__.pop('_frozen_pack', None)
@@ -433,29 +455,47 @@ class QuantModule(nn.Module):
         """Install packed weights read from a packed checkpoint (utils.load_packed_ckpt): the integer path then never
         looks at the fp32 weight / AdaRound alpha again (they can be freed); invalidate() returns to the live weights."""
         self._geometry()                                   # records the kernel size while the weight still has its shape
+        engine.bump_state()
         self.__dict__['_frozen_pack'] = pack
         self.__dict__['_frozen_geglu_pack'] = geglu_pack
         self._pack_key = self._plan_key = None
         self.__dict__.pop('_geglu_cache', None)
 
-    def conv_plan(self):
-        """Packed weights + epilogue constants for the current quantiser state (lazy, cached)."""
+    def plan_keys(self):
+        """(wkey, akey): identity of everything the packed weights resp. the whole plan are made from — quantiser objects and
+        their tensors (object, in-place version, storage), the weight, the bias, the split.  conv_plan() rebuilds when they
+        move; QuantModel compares them model-wide to decide whether its HIP graphs / prepared contexts are still valid."""
         wqs, aqs = self._weight_quantizers(), self._act_quantizers()
         frozen = self.__dict__.get('_frozen_pack')
         if frozen is not None:
             wkey = ('frozen', id(frozen))
-            if self._pack_key != wkey:
-                self._pack, self._pack_key, self._plan_key = frozen, wkey, None
         else:
             for q, w in zip(wqs, self._weight_slices()):
                 if hasattr(q, 'ensure_init'):
                     q.ensure_init(w)
-            wkey = (tuple(engine.quantizer_key(q) for q in wqs), self.weight._version, self.weight.data_ptr(), self.split)
+            wkey = (tuple(engine.quantizer_key(q) for q in wqs), engine.tensor_version(self.weight), self.weight.data_ptr(), self.split)
+        bias_key = None if self.bias is None else (engine.tensor_version(self.bias), self.bias.data_ptr())
+        return wkey, (wkey, tuple(engine.quantizer_key(q) for q in aqs), bias_key)
+
+    def state_tensors(self):
+        """Every tensor whose in-place modification must invalidate what was built from this module (QuantModel sums their
+        version counters per evaluation: cheaper than re-deriving plan_keys())."""
+        out = [self.weight, self.bias]
+        qs = self._weight_quantizers() + (self._act_quantizers() if self.act_quant_mode == 'qdiff' else [])
+        for q in qs:
+            out += [getattr(q, n, None) for n in ("delta", "zero_point", "alpha")]
+        return [t for t in out if torch.is_tensor(t)]
+
+    def conv_plan(self):
+        """Packed weights + epilogue constants for the current quantiser state (lazy, cached)."""
+        wqs, aqs = self._weight_quantizers(), self._act_quantizers()
+        wkey, akey = self.plan_keys()
+        frozen = self.__dict__.get('_frozen_pack')
+        if frozen is not None and self._pack_key != wkey:
+            self._pack, self._pack_key, self._plan_key = frozen, wkey, None
         if self._pack_key != wkey:
             self._pack = engine.pack_module_weights(self.weight, wqs, self.split)
             self._pack_key, self._plan_key = wkey, None
-        bias_key = None if self.bias is None else (self.bias._version, self.bias.data_ptr())
-        akey = (wkey, tuple(engine.quantizer_key(q) for q in aqs), bias_key)
         if self._plan_key != akey:
             kh, kw, stride, pad = self._geometry()
             self._plan = engine.build_conv_plan(self._pack, aqs, kh, kw, stride, pad, self.bias)
@@ -519,8 +559,8 @@ class QuantModule(nn.Module):
         wq, aq = self.weight_quantizer, self.act_quantizer
         if hasattr(wq, 'ensure_init'):
             wq.ensure_init(self.weight)
-        key = (engine.quantizer_key(wq), engine.quantizer_key(aq), self.weight._version, self.weight.data_ptr(),
-               None if self.bias is None else (self.bias._version, self.bias.data_ptr()))
+        key = (engine.quantizer_key(wq), engine.quantizer_key(aq), engine.tensor_version(self.weight), self.weight.data_ptr(),
+               None if self.bias is None else (engine.tensor_version(self.bias), self.bias.data_ptr()))
         cache = self.__dict__.setdefault('_geglu_cache', [None, None])
         if cache[0] != key:
             pack = engine.pack_module_weights(self.weight, [wq], 0, row_perm=engine.geglu_row_perm(F, self.weight.device))

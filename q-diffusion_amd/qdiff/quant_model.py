@@ -24,6 +24,8 @@ from .arch import ddim_unet, ldm_unet
 
 logger = logging.getLogger(__name__)
 
+_MAX_GRAPHS = max(1, int(os.environ.get("QDIFF_HIP_GRAPH_MAX", "8")))       # captured evaluations kept per model (oldest dropped)
+
 
 class QuantModel(nn.Module):
 
@@ -40,7 +42,13 @@ class QuantModel(nn.Module):
         self.quant_block_refactor(self.model, weight_quant_params, act_quant_params)
         self._adopt_reference_modules()
         self._fuse_time_embedding()
-        self._graphs = None
+        # HIP-graph replay of whole evaluations (qdiff/graph.py): ON by default for the integer state — the unmodified reference
+        # scripts never ask for it (scripts/txt2img.py:381-390 wraps the UNet and samples) — with a graph captured the SECOND time
+        # a call signature is seen, so that one-off shapes (calibration batches) are never captured; QDIFF_HIP_GRAPH=0 switches
+        # the default off, enable_hip_graphs() overrides it either way (and captures on first sight).
+        self._graphs = {} if os.environ.get("QDIFF_HIP_GRAPH", "1") != "0" else None
+        self._graph_after, self._graph_seen, self._graph_tok = 1, {}, None
+        self._own_hooks = self._hook_census()           # a replayed graph runs no Python: foreign forward hooks keep the model eager
         self._quant_state = (False, False)
         import weakref
         weakref.finalize(self, engine.release_model, id(self))      # the per-model V-sum arena dies with the model
@@ -82,6 +90,7 @@ class QuantModel(nn.Module):
             elif isinstance(m, QuantResnetBlock) and isinstance(m.temb_proj, QuantModule):
                 group.register(m, m.temb_proj)
         ctx = ContextKV()                # cross-attention keys / values of every transformer block: one side-stream branch
+        ctx.token = lambda: self.__dict__.get("_tok", -1)      # the token forward() / prepare_context() derived last (cheap: no re-derivation per block)
         self.__dict__["_ctx_kv"] = ctx
         for m in self.model.modules():
             if isinstance(m, QuantBasicTransformerBlock):
@@ -91,8 +100,7 @@ class QuantModel(nn.Module):
         from . import quant_block as _qb
         self.model.register_forward_pre_hook(lambda _m, _a: (group.reset(), ctx.reset(), engine.begin_evaluation(id(self)),
                                                              self._select_stream(),
-                                                             ctx.start(_a[2]) if _qb._CTX_FORK == "start" and len(_a) > 2 and torch.is_tensor(_a[2])
-                                                             else None) and None)
+                                                             ctx.begin(_a[2] if len(_a) > 2 else None, _qb._CTX_FORK == "start")) and None)
         # end of the evaluation: the context branch is joined, and the stream type in force goes back to "unset" (code that
         # drives kernels directly afterwards gets engine.STREAM_DTYPE, not this model's verdict)
         self.model.register_forward_hook(lambda _m, _a, _o: (ctx.finish(), engine._EFFECTIVE.__setitem__(0, None)) and None, always_call=True)
@@ -215,56 +223,132 @@ class QuantModel(nn.Module):
             elif ref.get("Upsample") is not None and type(m) is ref["Upsample"] and getattr(m, "dims", 2) == 2:
                 m.qd_takes_out_slot = True
 
+    def _hook_census(self):
+        """Forward (pre-)hooks registered below the wrapped model.  Calibration and the tests' recorders hook sub-modules and
+        expect every evaluation to run them; a HIP-graph replay runs no Python at all, so an evaluation is captured only while
+        the census is the one this wrapper left behind (its own hooks)."""
+        return sum(len(m._forward_hooks) + len(m._forward_pre_hooks) for m in self.model.modules())
+
+    # ---- state token: "the whole model is on the integer path, and these are the tensors its plans were made from" ------------
+    # HIP graphs and prepared contexts bake device pointers and quantiser values in; they are valid for as long as the token
+    # does not move.  Per evaluation the check costs one integer compare (engine.STATE_GENERATION: bumped by every (re)assignment
+    # of a quantiser attribute, weight, switch — the __setattr__ hooks of quant_layer / adaptive_rounding — and by
+    # invalidate()) plus the sum of ~1.5k tensor version counters (in-place edits: optimizer steps, load_state_dict); only when
+    # one of the two has moved are the per-layer plan keys re-derived and compared.  Writes through `.data` bypass both, as they
+    # bypass the plan caches: invalidate_plans() after such an edit.
+    def _fingerprint(self):
+        if self._quant_state != (True, True) or engine.SIMULATE:
+            return None, None
+        keys, tens = [], []
+        names = ("act_quantizer_q", "act_quantizer_k", "act_quantizer_v", "act_quantizer_w")
+        for m in self.model.modules():
+            if isinstance(m, QuantModule):
+                if not m.int_ready() or any((not q.inited) or q.running_stat for q in m._act_quantizers()):
+                    return None, None
+                keys.append(m.plan_keys()[1])
+                tens += m.state_tensors()
+                continue
+            qs = [q for q in (m.__dict__.get("_modules", {}).get(n) for n in names) if isinstance(q, UniformAffineQuantizer)]
+            if qs:
+                if any((not q.inited) or q.running_stat for q in qs):
+                    return None, None
+                keys.append(tuple(engine.quantizer_key(q) for q in qs))
+                tens += [t for q in qs for t in (q.delta, q.zero_point) if torch.is_tensor(t)]
+            if isinstance(m, (nn.GroupNorm, nn.LayerNorm)):
+                keys.append(tuple((id(t), t.data_ptr()) for t in (m.weight, m.bias) if torch.is_tensor(t)))
+        return tuple(keys), tens
+
+    @staticmethod
+    def _vsum(tens):
+        try:
+            return sum(t._version for t in tens)
+        except RuntimeError:                               # inference tensors carry no counter
+            return sum(engine.tensor_version(t) or 0 for t in tens)
+
+    def _state_token(self):
+        """>= 0: every layer takes the integer path and nothing its plans were made from has changed since this number was
+        handed out; -1: not (yet) the case.  Never re-derives under stream capture (the warm-up evaluations did)."""
+        d = self.__dict__
+        gen = engine.STATE_GENERATION[0]
+        tens = d.get("_tok_tensors")
+        if d.get("_tok_gen") == gen and (tens is None or self._vsum(tens) == d["_tok_vsum"]):
+            return d["_tok"]
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return d.get("_tok", -1)
+        keys, tens = self._fingerprint()
+        if keys is None:
+            d["_tok"], d["_tok_keys"] = -1, None
+        elif d.get("_tok_keys") != keys:
+            d["_tok_serial"] = d.get("_tok_serial", -1) + 1
+            d["_tok"], d["_tok_keys"] = d["_tok_serial"], keys
+        else:
+            d["_tok"] = d["_tok_serial"]
+        d["_tok_tensors"], d["_tok_vsum"] = tens, (self._vsum(tens) if tens is not None else 0)
+        d["_tok_gen"] = engine.STATE_GENERATION[0]         # plan_keys() may have initialised weight quantisers (bumps)
+        return d["_tok"]
+
+    def state_token(self):
+        return self._state_token()
+
     def _select_stream(self):
-        """fp16 activation stream (engine.STREAM_DTYPE) only for evaluations that run entirely on the integer path; the
-        verdict is cached once positive (set_quant_state / invalidate_plans / set_running_stat drop it)."""
+        """fp16 activation stream (engine.STREAM_DTYPE) only for evaluations that run entirely on the integer path."""
         if engine.STREAM_DTYPE == torch.float32:
             engine._EFFECTIVE[0] = None
             return
-        ready = self.__dict__.get("_stream_ready", False) and self.__dict__.get("_stream_ready_gen") == engine.STATE_GENERATION[0]
-        if not ready and self._quant_state == (True, True) and not torch.is_grad_enabled() and not engine.SIMULATE and not self.model.training:
-            ready = True
-            for m in self.model.modules():
-                if isinstance(m, QuantModule):
-                    if not m.int_ready() or any((not q.inited) or q.running_stat for q in m._act_quantizers()):
-                        ready = False
-                        break
-                else:
-                    qs = [getattr(m, n, None) for n in ("act_quantizer_q", "act_quantizer_k", "act_quantizer_v", "act_quantizer_w")]
-                    if any(isinstance(q, UniformAffineQuantizer) and ((not q.inited) or q.running_stat) for q in qs):
-                        ready = False
-                        break
-            self.__dict__["_stream_ready"] = ready
-            self.__dict__["_stream_ready_gen"] = engine.STATE_GENERATION[0]
-        ok = ready and self._quant_state == (True, True) and not torch.is_grad_enabled() and not engine.SIMULATE
+        ok = (not torch.is_grad_enabled()) and not self.model.training and self._state_token() >= 0
         engine._EFFECTIVE[0] = engine.STREAM_DTYPE if ok else torch.float32
+
+    def _prepare(self, context):
+        """ContextKV.pin under this model's stream verdict (the chain's projections must emit the rows an evaluation would:
+        engine._EFFECTIVE is unset outside evaluations).  Returns the entry or None."""
+        ctx = self.__dict__.get("_ctx_kv")
+        if (ctx is None or not torch.is_tensor(context) or torch.is_grad_enabled() or self.model.training
+                or (context.is_cuda and torch.cuda.is_current_stream_capturing())      # captured launches would not have run yet
+                or self._state_token() < 0):
+            return None
+        self._select_stream()
+        try:
+            return ctx.pin(context)
+        finally:
+            engine._EFFECTIVE[0] = None
 
     def prepare_context(self, context):
         """Compute the cross-attention K / V^T operands of every transformer block for `context` ONCE; evaluations that are
-        handed this very tensor (same object, not modified in place since) skip the ~150-launch chain of to_k / to_v /
-        head-layout quantisers that the reference repeats in each of the 51 evaluations of a sampling run
-        (quant_block.py:193-195; plms.py:184-187 passes the same `torch.cat([uncond, c])` at every step).  Static input,
+        handed this tensor — or ANY tensor with the same bytes: the reference's samplers rebuild `torch.cat([uncond, c])` at
+        every step (plms.py:184-187), see ContextKV.match — skip the ~150-launch chain of to_k / to_v / head-layout quantisers
+        that the reference repeats in each of the 51 evaluations of a sampling run (quant_block.py:193-195).  Static input,
         static weights, static quantisers: the bytes are those the per-evaluation branch produces, bit for bit
         (tests/test_engine_models.py::test_prepared_context_changes_nothing).  Only in the integer state with every
         quantiser initialised and no running statistics; returns False (and changes nothing) otherwise or when QDIFF_CTX_PIN=0.
-        Any other context, a changed quant state or re-packed weights fall back to the per-evaluation branch; call again for a
-        new context.  The captured HIP graph of a prepared evaluation reads the pinned buffers and survives re-preparation."""
-        ctx = self.__dict__.get("_ctx_kv")
-        if (ctx is None or not torch.is_tensor(context) or self._quant_state != (True, True) or torch.is_grad_enabled()
-                or engine.SIMULATE or self.model.training
-                or (context.is_cuda and torch.cuda.is_current_stream_capturing())):      # captured launches would not have run yet
-            if ctx is not None:
-                ctx.unpin()
-            return False
-        return ctx.pin(context)
+        Calling it is OPTIONAL since round 5: forward() prepares a context it has not seen by itself (QDIFF_CTX_AUTO=0 to
+        switch that off) and keeps QDIFF_CTX_PINS (2) of them; a changed quant state or re-packed weights drop them."""
+        return self._prepare(context) is not None
 
     def release_context(self):
         ctx = self.__dict__.get("_ctx_kv")
         if ctx is not None:
             ctx.unpin()
 
+    def lock_context(self, context):
+        """For callers that capture evaluations of this model into graphs of their OWN (sampling.DevicePLMS): the prepared
+        entry of `context` (prepared now if need be) is pinned down — not evicted, not rewritten with other bytes — until
+        unlock_context(handle).  Under stream capture only a locked entry is used.  Returns the handle or None."""
+        ctx = self.__dict__.get("_ctx_kv")
+        if ctx is None or not torch.is_tensor(context):
+            return None
+        e = ctx.match(context) if self._state_token() >= 0 else None
+        if e is None:
+            e = self._prepare(context)
+        if e is not None:
+            e["locked"] += 1
+        return e
+
+    def unlock_context(self, handle):
+        if handle is not None and handle["locked"] > 0:
+            handle["locked"] -= 1
+
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
-        self.__dict__["_stream_ready"] = False
+        engine.bump_state()
         self.release_context()
         self._quant_state = (bool(weight_quant), bool(act_quant))
         for m in self.model.modules():
@@ -272,22 +356,50 @@ class QuantModel(nn.Module):
                 m.set_quant_state(weight_quant, act_quant)
 
     def forward(self, x, timesteps=None, context=None):
-        if self._graphs is not None and not torch.is_grad_enabled() and torch.is_tensor(timesteps) and x.is_cuda:
-            from .graph import GraphedUNet, signature
-            ckv = self.__dict__.get("_ctx_kv")
-            pinned = bool(context is not None and ckv is not None and ckv._pin is not None and ckv.pinned(context, deep=False))
-            key = signature(x, timesteps, context) + (self._quant_state, engine.STREAM_DTYPE, pinned)
-            g = self._graphs.get(key)
-            if g is None:
-                g = self._graphs[key] = GraphedUNet(self, x, timesteps, context, pinned=pinned)
-            return g(x, timesteps, context).to(x.dtype, copy=True)
-        y = self.model(x, timesteps, context)
+        from . import quant_block as qb
+        ckv = self.__dict__.get("_ctx_kv")
+        cuda = torch.is_tensor(x) and x.is_cuda
+        capturing = cuda and torch.cuda.is_current_stream_capturing()
+        tok = -1
+        if not torch.is_grad_enabled() and not self.model.training and not capturing:
+            tok = self._state_token()
+        entry = None
+        if tok >= 0 and ckv is not None and torch.is_tensor(context) and qb._CTX_PIN:
+            # the run's conditioning: prepared before (same tensor, or the same BYTES in a fresh tensor), or prepared now
+            entry = ckv.match(context)
+            if entry is None and qb._CTX_AUTO:
+                entry = self._prepare(context)
+        if ckv is not None:
+            ckv.select(entry, context)
+        try:
+            if self._graphs is not None and tok >= 0 and cuda and torch.is_tensor(timesteps):
+                from .graph import GraphedUNet, signature
+                if self._graph_tok != tok:                 # plans were rebuilt: the captured pointers are stale
+                    self._graphs.clear()
+                    self._graph_seen.clear()
+                    self._graph_tok = tok
+                key = signature(x, timesteps, context) + (engine.STREAM_DTYPE, None if entry is None else entry["slot"])
+                g = self._graphs.get(key)
+                if g is None:
+                    seen = self._graph_seen.get(key, 0)
+                    self._graph_seen[key] = seen + 1
+                    if seen >= self._graph_after and self._hook_census() == self._own_hooks:
+                        while len(self._graphs) >= _MAX_GRAPHS:
+                            self._graphs.pop(next(iter(self._graphs)))
+                        g = self._graphs[key] = GraphedUNet(self, x, timesteps, context, pinned=entry is not None)
+                if g is not None:
+                    return g(x, timesteps, context).to(x.dtype, copy=True)
+            y = self.model(x, timesteps, context)
+        finally:
+            if ckv is not None:
+                ckv.select(None, None)
         # an fp16 activation stream ends here: the samplers' update arithmetic runs in the latent's own type
         return y.to(x.dtype) if torch.is_tensor(y) and y.dtype == torch.float16 and x.dtype != torch.float16 else y
 
     def invalidate_plans(self):
         """Forget every packed weight / epilogue constant / captured graph (see QuantModule.invalidate)."""
-        self.__dict__["_stream_ready"] = False
+        engine.bump_state()
+        self.__dict__["_tok_keys"] = None                  # the next token is a new one even if every key looks the same
         self.release_context()
         for m in self.model.modules():
             if isinstance(m, QuantModule):
@@ -295,16 +407,19 @@ class QuantModel(nn.Module):
             m.__dict__.pop("_attn_plan_cache", None)
         if self._graphs is not None:
             self._graphs = {}
+            self._graph_seen = {}
 
     def enable_hip_graphs(self, on: bool = True):
-        """Replay each (shape, quant-state) UNet evaluation as one HIP graph (qdiff/graph.py).
-        Quantiser parameters are baked into device tensors at capture; call again (or toggle the
-        quant state) after changing them."""
+        """Replay each (shape, quant-state) UNet evaluation as one HIP graph (qdiff/graph.py), captured the FIRST time a call
+        signature is seen (the default — replay on, capture on second sight — needs no call).  Quantiser parameters are baked
+        into device tensors at capture; the state token (see _state_token) drops the graphs when they change."""
         self._graphs = {} if on else None
+        self._graph_seen = {}
+        self._graph_after = 0
 
     def set_running_stat(self, running_stat: bool, sm_only=False):
         """reference :71-87"""
-        self.__dict__["_stream_ready"] = False
+        engine.bump_state()
         self.release_context()
         for m in self.model.modules():
             if isinstance(m, QuantBasicTransformerBlock):

@@ -98,11 +98,14 @@ for name in ("kl_tiny", "vq_tiny"):
     with torch.no_grad():
         still_same = torch.equal(dec(pq(c["z"])), c["out"])
         fh._on_device, hip.available = (lambda z: True), (lambda: True)
+        gated = torch.equal(dec(pq(c["z"])), c["out"])        # default QDIFF_ADOPT_DECODER=autocast: an fp32 decode stays the reference's
+        fh.ADOPT_DECODER = "always"
         adopted = dec(pq(c["z"]))
+        fh.ADOPT_DECODER = "autocast"
         fh._on_device = lambda z: bool(z.is_cuda)
     with torch.enable_grad():
         grad_path = dec(pq(c["z"]))
-    res[name] = dict(cls=type(dec).__module__, golden_reproduced=bool(same), adopted_cpu_untouched=bool(still_same),
+    res[name] = dict(cls=type(dec).__module__, golden_reproduced=bool(same), adopted_cpu_untouched=bool(still_same and gated),
                      adopted_equals_hipdecoder=bool(torch.equal(adopted, out)), grad_path_is_reference=bool(torch.equal(grad_path.detach(), c["out"])),
                      err=((out - c["out"]).abs().max() / c["out"].abs().max()).item())
 print("RESULT " + json.dumps(res))
@@ -378,17 +381,30 @@ def test_foreign_decoder_class_is_adopted_on_the_gpu(cuda, monkeypatch):
     qdiff.QuantModel(ddim_unet.Model(ddim_unet.cifar10_config(split_shortcut=True)), wq, aq)
     assert Decoder.__dict__.get("_qd_hip_forward")
     z = m.post_quant_conv(case["z"]).detach().to(cuda)
+    rng = case["out"].abs().max().item()
+    # default (QDIFF_ADOPT_DECODER=autocast): an fp32 decode — `--precision full`, the FID runs — stays the foreign
+    # class's own fp32 forward; under autocast, where the reference itself decodes in fp16, the MFMA kernels take over
+    with torch.no_grad():
+        full = dec(z)
+    assert calls["foreign"] == 1 and calls["conv"] == 0 and full.dtype == torch.float32
+    assert (full.cpu() - case["out"]).abs().max().item() <= 1e-4 * rng
+    with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+        out = dec(z)
+    torch.cuda.synchronize()
+    assert out.dtype == torch.float16 and calls["foreign"] == 1 and calls["conv"] > 20
+    err = (out.float().cpu() - case["out"]).abs().max().item() / rng
+    assert err <= DECODER_TOL[torch.float16] + 1e-3, err               # + the fp16 rounding of the returned image
+    monkeypatch.setattr(fh, "ADOPT_DECODER", "always")              # opt-in: fp32 callers too
+    n0 = calls["conv"]
     with torch.no_grad():
         out = dec(z)
     torch.cuda.synchronize()
-    assert calls["foreign"] == 0 and calls["conv"] > 20
-    err = (out.float().cpu() - case["out"]).abs().max().item() / case["out"].abs().max().item()
+    assert calls["foreign"] == 1 and calls["conv"] > n0 + 20
+    err = (out.float().cpu() - case["out"]).abs().max().item() / rng
     assert out.dtype == torch.float32 and err <= DECODER_TOL[torch.float16], err
-    with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
-        assert dec(z).dtype == torch.float16 and calls["foreign"] == 0
     with torch.enable_grad():
         ref = dec(z)                                     # autograd on: the foreign class's own forward
-    assert calls["foreign"] == 1 and (ref.detach().cpu() - case["out"]).abs().max().item() <= 1e-4 * case["out"].abs().max().item()
+    assert calls["foreign"] == 2 and (ref.detach().cpu() - case["out"]).abs().max().item() <= 1e-4 * rng
     with torch.no_grad():
         dec.cpu()(z.cpu())                               # host tensors: its own forward again
-    assert calls["foreign"] == 2
+    assert calls["foreign"] == 3

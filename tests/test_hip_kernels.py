@@ -578,12 +578,18 @@ def test_attention_fused(cuda, case):
     assert ((got - want_fq).abs() > 1e-3 * rng).float().mean().item() <= 1e-2
 
 
-@pytest.mark.parametrize("shape", [(2, 320, 32, 320, 3), (1, 640, 16, 640, 3), (2, 320, 64, 320, 1), (3, 96, 16, 200, 3), (16, 256, 8, 1280, 3)])
+@pytest.mark.parametrize("shape", [(2, 320, 32, 320, 3), (1, 640, 16, 640, 3), (2, 320, 64, 320, 1), (3, 96, 16, 200, 3), (16, 256, 8, 1280, 3),
+                                   (4, 160, 64, 640, 3), (8, 64, 64, 320, 1), (2, 224, 32, 224, 3), (3, 96, 16, 196, 3), (3, 96, 16, 198, 3),
+                                   (2, 64, 32, 128, 3), (1, 32, 16, 64, 1)])
 def test_conv_fp16_stream_is_the_rounded_fp32_epilogue(cuda, shape):
     """fp16 activation stream (out / residual stored as halves): the epilogue computes the SAME fp32 value and rounds it once
     (RN) on the store, reads the residual as float(half) — so with a half-representable residual the fp16 output equals
     `fp32_output.half()` bit for bit, the GroupNorm statistics (taken from the fp32 values) are identical, on the 128x320
-    tile, the 256x160 / 128x160 tiles, a ragged width (scalar path) and the split-K schedule alike."""
+    tile, the 256x160 / 128x160 tiles, a ragged width (scalar path) and the split-K schedule alike.  Round 5: the full-line
+    epilogue (two MFMA tiles per transposition, 16-byte lanes) — the added shapes hit the 128 x 320 tile of 2 x 2 waves (its
+    second wave column starts in the upper half of a line), the 256 x 160 tile with odd N blocks, the 224-wide tile whose row
+    stride is not a multiple of a line, a width that is a multiple of 8 but not of 32 (200), widths that fall back to the
+    8-byte / scalar forms (196, 198) and the 128- / 64-wide tiles."""
     from qdiff import engine
     B, Cin, H, Cout, k = shape
     g = torch.Generator().manual_seed(53)
@@ -604,6 +610,97 @@ def test_conv_fp16_stream_is_the_rounded_fp32_epilogue(cuda, shape):
         assert o16.dtype == torch.float16 and torch.equal(o16, o32.half())
         if hasattr(o32, "qd_gn_part"):
             assert hasattr(o16, "qd_gn_part") and torch.equal(o16.qd_gn_part, o32.qd_gn_part)
+
+
+@pytest.mark.parametrize("B,H,C1,C2,Cmid", [(2, 16, 320, 160, 320), (1, 32, 640, 320, 160)])
+def test_concatenation_slot_fp16_rows(cuda, B, H, C1, C2, Cmid):
+    """The full-line fp16 epilogue writing into a column range of a wider buffer (engine.CatSlot: ldo > Cout, the second side
+    starts C1 columns in): values = the plain fp16 output, statistics = the fp32 run's, bit for bit."""
+    from qdiff import engine
+    g = torch.Generator().manual_seed(72)
+    S = H * H
+    engine.set_stream_dtype(torch.float16)
+    try:
+        slot = engine.CatSlot(C1, C2)
+        for side, Cout in enumerate((C1, C2)):
+            x = F.silu(torch.randn(B, Cmid, H, H, generator=g))
+            w = torch.randn(Cout, Cmid, 3, 3, generator=g) * 0.05
+            d, z = R.uaq_init_scale(x, 8, False, False, "max")
+            plan = engine.build_conv_plan(engine.pack_module_weights(w.to(cuda), [_weight_quantizer(w, 4, True, g)], 0), [_aq(d, z)], 3, 3, 1, 1,
+                                          torch.randn(Cout, generator=g).to(cuda))
+            xq = engine.quantize_rows(x.to(cuda), plan, B, Cmid, S, (Cmid * S, S, 1))
+            o32 = engine.conv_forward(plan, xq, B, H, H, gn_stats=True, splitk=False, out_dtype=torch.float32)
+            plain = engine.conv_forward(plan, xq, B, H, H, gn_stats=True, splitk=False)
+            got = engine.conv_forward(plan, xq, B, H, H, gn_stats=True, splitk=False, slot=slot.side(side))
+            torch.cuda.synchronize()
+            assert got.dtype == torch.float16 and got.stride(0) == C1 + C2
+            assert torch.equal(plain, o32.half()) and torch.equal(got, plain)
+            assert torch.equal(got.qd_gn_part, o32.qd_gn_part)
+    finally:
+        engine.set_stream_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("C,S,silu,raw", [(320, 256, True, False), (640, 64, True, True), (1920, 16, False, True), (64, 100, True, False)])
+def test_groupnorm_fp16_rows_16_byte_lanes(cuda, C, S, silu, raw):
+    """Producers of the fp16 activation stream (8 halves per lane: gn_partial_h8 / gn_apply_rows_h8): the same halves widened to
+    fp32 and sent through the fp32 kernels give the same first-level statistics, the same int8 codes and the same raw
+    (skip-connection) codes, bit for bit — the arithmetic per element is identical, only the access width differs."""
+    from qdiff import engine, hip
+    g = torch.Generator().manual_seed(17)
+    B = 2
+    x16 = (torch.randn(B * S, C + 16, generator=g) * 2 + 0.3).half().to(cuda)[:, :C]          # strided rows: ldx = C + 16
+    x32 = x16.float()
+    gn = torch.nn.GroupNorm(32, C, eps=1e-6).to(cuda)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C, generator=g))
+        gn.bias.copy_(torch.randn(C, generator=g))
+    qp = torch.tensor([0.043, 131.0], device=cuda)
+    grid = engine.act_grid(8, False)
+    ws = torch.empty(hip.groupnorm_ws_bytes(B, C, S), dtype=torch.uint8, device=cuda)
+    res = {}
+    for tag, rows in (("h", x16), ("f", x32)):
+        out = torch.empty((B * S, C), dtype=torch.int8, device=cuda)
+        rawd = None
+        if raw:
+            half = C // 2
+            rawd = dict(out=torch.zeros((B * S, C), dtype=torch.int8, device=cuda),
+                        segs=[dict(c0=0, clen=half, oc0=0, qparams=torch.tensor([0.05, 120.0], device=cuda), grid=grid),
+                              dict(c0=half, clen=C - half, oc0=half, qparams=torch.tensor([0.07, 140.0], device=cuda), grid=grid)])
+        hip.groupnorm_silu_quant(rows, B, S, C, rows.stride(0), 32, 1e-6, gn.weight.data, gn.bias.data, silu, qp, grid, out, C, ws, raw=rawd)
+        torch.cuda.synchronize()
+        res[tag] = (out.clone(), None if rawd is None else rawd["out"].clone())
+    assert torch.equal(res["h"][0], res["f"][0])
+    if raw:
+        assert torch.equal(res["h"][1], res["f"][1]) and res["h"][1].abs().max() > 0
+
+
+@pytest.mark.parametrize("M,C", [(70, 320), (128, 640), (33, 1280)])
+def test_layernorm_fp16_rows_16_byte_lanes(cuda, M, C):
+    """ln_quant_h8: LayerNorm + three quantisers on fp16 rows with 8 halves per lane.  Against the fp32 kernel on the same
+    (widened) values: the statistics are summed in another lane order, so a code may move by one on a tie — <= 1e-3 of the
+    elements, none by more; against torch on the widened values: the bound of test_layernorm_quant_three_consumers."""
+    from qdiff import engine, hip
+    g = torch.Generator().manual_seed(8)
+    x16 = (torch.randn(M, C, generator=g) * 1.7).half()
+    x = x16.float()
+    ln = torch.nn.LayerNorm(C)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(C, generator=g))
+        ln.bias.copy_(torch.randn(C, generator=g))
+        y = ln(x)
+    params = [(0.031, 120), (0.02, 133), (0.05, 100)]
+    qps = [torch.tensor([d, float(z)], device=cuda) for d, z in params]
+    outs = {}
+    for tag, rows in (("h", x16.to(cuda)), ("f", x.to(cuda))):
+        o = [torch.empty((M, C), dtype=torch.int8, device=cuda) for _ in params]
+        hip.layernorm_quant(rows, M, C, C, ln.eps, ln.weight.data.to(cuda), ln.bias.data.to(cuda), qps, [engine.act_grid(8, False)] * 3, o, C)
+        torch.cuda.synchronize()
+        outs[tag] = o
+    for oh_, of_, (d, z) in zip(outs["h"], outs["f"], params):
+        mx, frac = _code_mismatch(oh_.cpu(), of_.cpu())
+        assert mx <= 1 and frac <= 1e-3
+        mx, frac = _code_mismatch(oh_.cpu(), R.uaq_codes(y, torch.tensor(d), z, 8, False) - 128)
+        assert mx <= 1 and frac <= 1e-3
 
 
 def test_linear_to_rows_with_fp16_residual(cuda):

@@ -481,20 +481,26 @@ def test_running_stat_updates_match_the_simulation_path(emu, name):
 
 
 def test_prepared_context_skips_the_chain_and_changes_nothing(emu, monkeypatch):
-    """QuantModel.prepare_context (cross-attention K / V^T operands once per sampling run instead of once per evaluation;
-    the reference recomputes to_k / to_v of the constant conditioning in every evaluation, quant_block.py:193-195): the
-    evaluation of the pinned tensor issues NO to_k / to_v GEMM and no head-layout quantiser, hands the attention kernel a
-    key-term table that belongs to the pinned keys (the emulator asserts it), and returns the unprepared output bit for bit —
-    for two different contexts; another tensor, an in-place modification, a quant-state flip and QDIFF_CTX_PIN=0 all fall
-    back to the per-evaluation branch."""
+    """Cross-attention K / V^T operands once per sampling run instead of once per evaluation (the reference recomputes to_k /
+    to_v of the constant conditioning in every evaluation, quant_block.py:193-195).  The evaluation of a prepared context
+    issues NO to_k / to_v GEMM and no head-layout quantiser, hands the attention kernel a key-term table that belongs to the
+    prepared keys (the emulator asserts it), and returns the unprepared output bit for bit.  Round 5: a context is recognised by
+    VALUE — a fresh tensor with the prepared bytes (plms.py:184-187 builds one per step) — two contexts stay prepared at a time
+    (least recently used evicted), and forward() prepares an unseen context by itself (QDIFF_CTX_AUTO), so that the unmodified
+    reference samplers run the chain once per run.  Changed bytes, a quant-state flip and QDIFF_CTX_PIN=0 fall back to the
+    per-evaluation branch."""
     from qdiff import hip, quant_block as qb, sampling
     fx = load_fixture("model_sd_tiny.pt")
     qnn = _resume_cpu(fx)
     x, t, c = fixture_inputs(fx, "test")
     g = torch.Generator().manual_seed(3)
-    c2 = torch.randn(c.shape, generator=g)
+    c2, c3 = torch.randn(c.shape, generator=g), torch.randn(c.shape, generator=g)
+    monkeypatch.setattr(qb, "_CTX_AUTO", False)           # first: explicit preparation only
     with torch.no_grad():
-        want, want2 = qnn(x, t, c), qnn(x, t, c2)
+        want, want2, want3 = qnn(x, t, c), qnn(x, t, c2), qnn(x, t, c3)
+        want2x = qnn(x, t, c2 * 2)
+    ckv = qnn.__dict__["_ctx_kv"]
+    assert not ckv._pins
     calls = {"heads": 0, "kterm_given": 0}
     real_qh, real_attn = hip.quantize_heads, hip.attn_i8
 
@@ -509,48 +515,106 @@ def test_prepared_context_skips_the_chain_and_changes_nothing(emu, monkeypatch):
     monkeypatch.setattr(hip, "quantize_heads", counting_qh)
     monkeypatch.setattr(hip, "attn_i8", counting_attn)
     # the library takes a table only on long key axes (LDS-staged kernel); here every eligible head dim does, so that the
-    # pinned tables travel through the host code and reach the emulator's staleness check
+    # prepared tables travel through the host code and reach the emulator's staleness check
     monkeypatch.setattr(hip, "attn_uses_keyterm", lambda d, S, asym: bool(asym) and d < 64 and d % 32 != 0)
     nblk = sum(isinstance(m, qb.QuantBasicTransformerBlock) for m in qnn.modules())
-    with torch.no_grad():
-        qnn(x, t, c)
-        per_eval = calls["heads"]
-        assert per_eval >= 2 * nblk                       # k and v^T of every cross-attention (+ ragged self-attention operands)
-        assert qnn.prepare_context(c) is True
+
+    def run(cc, expect):
         calls.update(heads=0, kterm_given=0)
-        got = qnn(x, t, c)
-        assert calls["heads"] == per_eval - 2 * nblk, calls   # the context chain did not run
-        assert 0 < calls["kterm_given"] <= nblk, calls      # cross-attentions of eligible head dims got their pinned key-term tables
-        assert torch.equal(got, want)
-        assert qnn.prepare_context(c2) is True            # re-preparation for another context
-        assert torch.equal(qnn(x, t, c2), want2)
-        calls["heads"] = 0
-        assert torch.equal(qnn(x, t, c), want) and calls["heads"] == per_eval      # not the pinned tensor: per-evaluation branch
-        c2.add_(0.0)                                      # in-place version bump: the pin no longer vouches for the bytes
-        calls["heads"] = 0
-        assert torch.equal(qnn(x, t, c2), want2) and calls["heads"] == per_eval
+        y = qnn(x, t, cc)
+        assert torch.equal(y, expect)
+        return calls["heads"]
+
+    with torch.no_grad():
+        per_eval = run(c, want)
+        assert per_eval >= 2 * nblk                       # k and v^T of every cross-attention (+ ragged self-attention operands)
+        prepared = per_eval - 2 * nblk                    # what an evaluation issues when the context chain does not run
+        assert qnn.prepare_context(c) is True
+        assert run(c, want) == prepared
+        assert 0 < calls["kterm_given"] <= nblk, calls      # cross-attentions of eligible head dims got their prepared key-term tables
+        # a FRESH tensor holding the prepared bytes — what the reference's samplers hand over at every step
+        vm = ckv.value_matches
+        assert run(c.clone(), want) == prepared and ckv.value_matches == vm + 1
+        assert run(torch.cat([c[:1], c[1:]]), want) == prepared and ckv.value_matches == vm + 2
+        # a second context takes the second slot; both stay prepared
+        assert qnn.prepare_context(c2) is True
+        assert run(c2, want2) == prepared and run(c, want) == prepared and len(ckv._pins) == 2
+        assert {e["slot"] for e in ckv._pins} == {0, 1}
+        # a third one evicts the least recently used (c2: c was used last)
+        assert qnn.prepare_context(c3) is True
+        assert run(c3, want3) == prepared and run(c, want) == prepared and len(ckv._pins) == 2
+        assert run(c2, want2) == per_eval                  # no longer prepared, automatic preparation is off: per-evaluation branch
+        # in-place edits of a prepared tensor: its version moved, so the bytes decide
+        c.add_(0.0)
+        assert run(c, want) == prepared                    # same bytes
+        c2m = c2.clone()
+        assert qnn.prepare_context(c2m) is True and run(c2m, want2) == prepared
+        c2m.mul_(2)
+        assert run(c2m, want2x) == per_eval                # other bytes: not prepared
+        # any state change drops the prepared contexts (their bytes were made by the old plans)
         qnn.prepare_context(c)
-        qnn.set_quant_state(True, True)                   # any state change drops the pin
-        calls["heads"] = 0
-        assert torch.equal(qnn(x, t, c), want) and calls["heads"] == per_eval
+        qnn.set_quant_state(True, True)
+        assert not ckv._pins and run(c, want) == per_eval
         monkeypatch.setattr(qb, "_CTX_PIN", False)
-        assert qnn.prepare_context(c) is False
+        assert qnn.prepare_context(c) is False and run(c, want) == per_eval
         monkeypatch.setattr(qb, "_CTX_PIN", True)
         # a prepared context handed to a latent batch it was not made for is refused, not read out of bounds
         assert qnn.prepare_context(c) is True
         with pytest.raises(hip.HipEngineError):
             qnn(torch.cat([x, x]), torch.cat([t, t]), c)
         qnn.release_context()
-        # the samplers announce the run's conditioning themselves
+        assert not ckv._pins
+        # ---- automatic preparation (the default): the model prepares what it has not seen -----------------------------------
+        monkeypatch.setattr(qb, "_CTX_AUTO", True)
+        runs = ckv.chain_runs
+        assert run(c, want) == per_eval and ckv.chain_runs == runs + 1          # first sight: the chain ran once, into a slot
+        assert run(c.clone(), want) == prepared and ckv.chain_runs == runs + 1
+        assert run(c2, want2) == per_eval and run(c2.clone(), want2) == prepared and run(c, want) == prepared
+        assert ckv.chain_runs == runs + 2
+        qnn.release_context()
+        # the reference's sampler loop, as plms.py:176-190 writes it: fresh concatenations at every step, no announcement
         table = sampling.StepTable(sampling.ldm_betas(0.00085, 0.0120), 4, eta=0.0)
         uc = torch.randn(c.shape, generator=g)
+        monkeypatch.setattr(qb, "_CTX_AUTO", False)
         unet = lambda xx, tt, cc=None: qnn(xx, tt, cc)
+        ref = sampling.plms_sample(unet, x, table, cond=c, uncond=uc, scale=3.0)            # every evaluation runs the chain
+        monkeypatch.setattr(qb, "_CTX_AUTO", True)
+
+        def as_script(xx, tt, cc=None):                   # guided_eps hands over its own ctx2: rebuild it as the reference does
+            return qnn(xx, tt, torch.cat([uc, c]))
+        calls["heads"] = 0
+        got = sampling.plms_sample(as_script, x, table, cond=c, uncond=uc, scale=3.0)
+        assert torch.equal(got, ref)
+        assert calls["heads"] == 5 * prepared + 2 * nblk, calls                            # 4 steps = 5 evaluations, ONE context chain
         qnn.release_context()
-        ref = sampling.plms_sample(unet, x, table, cond=c, uncond=uc, scale=3.0)            # a plain callable: nothing to prepare
+        # the samplers of this package announce the run's conditioning themselves
         calls["heads"] = 0
         got = sampling.plms_sample(qnn, x, table, cond=c, uncond=uc, scale=3.0)
         assert torch.equal(got, ref)
-        assert calls["heads"] == 5 * (per_eval - 2 * nblk) + 2 * nblk, calls                # 4 steps = 5 evaluations, ONE context chain
+        assert calls["heads"] == 5 * prepared + 2 * nblk, calls
+
+
+def test_sampling_under_inference_mode_and_value_match_of_inference_tensors(emu):
+    """tensors created under torch.inference_mode() carry no version counter (`t._version` raises); the prepared-
+    context bookkeeping and the plan caches must not touch it.  An inference tensor is recognised by value only."""
+    from qdiff import sampling
+    fx = load_fixture("model_sd_tiny.pt")
+    qnn = _resume_cpu(fx)
+    x, t, c = fixture_inputs(fx, "test")
+    table = sampling.StepTable(sampling.ldm_betas(0.00085, 0.0120), 4, eta=0.0)
+    with torch.no_grad():
+        uc = torch.randn(c.shape, generator=torch.Generator().manual_seed(5))
+        want = sampling.plms_sample(qnn, x, table, cond=c, uncond=uc, scale=2.0)
+    qnn.release_context()
+    ckv = qnn.__dict__["_ctx_kv"]
+    with torch.inference_mode():
+        ci, uci = c.clone(), uc.clone()                   # inference tensors
+        with pytest.raises(RuntimeError):
+            ci._version
+        runs = ckv.chain_runs
+        got = sampling.plms_sample(qnn, x.clone(), table, cond=ci, uncond=uci, scale=2.0)
+        assert ckv.chain_runs == runs + 1                 # prepared once, recognised at every step (by value)
+    assert torch.equal(got, want)
 
 
 @pytest.mark.parametrize("name", ["cifar_tiny", "ldm_tiny", "sd_tiny", "ldm_updown_tiny"])
@@ -666,6 +730,7 @@ def test_context_branch_fork_points(emu, monkeypatch):
     fx = load_fixture("model_sd_tiny.pt")
     x, t, c = fixture_inputs(fx, "test")
     outs, orders = {}, {}
+    monkeypatch.setattr(qb, "_CTX_AUTO", False)           # the per-evaluation branch is the subject: no automatic preparation
     for mode in ("late", "start", "attn"):
         monkeypatch.setattr(qb, "_CTX_FORK", mode)
         qnn = _resume_cpu(fx)

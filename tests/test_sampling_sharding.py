@@ -53,6 +53,22 @@ def test_generalized_steps_matches_reference():
     assert torch.equal(out, fx["out"])
 
 
+def test_device_resident_generalized_steps_match_reference():
+    """DeviceGeneralizedSteps (step counter, timestep labels and alpha products on the device: one capturable step) == the
+    reference's generalized_steps trajectory (denoising.py:10-32), bit for bit."""
+    from qdiff import sampling
+    fx = load_fixture("samplers.pt")["generalized"]
+    betas = torch.from_numpy(sampling.ddpm_betas()).float()
+    labels = []
+
+    def unet(x, t):
+        assert t.dtype == torch.float32 and t.shape == (fx["x"].shape[0],)        # float labels, as denoising.py:17 builds them
+        labels.append(float(t[0]))
+        return stub_eps(x, t)
+    out = sampling.DeviceGeneralizedSteps(unet, fx["x"], fx["seq"], betas).run()
+    assert labels == [float(i) for i in reversed(fx["seq"])] and torch.equal(out, fx["out"])
+
+
 def test_device_resident_plms_matches_reference_sampler():
     """DevicePLMS (step counter, coefficients and multistep history on the device: one capturable step) == the reference's
     PLMSSampler trajectory, bit for bit."""
@@ -95,6 +111,40 @@ def test_shard_bounds_cover_batch():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker8(rank, world, port, gb, out_dir):
+    """One of the 8 ranks of `bench.py --gpus 8`'s shard arithmetic (no model): the full-batch noise drawn on every rank and
+    sliced, a rank-dependent "sampler", the all_gather of the results."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from qdiff import sampling
+    x = sampling.sharded_noise((gb, 4, 8, 8), seed=0, world_size=world, rank=rank, device=torch.device("cpu"))
+    lo, hi = sampling.shard_bounds(gb, world, rank)
+    assert x.shape[0] == hi - lo
+    y = x * 2 + 1                                               # stands in for the (sample-independent) sampler
+    full = sampling.gather_samples(y, gb)
+    t = torch.tensor([float(hi - lo)])
+    dist.all_reduce(t)
+    if rank == 0:
+        torch.save({"full": full, "count": int(t.item())}, os.path.join(out_dir, "g8.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gb", [64, 61])
+def test_eight_rank_shard_arithmetic_gloo(tmp_path, gb):
+    """the exact `--gpus 8` partitioning (batch 64 -> 8 per GPU; 61 = ragged shards) with
+    eight gloo ranks: every rank draws the full-batch x_T and keeps its slice, the gathered result equals the single-process
+    one bit for bit, and the shards cover the batch exactly once."""
+    import torch.multiprocessing as mp
+    from qdiff import sampling
+    port = _free_port()
+    mp.spawn(_worker8, args=(8, port, gb, str(tmp_path)), nprocs=8, join=True)
+    got = torch.load(os.path.join(str(tmp_path), "g8.pt"))
+    single = sampling.sharded_noise((gb, 4, 8, 8), seed=0, world_size=1, rank=0, device=torch.device("cpu"))
+    assert got["count"] == gb and torch.equal(got["full"], single * 2 + 1)
 
 
 def _free_port():
