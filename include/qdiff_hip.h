@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 18
+#define QD_ABI_VERSION 19
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -327,6 +327,9 @@ int qd_geglu_quant(const void* h, int h_dtype, int64_t M, int F, int64_t ldh,
  *           order; ktab 0 = ignore kterm (constant-operand MFMAs, A/B runs); lean 0 = attn_kernel for every head dim, 1 = lean /
  *           LDS-staged kernels for d < 64 (default), 3 = also d = 80 on the lean kernel (measured slower).  Initial values:
  *           QD_ATTN_PIPE / QD_ATTN_XCD / QD_ATTN_KTAB / QD_ATTN_LEAN, read once.
+ *     qd_attn_sync (ABI v19): tiles per block-wide rendezvous of the LDS-staged kernel: 2 (default; QD_ATTN_SYNC) = the four
+ *           waves of a block meet every second 32-key tile and prefetch two tiles per meeting (8-stage ring), 1 = round 3's
+ *           one-barrier-per-tile schedule (4-stage ring).  Same arithmetic in the same order: bit-identical results.
  * ------------------------------------------------------------------------------------------ */
 int qd_quantize_heads(const void* x, int x_dtype, int B, int T, int H, int d,
                       int64_t sb, int64_t st, int64_t sh, int64_t sd, float prescale,
@@ -336,6 +339,7 @@ int qd_quantize_heads(const void* x, int x_dtype, int B, int T, int H, int d,
 int qd_attn_uses_keyterm(int d, int S, int q_asym);
 int qd_attn_keyterm(const int8_t* k, int BH, int Spad, int dpad, const float* prm, int32_t* kterm, void* stream);
 void qd_attn_config(int pipe_mode, int xcd, int ktab, int lean);
+void qd_attn_sync(int tiles_per_rendezvous);
 int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt,
                const int32_t* qsum, const int32_t* kterm, const int32_t* vsum,
                int BH, int H, int T, int S, int d, int Tpad, int Spad, int dpad,

@@ -679,12 +679,19 @@ template <int N>
 __device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void attn_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int DT, bool P16, int KT>
+// SE (round 5): tiles per block-wide rendezvous.  SE = 1 is round 3's schedule (one s_barrier per 32-key tile: 256 per sweep pair
+// at 4096 keys; the counters charge 0.21 of the wave cycles to s_waitcnt / s_barrier, profiles/r04_pmc_attn_table.txt).  SE = 2:
+// the ring holds 8 tile stages, the waves meet every SECOND tile (in the even iterations of the two-tile software pipeline) and
+// prefetch two tiles per meeting — half the barriers, the same DMA instructions, the same arithmetic in the same order
+// (bit-identical: tests/test_hip_kernels.py::test_attention_lds_equals_lean runs both).
+template <int DT, bool P16, int KT, int SE>
 __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
     // a*b+c written as such stays unfused: hipcc's default -ffp-contract=fast lets the optimiser fuse (or not) depending on the
     // surrounding code, and the lean and the LDS-staged bodies must produce the same normaliser bit for bit
 #pragma clang fp contract(off)
-    constexpr int NST = 4;                                    // ring stages (tiles): jt+1 in use, jt+2 landed / landing, jt+3 issued
+    static_assert(SE == 1 || SE == 2, "tiles per rendezvous");
+    constexpr int NST = 4 * SE;                               // ring stages (tiles).  SE = 1: jt+1 in use, jt+2 landed / landing, jt+3 issued
+    constexpr int PD = SE == 1 ? NST - 1 : 6;                 // prefetch distance (tiles ahead of the iteration that issues them)
     constexpr int KB = 1024 * DT, VB = 1024 * DT;             // K tile: 32 keys x dpad bytes; V^T tile: dpad rows x 32 keys
     constexpr int TB = KT == 2 ? 128 : 0;                     // the tile's 32 accumulator seeds (per-key zero-point term, qd_attn_keyterm)
     constexpr int STAGE = KB + VB + TB;
@@ -802,18 +809,23 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
     auto prologue = [&](bool with_v) __attribute__((always_inline)) {
         __syncthreads();                                      // nobody still reads the ring of the previous sweep / pass
 #pragma unroll
-        for (int j = 0; j < NST - 1; ++j) issue(j, with_v);
-        attn_wait_vmcnt<NST - 2>();
+        for (int j = 0; j < PD; ++j) issue(j, with_v);
+        attn_wait_vmcnt<PD - 1>();                            // (wave 3 issues two copies per tile: it over-waits, which is safe)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");                        // no LDS read of the new tiles is hoisted above the barrier
     };
-    // head of iteration jt: tile jt+1 landed for every wave, the stage of tile jt-1 is free -> tile jt+NST-1 goes there
-    auto step_sync = [&](int jt, bool with_v) __attribute__((always_inline)) {
-        attn_wait_vmcnt<NST - 3>();
+    // SE = 1, head of iteration jt: tile jt+1 landed for every wave, the stage of tile jt-1 is free -> tile jt+NST-1 goes there.
+    // SE = 2, head of the EVEN iterations only: iterations jt and jt+1 read K of tiles jt+1, jt+2 and V^T of jt, jt+1 — tiles up to
+    // jt+2 must have landed for every wave (three later ones may be in flight); every wave is past iteration jt-1, i.e. tiles
+    // <= jt-1 are consumed, so tiles jt+6 and jt+7 may overwrite the stages of jt-2 and jt-1.
+    auto step_sync = [&](int jt, bool with_v, bool even) __attribute__((always_inline)) {
+        if (SE == 2 && !even) return;
+        attn_wait_vmcnt<SE == 1 ? NST - 3 : 3>();
         attn_wait_lgkm0();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue(jt + NST - 1, with_v);
+        issue(jt + PD, with_v);
+        if (SE == 2) issue(jt + PD + 1, with_v);
     };
 
     // ---- sweep 1 ----------------------------------------------------------------------------------------------------
@@ -847,7 +859,7 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
             auto s1_iter = [&](int jt, auto par_tag, auto tail_tag) __attribute__((always_inline)) {
                 constexpr int C = decltype(par_tag)::value, N = 1 - C;
                 constexpr bool tail = decltype(tail_tag)::value;
-                step_sync(jt, false);
+                step_sync(jt, false, C == 0);
                 read_k(jt + 1, kf);
                 read_t(jt + 1, ti);
                 if (tail) {
@@ -943,7 +955,7 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
             constexpr int C = decltype(par_tag)::value, N = 1 - C;
             constexpr bool tail = decltype(tail_tag)::value, CLAMP = decltype(clamp_tag)::value, HI = decltype(hi_tag)::value;
             constexpr int NPV = DT * (HI ? 2 : 1);
-            step_sync(jt, true);
+            step_sync(jt, true, C == 0);
             read_v(jt, vfr[C]);
             read_k(jt + 1, kf);
             read_t(jt + 1, ti);
@@ -1057,9 +1069,10 @@ __global__ __launch_bounds__(256) void attn_keyterm_rows_kernel(const int8_t* __
 
 // kt: 0 = symmetric q (no per-key term), 1 = constant-operand MFMAs, 2 = key-term table (AttnK::kterm)
 template <int DT>
-int launch_lds(const AttnK& k, bool p16, int kt, hipStream_t st) {
+int launch_lds(const AttnK& k, bool p16, int kt, int se, hipStream_t st) {
     dim3 grid((unsigned)(k.gx * k.BH));
-#define QD_LDS_CASE(P, K) if (p16 == P && kt == K) hipLaunchKernelGGL((attn_lds_kernel<DT, P, K>), grid, dim3(256), 0, st, k);
+#define QD_LDS_CASE(P, K) if (p16 == P && kt == K) { if (se == 2) hipLaunchKernelGGL((attn_lds_kernel<DT, P, K, 2>), grid, dim3(256), 0, st, k); \
+                                                     else hipLaunchKernelGGL((attn_lds_kernel<DT, P, K, 1>), grid, dim3(256), 0, st, k); }
     QD_LDS_CASE(true, 0) QD_LDS_CASE(true, 1) QD_LDS_CASE(true, 2) QD_LDS_CASE(false, 0) QD_LDS_CASE(false, 1) QD_LDS_CASE(false, 2)
 #undef QD_LDS_CASE
     return 0;
@@ -1105,11 +1118,11 @@ int launch_dt(const AttnK& k, bool p16, bool asym, hipStream_t st) {
 
 // Run-time knobs of the attention launcher: read from the environment ONCE (first call), changed afterwards only through
 // qd_attn_config (tests and A/B runs flip the kernel choice inside one process).
-struct AttnKnobs { int lean, pipe, xcd, ktab; };
+struct AttnKnobs { int lean, pipe, xcd, ktab, sync; };
 static AttnKnobs& attn_knobs() {
     static AttnKnobs k = [] {
         auto env = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
-        return AttnKnobs{env("QD_ATTN_LEAN", 1), env("QD_ATTN_PIPE", 2), env("QD_ATTN_XCD", 1), env("QD_ATTN_KTAB", 1)};
+        return AttnKnobs{env("QD_ATTN_LEAN", 1), env("QD_ATTN_PIPE", 2), env("QD_ATTN_XCD", 1), env("QD_ATTN_KTAB", 1), env("QD_ATTN_SYNC", 2)};
     }();
     return k;
 }
@@ -1129,6 +1142,10 @@ extern "C" void qd_attn_config(int pipe_mode, int xcd, int ktab, int lean) {
     if (xcd >= 0) k.xcd = xcd;
     if (ktab >= 0) k.ktab = ktab;
     if (lean >= 0) k.lean = lean;
+}
+
+extern "C" void qd_attn_sync(int tiles_per_rendezvous) {
+    if (tiles_per_rendezvous == 1 || tiles_per_rendezvous == 2) attn_knobs().sync = tiles_per_rendezvous;
 }
 
 // the table pays where the LDS-staged kernel runs (thousands of keys); the register-fed kernel on short key axes (the 77
@@ -1181,8 +1198,9 @@ extern "C" int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt, co
         const int kt = !asym ? 0 : (kterm && qd_attn_uses_keyterm(d, S, q_asym)) ? 2 : 1;     // per-key zero-point term: none / constant-operand MFMAs / table
         const bool lds_fits = dpad <= 64 && Spad <= QD_ONES_ROW && (long)Spad * dpad < (1L << 31);
         if (lds_fits && (kn.pipe == 3 || (kn.pipe == 2 && S >= 512))) {         // short key axes: ring start-up and barriers lose
-            if (dpad == 32) launch_lds<1>(a, p16, kt, st);
-            else launch_lds<2>(a, p16, kt, st);
+            const int se = kn.sync == 1 ? 1 : 2;
+            if (dpad == 32) launch_lds<1>(a, p16, kt, se, st);
+            else launch_lds<2>(a, p16, kt, se, st);
         } else if (dpad == 32) launch_lean<1>(a, p16, kt, st);
         else if (dpad == 64) launch_lean<2>(a, p16, kt, st);
         else launch_lean<3>(a, p16, kt, st);

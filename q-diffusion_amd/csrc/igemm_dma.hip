@@ -883,7 +883,9 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
                         }
                         if (gn) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
+                            // (explicit fma: the 4- and the 8-column forms must round alike — left to the optimiser, one is
+                            //  packed into v_pk_mul + v_pk_add and the other contracted)
+                            for (int e = 0; e < 4; ++e) { gs[e] += v[e]; gq[e] = __builtin_fmaf(v[e], v[e], gq[e]); }
                         }
                     }
                 }
@@ -968,17 +970,19 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
                 tb[rl * 64 + 32 + pc] = __float_as_uint(v1);
             }
             __builtin_amdgcn_sched_barrier(0);
-            v4i rs[4];
-            long mrow[4];
 #pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                const long m = m0 + rbase + ps * 8 + rr0;
-                mrow[ps] = m < p.M ? m : m0;
-                if (has_res) rs[ps] = *reinterpret_cast<const v4i*>(rh + mrow[ps] * p.ldr + n8c);
+            for (int pb = 0; pb < 4; pb += 2) {        // two passes at a time: their residual loads in flight together, 8 registers
+            v4i rs[2];
+            long mrow[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const long m = m0 + rbase + (pb + u) * 8 + rr0;
+                mrow[u] = m < p.M ? m : m0;
+                if (has_res) rs[u] = *reinterpret_cast<const v4i*>(rh + mrow[u] * p.ldr + n8c);
             }
 #pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                const int rl = ps * 8 + rr0;
+            for (int u = 0; u < 2; ++u) {
+                const int rl = (pb + u) * 8 + rr0;
                 const bool mok = m0 + rbase + rl < p.M;
                 v4f lo = *reinterpret_cast<const v4f*>(tb + rl * 64 + rd_lo);
                 v4f hi = *reinterpret_cast<const v4f*>(tb + rl * 64 + rd_hi);
@@ -989,21 +993,22 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
                 }
                 if (has_res) {
                     v4f a, b;
-                    qd_h8_to_f(rs[ps], a, b);
+                    qd_h8_to_f(rs[u], a, b);
                     lo += a; hi += b;
                 }
                 if (mok && nok8) {
                     const v4i pk = {(int)qd_pack2h(lo[0], lo[1]), (int)qd_pack2h(lo[2], lo[3]),
                                     (int)qd_pack2h(hi[0], hi[1]), (int)qd_pack2h(hi[2], hi[3])};
-                    *reinterpret_cast<v4i*>(oh + mrow[ps] * p.ldo + n8) = pk;
+                    *reinterpret_cast<v4i*>(oh + mrow[u] * p.ldo + n8) = pk;
                     if (gn) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            gs[e] += lo[e]; gq[e] += lo[e] * lo[e];
-                            gs[4 + e] += hi[e]; gq[4 + e] += hi[e] * hi[e];
+                            gs[e] += lo[e]; gq[e] = __builtin_fmaf(lo[e], lo[e], gq[e]);
+                            gs[4 + e] += hi[e]; gq[4 + e] = __builtin_fmaf(hi[e], hi[e], gq[4 + e]);
                         }
                     }
                 }
+            }
             }
         }
         if (gn) {
@@ -1028,25 +1033,14 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
     bool lines16 = false;
     if constexpr (H16_OUT && !BF) lines16 = p.vec == 2;
     if (lines16) {
-        // tile 0 of this wave starts in the UPPER half of a 128-byte line (n0 / the wave's column offset is an odd multiple
-        // of 32 columns: every other block of the 160-wide tiles, wave column 1 of the 128 x 320 tile): it goes alone and
-        // the pairs start at tile 1, so that every pair is one aligned line (row strides are multiples of 64 columns for
-        // every SD width; where they are not — 224-wide LDM rows — pairs are still 128 contiguous bytes)
-#ifdef QD_F16_NOODD           // measurement-only build: pairs always start at tile 0 (half of the code, pairs of odd blocks straddle two lines)
-        const bool odd = false;
-#else
-        const bool odd = __builtin_amdgcn_readfirstlane((int)((reinterpret_cast<uintptr_t>(oh + (long)m0 * p.ldo + wcol0) >> 6) & 1)) != 0;
-#endif
-        if (odd) {
-            single(0);
+        // Pairs start at tile 0 whatever the alignment.  Where the wave's first column is an odd multiple of 32 (every other
+        // block of the 160-wide tiles, wave column 1 of the 128 x 320 tile) a pair straddles two lines — two half-line
+        // requests, what the 4-halves form issues everywhere.  The variant that peels tile 0 on those waves (every pair one
+        // aligned line) was measured SLOWER: 19.33 vs 18.98 ms per SD step (profiles/r05_streams_ab.md) — a second copy of
+        // the epilogue with other accumulator indices, 62 -> 109 spilled registers on the MT = 2 tiles.
 #pragma unroll
-            for (int q = 0; q < (NT - 1) / 2; ++q) pair(1 + 2 * q);
-            if constexpr ((NT - 1) % 2 == 1) single(NT - 1);
-        } else {
-#pragma unroll
-            for (int q = 0; q < NT / 2; ++q) pair(2 * q);
-            if constexpr (NT % 2 == 1) single(NT - 1);
-        }
+        for (int q = 0; q < NT / 2; ++q) pair(2 * q);
+        if constexpr (NT % 2 == 1) single(NT - 1);
     } else {
 #pragma unroll
         for (int j = 0; j < NT; ++j) single(j);
@@ -1154,42 +1148,6 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const int32_t* __r
         if (residual) v += __half2float(residual[m * ldr + n]);
         out[m * ldo + n] = __float2half(v);
     }
-}
-
-// the same pass for fp16 rows with 8-element-aligned strides: thread = 8 consecutive outputs of one row (two 16-byte loads per
-// slice, one 16-byte store instead of eight 2-byte ones).  Same integer sum, same float sequence per element.
-__global__ __launch_bounds__(256) void splitk_finalize_h8_kernel(const int32_t* __restrict__ part, int nsplit, long MN, int Cout, int HoWo,
-                                                                 const float* __restrict__ scale, const int* __restrict__ zc,
-                                                                 const int* __restrict__ zw, const int* __restrict__ zfill,
-                                                                 const float* __restrict__ bias, const float* __restrict__ rowbias, long ldrb,
-                                                                 const __half* __restrict__ residual, long ldr, __half* __restrict__ out, long ldo) {
-    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
-    if (e >= MN) return;
-    const long m = e / Cout;
-    const int  n = (int)(e - m * Cout);
-    int I[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int s = 0; s < nsplit; ++s) {
-        const v4i a = *reinterpret_cast<const v4i*>(part + (long)s * MN + e), b = *reinterpret_cast<const v4i*>(part + (long)s * MN + e + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { I[j] += a[j]; I[4 + j] += b[j]; }
-    }
-    const int kz = zfill ? zfill[1] : 0;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int Ij = I[j] - (zc ? zc[n + j] : 0) + (zw ? zw[n + j] : 0) * kz;
-        v[j] = (float)Ij * scale[n + j];
-        v[j] += bias ? bias[n + j] : 0.f;
-        if (rowbias) v[j] += rowbias[(m / HoWo) * ldrb + n + j];
-    }
-    if (residual) {
-        float r[8];
-        qd_ld8h(residual + m * ldr + n, r);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += r[j];
-    }
-    const v4i pk = {(int)qd_pack2h(v[0], v[1]), (int)qd_pack2h(v[2], v[3]), (int)qd_pack2h(v[4], v[5]), (int)qd_pack2h(v[6], v[7])};
-    *reinterpret_cast<v4i*>(out + m * ldo + n) = pk;
 }
 
 // tile-ordered s8 packer: thread = one 16-byte unit (row n, 16 consecutive K), stored byte = W - 128
@@ -1406,11 +1364,9 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
         const SegD& sg = k.seg[0];
         const long MN = M * N;
         dim3 grid((unsigned)((MN + 255) / 256)), block(256);
-        if (d->out_dtype == QD_F16 && f16_lines && N % 8 == 0 && d->ldo % 8 == 0 && qd_aligned(k.out, 16) &&
-            (!k.residual || (d->ldr % 8 == 0 && qd_aligned(k.residual, 16))))
-            hipLaunchKernelGGL(splitk_finalize_h8_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), block, 0, st, k.iout, nsplit, MN, N, d->Ho * d->Wo, sg.scale, sg.zc, sg.zw,
-                               sg.zfill, k.bias, k.rowbias, k.ldrb, (const __half*)k.residual, k.ldr, (__half*)k.out, k.ldo);
-        else if (d->out_dtype == QD_F16)
+        // (an 8-outputs-per-thread form of this pass for fp16 rows was measured +15 us per launch: the pass is bound by its
+        //  nsplit int32 reads per output, of which the one-output-per-thread form keeps eight times more in flight)
+        if (d->out_dtype == QD_F16)
             hipLaunchKernelGGL(splitk_finalize_kernel<__half>, grid, block, 0, st, k.iout, nsplit, MN, N, d->Ho * d->Wo, sg.scale, sg.zc, sg.zw,
                                sg.zfill, k.bias, k.rowbias, k.ldrb, (const __half*)k.residual, k.ldr, (__half*)k.out, k.ldo);
         else

@@ -64,7 +64,7 @@ EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_make_qparams",
            "qd_pack_weights_t8",
            "qd_conv2d_i8", "qd_conv2d_i8_splitk_ws_bytes",
            "qd_conv2d_i8_acc", "qd_groupnorm_ws_bytes", "qd_groupnorm_silu_quant", "qd_groupnorm_mod_silu_quant", "qd_layernorm_quant",
-           "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8", "qd_attn_keyterm", "qd_attn_uses_keyterm", "qd_attn_config", "qd_bmm_qk_i8", "qd_bmm_pv_i8", "qd_temb_mlp",
+           "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8", "qd_attn_keyterm", "qd_attn_uses_keyterm", "qd_attn_config", "qd_attn_sync", "qd_bmm_qk_i8", "qd_bmm_pv_i8", "qd_temb_mlp",
            "qd_fakequant_blocks", "qd_fakequant_fwd", "qd_fakequant_bwd",
            "qd_conv2d_bf16", "qd_pack_weights_bf16_bytes", "qd_pack_weights_bf16", "qd_groupnorm_silu_bf16",
            "qd_pack_weights_h16", "qd_groupnorm_silu_h16"]
@@ -124,8 +124,13 @@ def load():
     lib.qd_groupnorm_silu_bf16.argtypes = [vp, i64, i64, i32, i64, i32, f32, vp, vp, i32, vp, i64, vp, vp, i32, i64, vp]
     lib.qd_pack_weights_h16.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     lib.qd_groupnorm_silu_h16.argtypes = [vp, i64, i64, i32, i64, i32, f32, vp, vp, i32, i32, vp, i64, vp, vp, i32, i64, vp]
-    if lib.qd_abi_version() != 18:
+    ver = lib.qd_abi_version()
+    # QDIFF_HIP_LIB may name an older build for A/B measurements (v18 = round 4: everything but qd_attn_sync)
+    if ver != 19 and not (ver == 18 and os.environ.get("QDIFF_HIP_LIB")):
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
+    if ver >= 19:
+        lib.qd_attn_sync.argtypes = [i32]
+        lib.qd_attn_sync.restype = None
     _lib = lib
     return lib
 
@@ -459,8 +464,10 @@ def attn_keyterm(k, BH, Spad, dpad, prm, kterm=None):
     return kterm
 
 
-def attn_config(pipe_mode=-1, xcd=-1, ktab=-1, lean=-1):
+def attn_config(pipe_mode=-1, xcd=-1, ktab=-1, lean=-1, sync=-1):
     load().qd_attn_config(int(pipe_mode), int(xcd), int(ktab), int(lean))
+    if sync in (1, 2):
+        load().qd_attn_sync(int(sync))
 
 
 def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, wmax, q_asym, out, ldo,

@@ -364,20 +364,38 @@ class QuantModel(nn.Module):
         if not torch.is_grad_enabled() and not self.model.training and not capturing:
             tok = self._state_token()
         entry = None
+        graphs = self._graphs is not None and tok >= 0 and cuda and torch.is_tensor(timesteps)
+        if graphs:
+            from .graph import GraphedUNet, signature
+            if self._graph_tok != tok:                     # plans were rebuilt: the captured pointers are stale
+                self._graphs.clear()
+                self._graph_seen.clear()
+                self._graph_tok = tok
         if tok >= 0 and ckv is not None and torch.is_tensor(context) and qb._CTX_PIN:
             # the run's conditioning: prepared before (same tensor, or the same BYTES in a fresh tensor), or prepared now
-            entry = ckv.match(context)
+            entry = ckv.match(context, by_value=False)
+            if entry is None and graphs and qb._CTX_SPECULATE:
+                # a fresh tensor right after one that matched by value: replay the prepared graph speculatively, verify behind it
+                cand = ckv.speculation_candidate(context)
+                g = self._graphs.get(signature(x, timesteps, context) + (engine.STREAM_DTYPE, cand["slot"])) if cand is not None else None
+                if g is not None:
+                    cmp = ckv.compare_async(context, cand)
+                    ckv.select(cand, context)
+                    try:
+                        y = g(x, timesteps, context).to(x.dtype, copy=True)
+                    finally:
+                        ckv.select(None, None)
+                    if ckv.compare_result(cmp, context, cand):
+                        return y
+                    del y                                  # a new prompt: the guess was wrong, the ordinary path follows
+            if entry is None:
+                entry = ckv.match(context)
             if entry is None and qb._CTX_AUTO:
                 entry = self._prepare(context)
         if ckv is not None:
             ckv.select(entry, context)
         try:
-            if self._graphs is not None and tok >= 0 and cuda and torch.is_tensor(timesteps):
-                from .graph import GraphedUNet, signature
-                if self._graph_tok != tok:                 # plans were rebuilt: the captured pointers are stale
-                    self._graphs.clear()
-                    self._graph_seen.clear()
-                    self._graph_tok = tok
+            if graphs:
                 key = signature(x, timesteps, context) + (engine.STREAM_DTYPE, None if entry is None else entry["slot"])
                 g = self._graphs.get(key)
                 if g is None:

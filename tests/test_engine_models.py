@@ -236,13 +236,44 @@ def test_hip_graph_replay_equals_eager(cuda, name):
     assert torch.equal(e1, g1) and torch.equal(e2, g2) and torch.equal(g1, g1b)
 
 
-def test_prepared_context_changes_nothing(cuda):
-    """QuantModel.prepare_context on the GPU: the evaluation of a prepared context (cross-attention K / V^T operands and
-    key-term tables computed once, reference quant_block.py:193-195 recomputes them per evaluation) equals the per-evaluation
-    computation bit for bit — eager and as a HIP graph, for two different contexts, with the graph captured for the first
-    one replayed after re-preparation for the second, and with an unprepared tensor falling back to the ordinary graph."""
+def test_prepared_context_under_the_fp16_stream(cuda):
+    """the preparation runs outside an evaluation, where engine._EFFECTIVE is unset — it must quantise the rows the
+    evaluation's own branch would (this model's stream verdict), so that prepared == per-evaluation, bit for bit, also with
+    QDIFF_STREAM=fp16."""
+    from qdiff import engine, quant_block as qb
     fx = load_fixture("model_sd_tiny.pt")
     qnn = _resume(fx, cuda)
+    qnn.enable_hip_graphs(False)
+    x, t, c = (a.to(cuda) for a in fixture_inputs(fx, "test"))
+    engine.set_stream_dtype(torch.float16)
+    try:
+        with torch.no_grad():
+            qb._CTX_AUTO, auto = False, qb._CTX_AUTO
+            try:
+                want = qnn(x, t, c).clone()               # per-evaluation branch
+            finally:
+                qb._CTX_AUTO = auto
+            ckv = qnn.__dict__["_ctx_kv"]
+            assert qnn.prepare_context(c) and engine._EFFECTIVE[0] is None
+            runs = ckv.chain_runs
+            got = qnn(x, t, c.clone()).clone()
+            assert ckv.chain_runs == runs
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+    finally:
+        engine.set_stream_dtype(torch.float32)
+
+
+def test_prepared_context_changes_nothing(cuda, monkeypatch):
+    """QuantModel.prepare_context on the GPU: the evaluation of a prepared context (cross-attention K / V^T operands and
+    key-term tables computed once, reference quant_block.py:193-195 recomputes them per evaluation) equals the per-evaluation
+    computation bit for bit — eager and as a HIP graph, for two different contexts (two slots since round 5: each with the
+    graph captured for it), and with an unprepared tensor falling back to the ordinary graph (automatic preparation off)."""
+    from qdiff import quant_block as qb
+    fx = load_fixture("model_sd_tiny.pt")
+    qnn = _resume(fx, cuda)
+    monkeypatch.setattr(qb, "_CTX_AUTO", False)           # explicit preparation is the subject
+    qnn.enable_hip_graphs(False)
     x, t, c = (a.to(cuda) for a in fixture_inputs(fx, "test"))
     g = torch.Generator(device=cuda).manual_seed(11)
     c2 = torch.randn(c.shape, device=cuda, generator=g)
@@ -255,18 +286,18 @@ def test_prepared_context_changes_nothing(cuda):
         runs = ckv.chain_runs
         got_eager = run(x, c)
         qnn.enable_hip_graphs(True)
-        g1 = run(x, c)                       # captures the prepared evaluation
+        g1 = run(x, c)                       # captures the prepared evaluation (slot 0)
         g2 = run(x2, c)                      # replays it
         assert ckv.chain_runs == runs, "a prepared context ran the to_k / to_v chain"
         u1 = run(x, c2)                      # c2 is not prepared: the ordinary graph (context copied in, chain inside)
         assert ckv.chain_runs > runs
-        assert qnn.prepare_context(c2)       # pinned buffers rewritten in place
+        assert qnn.prepare_context(c2)       # second slot
         runs = ckv.chain_runs
-        g3 = run(x, c2)                      # the prepared graph again, new operands
+        g3 = run(x, c2)                      # the prepared evaluation of slot 1: its own graph
         g4 = run(x2, c2)
         assert ckv.chain_runs == runs
-        u2 = run(x2, c)                      # c no longer prepared
-        assert len(qnn._graphs) == 2
+        u2 = run(x2, c.clone())              # c is still prepared (slot 0), recognised by value: its graph replays
+        assert ckv.chain_runs == runs and len(qnn._graphs) == 3
         qnn.enable_hip_graphs(False)
     torch.cuda.synchronize()
     which = lambda y: [k for k, w in want.items() if torch.equal(y, w)]
@@ -301,10 +332,12 @@ def test_default_graph_replay_and_value_matched_context(cuda, monkeypatch):
         runs = ckv.chain_runs
         got = [qnn(xx, t, c.clone()).clone() for xx in xs]          # a fresh context tensor per call
         assert ckv.chain_runs == runs + 1 and ckv.value_matches >= len(xs) - 1 and len(qnn._graphs) == 1
+        assert ckv.__dict__.get("speculation_misses", 0) == 0      # calls 3.. replayed speculatively, verified behind the graph
         y_id = qnn(xs[1], t, c).clone()                              # the same bytes through another object ...
         y_id2 = qnn(xs[1], t, c).clone()                             # ... which is then recognised by identity
         got2 = [qnn(xx, t, c2.clone()).clone() for xx in xs]        # second prompt: second slot, its own graph
         assert ckv.chain_runs == runs + 2 and len(qnn._graphs) == 2 and len(ckv._pins) == 2
+        assert ckv.__dict__.get("speculation_misses", 0) == 1      # the new prompt's first call: one wasted replay, the right result
         back = qnn(xs[2], t, c.clone()).clone()                      # the first prompt is still prepared
         assert ckv.chain_runs == runs + 2
         torch.cuda.synchronize()

@@ -786,15 +786,17 @@ def test_attention_lds_equals_lean(cuda, case):
     try:
         # pipe 0: attn_lean_kernel, 3: attn_lds_kernel on every eligible shape; ktab 1: per-key zero-point term from the
         # qd_attn_keyterm table (accumulator seeds), 0: from constant-operand MFMAs — the accumulators hold the same integers
-        for mode in (0, 3):
+        # sync (round 5): tiles per block-wide rendezvous of the LDS-staged kernel — 1 = one barrier per tile (4-stage ring),
+        # 2 = one per two tiles (8-stage ring, two tiles prefetched per meeting): the same arithmetic in the same order
+        for mode, sync in ((0, 2), (3, 1), (3, 2)):
             for ktab in (1, 0):
-                hip.attn_config(pipe_mode=mode, ktab=ktab, lean=3 if d >= 64 else 1)
+                hip.attn_config(pipe_mode=mode, ktab=ktab, lean=3 if d >= 64 else 1, sync=sync)
                 o = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d)
                 torch.cuda.synchronize()
-                outs[(mode, ktab)] = o.clone()
+                outs[(mode, sync, ktab)] = o.clone()
     finally:
-        hip.attn_config(pipe_mode=2, ktab=1, lean=1)
-    ref = outs[(0, 1)]
+        hip.attn_config(pipe_mode=2, ktab=1, lean=1, sync=2)
+    ref = outs[(0, 2, 1)]
     assert torch.isfinite(ref).all() and ref.abs().max() > 0
     for key, o in outs.items():
         assert torch.equal(ref, o), (key, (ref - o).abs().max().item())

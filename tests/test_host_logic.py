@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     from qdiff import hip
     assert sorted(hip.EXPORTS) == declared
     lib.qd_abi_version.restype = ctypes.c_int
-    assert lib.qd_abi_version() == 18
+    assert lib.qd_abi_version() == 19
     assert lib.qd_device_ok() in (0, 1)                  # no compute calls without a GPU
 
 
