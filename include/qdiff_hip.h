@@ -118,6 +118,25 @@ typedef struct {
                                 or NULL (= zeros)                                                  */
 } qd_conv_seg;
 
+/* LayerNorm fused into the epilogue (ABI v19; qd_conv_desc.ln): the Linear's output row (after bias and residual, as stored:
+ * rounded to fp16 when out_dtype = QD_F16) is layer-normalised over its Cout = 320 columns and quantised with up to three
+ * activation quantisers — `norm2(x)` -> to_q's input codes, `norm3(x)` -> the GEGLU projection's, `norm1(x)` -> to_q / to_k /
+ * to_v's (ldm/modules/attention.py:229-231, qdiff/quant_block.py:193-199) — in the launch that produces the row: the
+ * separate qd_layernorm_quant pass over the fp32 tensor disappears.  Needs w_tiled, one segment, QD_EPI_LINEAR, Cout == 320
+ * (a 128 x 320 tile whose waves own whole rows), no split-K.  Codes are those of qd_layernorm_quant on the stored rows,
+ * bit for bit (both reduce a row in the same order: eight lanes x 40 columns, butterfly over the lanes). */
+typedef struct {
+    const float*   gamma;    /* [Cout] */
+    const float*   beta;     /* [Cout] */
+    float          eps;
+    int32_t        nout;     /* 1..3 */
+    const float*   qparams[3];
+    int32_t        qmin[3], qmax[3], off[3];
+    int32_t        _pad;
+    int8_t*        out[3];   /* [M][ldo] int8 rows, one per quantiser */
+    int64_t        ldo;
+} qd_ln_fuse;
+
 typedef struct {
     const int8_t*  x;        /* [B][H][W][ldx] stored activation bytes                            */
     const uint8_t* w;        /* MFMA-tile-ordered weights of qd_pack_weights_t4 (wbits=4) / _t8 (wbits=8) */
@@ -172,6 +191,7 @@ typedef struct {
      * replication happens in the im2col source address, no up-sampled tensor exists.  Needs stride 1, kh*kw > 1, even H, W. */
     int32_t        upsample2x;
     int32_t        _pad3;
+    const qd_ln_fuse* ln;    /* optional (ABI v19): LayerNorm + quantisers of the output rows in the epilogue, see qd_ln_fuse */
 } qd_conv_desc;
 
 int qd_conv2d_i8(const qd_conv_desc* d, void* stream);
@@ -327,9 +347,10 @@ int qd_geglu_quant(const void* h, int h_dtype, int64_t M, int F, int64_t ldh,
  *           order; ktab 0 = ignore kterm (constant-operand MFMAs, A/B runs); lean 0 = attn_kernel for every head dim, 1 = lean /
  *           LDS-staged kernels for d < 64 (default), 3 = also d = 80 on the lean kernel (measured slower).  Initial values:
  *           QD_ATTN_PIPE / QD_ATTN_XCD / QD_ATTN_KTAB / QD_ATTN_LEAN, read once.
- *     qd_attn_sync (ABI v19): tiles per block-wide rendezvous of the LDS-staged kernel: 2 (default; QD_ATTN_SYNC) = the four
- *           waves of a block meet every second 32-key tile and prefetch two tiles per meeting (8-stage ring), 1 = round 3's
- *           one-barrier-per-tile schedule (4-stage ring).  Same arithmetic in the same order: bit-identical results.
+ *     qd_attn_sync (ABI v19): tiles per block-wide rendezvous of the LDS-staged kernel: 1 (default; QD_ATTN_SYNC) = round 3's
+ *           one-barrier-per-tile schedule (4-stage ring), 2 = the four waves of a block meet every second 32-key tile and
+ *           prefetch two tiles per meeting (8-stage ring).  Same arithmetic in the same order: bit-identical results;
+ *           measured equal in time (profiles/r05_attn_rendezvous.md).
  * ------------------------------------------------------------------------------------------ */
 int qd_quantize_heads(const void* x, int x_dtype, int B, int T, int H, int d,
                       int64_t sb, int64_t st, int64_t sh, int64_t sd, float prescale,

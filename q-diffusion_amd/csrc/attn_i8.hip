@@ -683,7 +683,10 @@ __device__ __forceinline__ void attn_wait_lgkm0() { asm volatile("s_waitcnt lgkm
 // at 4096 keys; the counters charge 0.21 of the wave cycles to s_waitcnt / s_barrier, profiles/r04_pmc_attn_table.txt).  SE = 2:
 // the ring holds 8 tile stages, the waves meet every SECOND tile (in the even iterations of the two-tile software pipeline) and
 // prefetch two tiles per meeting — half the barriers, the same DMA instructions, the same arithmetic in the same order
-// (bit-identical: tests/test_hip_kernels.py::test_attention_lds_equals_lean runs both).
+// (bit-identical: tests/test_hip_kernels.py::test_attention_lds_equals_lean runs both).  MEASURED EQUAL (1012 / 1013 vs 1022 /
+// 1011 us peaked, 930 / 925 vs 928 / 926 us flat, A/B/A/B on one box, profiles/r05_attn_rendezvous.md): the waiting the
+// counters see is not the rendezvous itself — a wave that arrives early waits just as long for the slowest wave's tile pair as
+// for its tile.  SE = 1 stays the default (QD_ATTN_SYNC=2 / qd_attn_sync(2) select the other).
 template <int DT, bool P16, int KT, int SE>
 __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
     // a*b+c written as such stays unfused: hipcc's default -ffp-contract=fast lets the optimiser fuse (or not) depending on the
@@ -1122,7 +1125,7 @@ struct AttnKnobs { int lean, pipe, xcd, ktab, sync; };
 static AttnKnobs& attn_knobs() {
     static AttnKnobs k = [] {
         auto env = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
-        return AttnKnobs{env("QD_ATTN_LEAN", 1), env("QD_ATTN_PIPE", 2), env("QD_ATTN_XCD", 1), env("QD_ATTN_KTAB", 1), env("QD_ATTN_SYNC", 2)};
+        return AttnKnobs{env("QD_ATTN_LEAN", 1), env("QD_ATTN_PIPE", 2), env("QD_ATTN_XCD", 1), env("QD_ATTN_KTAB", 1), env("QD_ATTN_SYNC", 1)};
     }();
     return k;
 }
@@ -1198,7 +1201,7 @@ extern "C" int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt, co
         const int kt = !asym ? 0 : (kterm && qd_attn_uses_keyterm(d, S, q_asym)) ? 2 : 1;     // per-key zero-point term: none / constant-operand MFMAs / table
         const bool lds_fits = dpad <= 64 && Spad <= QD_ONES_ROW && (long)Spad * dpad < (1L << 31);
         if (lds_fits && (kn.pipe == 3 || (kn.pipe == 2 && S >= 512))) {         // short key axes: ring start-up and barriers lose
-            const int se = kn.sync == 1 ? 1 : 2;
+            const int se = kn.sync == 2 ? 2 : 1;           // measured equal (profiles/r05_attn_rendezvous.md): round 3's schedule stays the default
             if (dpad == 32) launch_lds<1>(a, p16, kt, se, st);
             else launch_lds<2>(a, p16, kt, se, st);
         } else if (dpad == 32) launch_lean<1>(a, p16, kt, st);

@@ -450,6 +450,77 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(const T* __restrict__ x, 
     QD_FAST_DISPATCH(qa.fast && (nout < 2 || qb.fast) && (nout < 3 || qc.fast), lnbody);
 }
 
+// C = 32 * J (J <= 10: the 320-channel level of SD, where LayerNorm can also run inside the producing GEMM's epilogue — O_LN
+// of igemm_dma.hip): EIGHT lanes per row, lane c owns columns j*32 + c*4 .. +3 of every 32-column group j — the layout the
+// GEMM epilogue leaves its row-major values in.  A row is reduced exactly as there: 4*J values per lane in (group, column)
+// order, a butterfly over the eight lanes (xor 1, 2, 4), two passes, explicit fma — so the fused and the stand-alone
+// LayerNorm produce the same codes bit for bit (tests/test_hip_kernels.py::test_layernorm_in_the_epilogue).  A wave handles
+// eight rows; per group the eight lanes of a row read 128 (fp32) / 64 (fp16) contiguous bytes.
+template <typename T, int J>
+__global__ __launch_bounds__(256) void ln_quant_rows8_kernel(const T* __restrict__ x, long M, long ldx, float eps,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int nout, const float* qp0, const float* qp1, const float* qp2,
+                                                             float3 qmin, float3 qmax, int3 off, int8_t* o0, int8_t* o1,
+                                                             int8_t* o2, long ldo) {
+#pragma clang fp contract(off)
+    constexpr int C = 32 * J;
+    const int lane = threadIdx.x & 63, c4 = (lane & 7) * 4;
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (lane >> 3);
+    const bool ok = row < M;
+    const T* src = x + (ok ? row : M - 1) * ldx + c4;
+    float v[J][4];
+#pragma unroll
+    for (int j = 0; j < J; ++j) qd_ld4(src + j * 32, true, v[j]);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += v[j][e];
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[j][e] - mean;
+            q = __builtin_fmaf(d, d, q);
+        }
+    q += __shfl_xor(q, 1);
+    q += __shfl_xor(q, 2);
+    q += __shfl_xor(q, 4);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    const QP qa = qd_load_qp(qp0);
+    const QP qb = nout > 1 ? qd_load_qp(qp1) : QP{1.f, 0.f, 1.f, false};
+    const QP qc = nout > 2 ? qd_load_qp(qp2) : QP{1.f, 0.f, 1.f, false};
+    auto lnbody = [&](auto ft) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
+        constexpr bool FAST = decltype(ft)::value;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float4 g4 = *reinterpret_cast<const float4*>(gamma + j * 32 + c4), b4 = *reinterpret_cast<const float4*>(beta + j * 32 + c4);
+            const float g[4] = {g4.x, g4.y, g4.z, g4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+            unsigned u0 = 0, u1 = 0, u2 = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float tt = (v[j][e] - mean) * rstd;
+                const float y = __builtin_fmaf(tt, g[e], b[e]);
+                u0 |= (unsigned)((qd_code_t<FAST>(y, qa, qmin.x, qmax.x) - off.x) & 0xff) << (8 * e);
+                if (nout > 1) u1 |= (unsigned)((qd_code_t<FAST>(y, qb, qmin.y, qmax.y) - off.y) & 0xff) << (8 * e);
+                if (nout > 2) u2 |= (unsigned)((qd_code_t<FAST>(y, qc, qmin.z, qmax.z) - off.z) & 0xff) << (8 * e);
+            }
+            if (ok) {
+                *reinterpret_cast<unsigned*>(o0 + row * ldo + j * 32 + c4) = u0;
+                if (nout > 1) *reinterpret_cast<unsigned*>(o1 + row * ldo + j * 32 + c4) = u1;
+                if (nout > 2) *reinterpret_cast<unsigned*>(o2 + row * ldo + j * 32 + c4) = u2;
+            }
+        }
+    };
+    QD_FAST_DISPATCH(qa.fast && (nout < 2 || qb.fast) && (nout < 3 || qc.fast), lnbody);
+}
+
 // fp16 stream: lane = 8 consecutive channels per chunk (one 16-byte load; 8 code bytes per output), NV = chunks per lane
 // (ceil(C / 512)).  Same two-pass statistics per row (sum -> mean, sum of squared deviations -> rstd) with wave butterflies.
 template <int NV, int RPW>
@@ -784,7 +855,17 @@ extern "C" int qd_layernorm_quant(const void* x, int x_dtype, int64_t M, int C, 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nvl = (C / 4 + 63) / 64;
     static const bool f16_lines = !(getenv("QD_F16_LINES") && atoi(getenv("QD_F16_LINES")) == 0);
-    if (f16_lines && x_dtype == QD_F16 && qd_aligned(x, 16) && ldx % 8 == 0 && C % 8 == 0 && C <= 64 * 8 * 3) {
+    static const bool rows8 = !(getenv("QD_LN_ROWS8") && atoi(getenv("QD_LN_ROWS8")) == 0);      // A/B knob: 0 = the generic kernels at C = 320 too
+    if (rows8 && C == 320 && vec) {
+        // the reduction order of the GEMM epilogue's LayerNorm (O_LN): what runs fused and what runs here agree bit for bit
+        dim3 grid((unsigned)((M + 31) / 32));
+        if (x_dtype == QD_F32)
+            hipLaunchKernelGGL((ln_quant_rows8_kernel<float, 10>), grid, dim3(256), 0, st, (const float*)x, (long)M, (long)ldx, eps, gamma, beta, nout, qp[0], qp[1], qp[2],
+                               mn, mx, of, o[0], o[1], o[2], (long)ldo);
+        else
+            hipLaunchKernelGGL((ln_quant_rows8_kernel<__half, 10>), grid, dim3(256), 0, st, (const __half*)x, (long)M, (long)ldx, eps, gamma, beta, nout, qp[0], qp[1], qp[2],
+                               mn, mx, of, o[0], o[1], o[2], (long)ldo);
+    } else if (f16_lines && x_dtype == QD_F16 && qd_aligned(x, 16) && ldx % 8 == 0 && C % 8 == 0 && C <= 64 * 8 * 3) {
         const int nv8 = (C / 8 + 63) / 64;
         if (nv8 == 1) launch_ln_h8<1>(st, x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, (long)ldo);
         else if (nv8 == 2) launch_ln_h8<2>(st, x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, (long)ldo);

@@ -44,7 +44,15 @@ class ConvDesc(ctypes.Structure):
                 ("splitk_ws", ctypes.c_void_p), ("splitk_ws_bytes", ctypes.c_int64),
                 ("hd_H", ctypes.c_int32), ("hd_d", ctypes.c_int32), ("hd_T", ctypes.c_int32), ("hd_Tpad", ctypes.c_int32),
                 ("hd_dpad", ctypes.c_int32), ("oq_prescale", ctypes.c_float), ("hd_sum", ctypes.c_void_p),
-                ("gn_part", ctypes.c_void_p), ("gn_ld", ctypes.c_int64), ("upsample2x", ctypes.c_int32), ("_pad3", ctypes.c_int32)]
+                ("gn_part", ctypes.c_void_p), ("gn_ld", ctypes.c_int64), ("upsample2x", ctypes.c_int32), ("_pad3", ctypes.c_int32),
+                ("ln", ctypes.c_void_p)]
+
+
+class LnFuse(ctypes.Structure):
+    """qd_ln_fuse (ABI v19): LayerNorm + up to three quantisers of the output rows, in the GEMM's epilogue."""
+    _fields_ = [("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("eps", ctypes.c_float), ("nout", ctypes.c_int32),
+                ("qparams", ctypes.c_void_p * 3), ("qmin", ctypes.c_int32 * 3), ("qmax", ctypes.c_int32 * 3), ("off", ctypes.c_int32 * 3),
+                ("_pad", ctypes.c_int32), ("out", ctypes.c_void_p * 3), ("ldo", ctypes.c_int64)]
 
 
 class RawSeg(ctypes.Structure):
@@ -232,7 +240,7 @@ class ConvCall:
     """Python-side description of one qd_conv2d_i8 launch (tensors, not pointers)."""
     __slots__ = ("x", "w", "out", "bias", "rowbias", "residual", "ldx", "ldk", "ldo", "ldr", "ld_rowbias",
                  "B", "H", "W", "Ho", "Wo", "Cout", "kh", "kw", "stride", "pad_t", "pad_l", "wbits", "w_tiled", "segs",
-                 "epilogue", "oq_params", "oq_grid", "splitk", "heads", "gn_part", "upsample2x")
+                 "epilogue", "oq_params", "oq_grid", "splitk", "heads", "gn_part", "upsample2x", "ln", "_keep")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -300,6 +308,16 @@ def _conv_desc(c):
     if c.gn_part is not None:
         d.gn_ld = part_ld(c.gn_part)
     d.upsample2x = 1 if c.upsample2x else 0
+    if c.ln is not None:
+        # c.ln: dict(gamma, beta, eps, qparams=[float[4] device tensors], grids=[Grid], outs=[int8 rows], ldo)
+        L = LnFuse()
+        L.gamma, L.beta, L.eps, L.nout = _ptr(c.ln["gamma"], "ln gamma"), _ptr(c.ln["beta"], "ln beta"), float(c.ln["eps"]), len(c.ln["outs"])
+        qps = [_qp(q) for q in c.ln["qparams"]]
+        for i, (q, g, o) in enumerate(zip(qps, c.ln["grids"], c.ln["outs"])):
+            L.qparams[i], L.qmin[i], L.qmax[i], L.off[i], L.out[i] = _ptr(q, "ln qparams"), g.qmin, g.qmax, g.off, _ptr(o, "ln out")
+        L.ldo = int(c.ln["ldo"])
+        c._keep = (L, qps)                          # the struct and the completed qparams must outlive the launch call
+        d.ln = ctypes.addressof(L)
     d.nseg = len(c.segs)
     for i, s in enumerate(c.segs):
         g = d.seg[i]

@@ -1,0 +1,37 @@
+#!/bin/bash
+# GPU box: round-5 closing run — the whole GPU suite, smoke, the driver's bench command (headline + the child lines), the fp16
+# envelope summary, steady-state breakdown + timeline of the graph-replayed evaluation, kernel-trace stats of the bench
+# command, HBM traffic PMC passes (fp32 and fp16 stream), attention PMC passes.  QD_OUT names the output directory.
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/${QD_OUT:-r05f}; mkdir -p $out
+timeout 1700 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $out/pytest_gpu.log; tail -3 $out/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1; tail -2 $out/smoke.log
+timeout 1500 python bench.py > $out/bench_sd.json 2> $out/bench_sd.err; echo "bench rc=$?"; tail -c 1500 $out/bench_sd.json; echo
+timeout 900 python tools/fp16_envelope.py $out/fp16_envelope.json > $out/fp16_envelope.log 2>&1; tail -7 $out/fp16_envelope.log
+# steady-state graph-replayed evaluation (fp32 stream: the headline)
+timeout 600 rocprofv3 --kernel-trace -d $out -o evb -- python tools/eval_breakdown.py run sd 8 3 graph pin > $out/evb.log 2>&1
+db=$(find $out -name 'evb_results.db' | head -1)
+python tools/eval_breakdown.py join $db 3 > $out/sd_eval_breakdown_graph.txt; head -12 $out/sd_eval_breakdown_graph.txt | cut -c1-150
+python tools/eval_breakdown.py timeline $db 3 $out/sd_eval_timeline.tsv
+# kernel-trace stats of the bench command itself
+timeout 600 rocprofv3 --kernel-trace -d $out -o kt -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-denominators --no-extras > $out/kt.log 2>&1
+python tools/rocpd_stats.py $(find $out -name 'kt_results.db' | head -1) --md > $out/sd_bench_kernel_stats.md 2>&1; head -8 $out/sd_bench_kernel_stats.md | cut -c1-150
+timeout 400 rocprofv3 --kernel-trace -d $out -o ktc -- python bench.py --model cifar --images-per-gpu 64 --steps 5 --warmup 2 --no-cpu-baseline --no-denominators --no-extras > $out/ktc.log 2>&1
+python tools/rocpd_stats.py $(find $out -name 'ktc_results.db' | head -1) --md > $out/cifar_bench_kernel_stats.md 2>&1; head -6 $out/cifar_bench_kernel_stats.md | cut -c1-150
+find $out -name '*.db' -delete
+# HBM traffic (separate PMC passes, no other tracing domains), both streams
+for st in fp32 fp16; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    QDIFF_STREAM=$st timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_hbm_$st -o pmc_$c -- python tools/eval_breakdown.py run sd 8 2 pin > $out/pmc_${st}_$c.log 2>&1
+  done
+  QD_COMMIT=$QD_COMMIT python tools/pmc_eval_traffic.py $out/pmc_hbm_$st 2 $out/sd_igemm_hbm_traffic_$st.json | cut -c1-400
+done
+# attention counters (LDS-staged kernel, two tiles per rendezvous)
+A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE"
+B="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_WAVES"
+for set in A B; do
+  ctr=$([ $set = A ] && echo "$A" || echo "$B")
+  timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_attn -o pmc_attn_$set -- python tools/bench_attn.py 3 "sd self 64x64" > $out/pmc_attn_$set.log 2>&1
+done
+python tools/pmc_table.py $out/pmc_attn attn > $out/pmc_attn_table.txt 2>&1; head -40 $out/pmc_attn_table.txt
+find $out -name '*.csv' -size +2M -delete; find $out -name '*.db' -delete
