@@ -412,21 +412,13 @@ def extra_lines(a):
     out = {}
     common = ["--no-cpu-baseline", "--no-denominators", "--no-extras", "--steps", "10", "--warmup", "2"]
     for kind, n in (("cifar", 64), ("ldm", 64)):
-        d = _child(["--model", kind, "--images-per-gpu", str(n)] + common, 240, f"{kind} line")
+        # SURVEY.md §8d names batch 10 for C3 (README.md:47-49 `-n 10`); batch 64 is the throughput point: both from one child
+        d = _child(["--model", kind, "--images-per-gpu", str(n)] + (["--extra-batch", "10"] if kind == "ldm" else []) + common, 240, f"{kind} line")
         out[kind] = d if "error" in d else {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "wall_s") if k in d} | \
             {"workload": d["config"]["workload"], "igemm_frac": d.get("roofline", {}).get("frac"),
              "launches_per_eval_igemm": d.get("roofline", {}).get("launches_per_eval")} | \
-            {k: d["config"][k] for k in ("whole_step_graph_ms", "whole_step_graph_images_per_s") if k in d["config"]}
-    # SURVEY.md §8d names batch 10 for C3 (README.md:47-49 `-n 10`); batch 64 above is the throughput point
-    d = _child(["--model", "ldm", "--images-per-gpu", "10"] + common, 240, "ldm line, batch 10")
-    out["ldm_b10"] = d if "error" in d else {k: d[k] for k in ("value", "unit", "ms_per_step", "wall_s") if k in d} | \
-        {"workload": d["config"]["workload"], "igemm_frac": d.get("roofline", {}).get("frac")}
-    # the same SD workload on the opt-in fp16 activation stream (the reference scripts' own precision, txt2img.py:231-236)
-    d = _child(["--stream", "fp16", "--images-per-gpu", str(a.images_per_gpu)] + common, 300, "sd line, fp16 activation stream")
-    out["sd_fp16_stream"] = d if "error" in d else {k: d[k] for k in ("value", "unit", "ms_per_step", "dtype", "wall_s") if k in d} | \
-        {"igemm_frac": d.get("roofline", {}).get("frac"), "by_launch_class": d.get("roofline", {}).get("by_launch_class"),
-         "envelope": _committed("_fp16_envelope.json")}
-    # ... and driven exactly like the reference's unmodified sampler drives it (no graph / context calls by the caller)
+            {k: d["config"][k] for k in ("whole_step_graph_ms", "whole_step_graph_images_per_s", "extra_batch") if k in d["config"]}
+    # the SD workload driven exactly like the reference's unmodified sampler drives it (no graph / context calls by the caller)
     out["sd_as_script"] = _child(["--as-script", "--images-per-gpu", str(a.images_per_gpu)], 300, "sd line, the unmodified sampler's call pattern")
     out["first_stage_decode_sd"] = first_stage_decode("sd", a.images_per_gpu, legs=("hip",), cap_s=240)["hip"]
     return out
@@ -460,6 +452,7 @@ def main():
     ap.add_argument("--stream", default=None, choices=["fp32", "fp16"],
                     help="storage type of the inter-kernel activations (default: QDIFF_STREAM or fp32); fp16 = the precision the "
                          "reference scripts run at (--precision autocast); compute stays int8 MFMA / fp32 epilogues")
+    ap.add_argument("--extra-batch", type=int, default=0, help="also time the same loop at this (smaller) number of images per GPU; extra key of config")
     ap.add_argument("--as-script", action="store_true",
                     help="(child mode) SD driven exactly as the reference's unmodified PLMS sampler drives it: fresh torch.cat of x / t / context "
                          "per step, no enable_hip_graphs / prepare_context calls; prints its own JSON line")
@@ -620,6 +613,19 @@ def main():
 
     ms_per_step = 1000.0 * elapsed / a.steps + prepare_ms / evals
     images_per_s = gb / (evals * ms_per_step / 1000.0)
+
+    def retime(warm=4):
+        """The timed loop again (same model, whatever stream type / batch is now in force): ms per step, rank-local."""
+        state.update(old=[], i=0)
+        with torch.no_grad():
+            for _ in range(warm):
+                one_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                one_step()
+            torch.cuda.synchronize()
+        return 1000.0 * (time.perf_counter() - t1) / a.steps
     out = {
         "metric": "denoising images/sec (whole node), SD-v1.4 W4A8 512x512 50-step PLMS" if kind == "sd" else f"denoising images/sec ({kind})",
         "value": round(images_per_s, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -709,8 +715,41 @@ def main():
                                                              f"{2 if guide != 1.0 else 1} samples per image"}
         if a.decode and kind in ("sd", "ldm", "churches"):
             out["first_stage_decode"] = first_stage_decode(kind, n)
+        if a.extra_batch and 0 < a.extra_batch < n and world == 1 and not ctx_shape:
+            # the same loop at another batch (BASELINE configs[2] is quoted at `-n 10`): extra key, same process, same model
+            try:
+                xs = state["x"]
+                state["x"] = xs[:a.extra_batch].clone()
+                ms_b = retime()
+                out["config"]["extra_batch"] = {"images_per_gpu": a.extra_batch, "ms_per_step": round(ms_b, 4),
+                                                "images_per_s": round(a.extra_batch / (evals * ms_b / 1000.0), 4)}
+                state["x"] = xs
+            except Exception as exc:  # noqa: BLE001 - never lose the line over an extra
+                out["config"]["extra_batch"] = {"error": repr(exc)[:200]}
         if kind == "sd" and world == 1 and not a.no_extras:
-            out["other_configs"] = extra_lines(a)
+            other = {}
+            if engine.STREAM_DTYPE == torch.float32:
+                # the same workload on the opt-in fp16 activation stream (the reference scripts' own precision, txt2img.py:231-236):
+                # same process, same packed model; the context is prepared again (its operands depend on the stream's rows)
+                try:
+                    engine.set_stream_dtype(torch.float16)
+                    with torch.no_grad():
+                        qnn(torch.cat([state["x"]] * 2), torch.full((2 * state["x"].shape[0],), 500, device=dev, dtype=torch.long), ctx2)
+                        qnn.prepare_context(ctx2)
+                    ms16 = retime() + prepare_ms / evals
+                    measure_igemm(qnn, margs)
+                    r16 = measure_igemm(qnn, margs)
+                    ach16 = r16["ops"] / (r16["total_ms"] * 1e-3) / 1e12
+                    other["sd_fp16_stream"] = {"ms_per_step": round(ms16, 4), "value": round(gb / (evals * ms16 / 1000.0), 4), "unit": "images/s",
+                                               "dtype": "int8xint4->int32 (fp16 residual stream)", "vs_fp32_stream_ms": round(ms16 - ms_per_step, 4),
+                                               "igemm_ms_per_eval": round(r16["total_ms"], 3), "igemm_frac": round(ach16 / I8_MFMA_PEAK_TOPS, 4),
+                                               "by_launch_class": r16["classes"], "envelope": _committed("_fp16_envelope.json")}
+                except Exception as exc:  # noqa: BLE001
+                    other["sd_fp16_stream"] = {"error": repr(exc)[:300]}
+                finally:
+                    engine.set_stream_dtype(torch.float32)
+            other.update(extra_lines(a))
+            out["other_configs"] = other
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -219,6 +219,17 @@ __device__ __forceinline__ void qd_bytes2_t(v2f x, const QP& q, const QB& b, int
     b0 = __float_as_int(c.x) + b.n;
     b1 = __float_as_int(c.y) + b.n;
 }
+// four values -> the four stored code bytes of ONE quantiser in a word (byte e = value e): qd_code_t's bytes bit for bit, at
+// ~5 instructions per value instead of ~12 (the producers — GroupNorm apply, LayerNorm with up to three quantisers — are
+// VALU-bound once the activation stream is fp16, and sit at the edge of it in fp32: profiles/r05_streams_ab.md)
+template <bool FAST>
+__device__ __forceinline__ unsigned qd_pack4_t(float y0, float y1, float y2, float y3, const QP& q, const QB& b) {
+    int b0, b1, b2, b3;
+    qd_bytes2_t<FAST>(v2f{y0, y1}, q, b, b0, b1);
+    qd_bytes2_t<FAST>(v2f{y2, y3}, q, b, b2, b3);
+    return __builtin_amdgcn_perm(__builtin_amdgcn_perm((unsigned)b3, (unsigned)b2, 0x0c0c0400u),
+                                 __builtin_amdgcn_perm((unsigned)b1, (unsigned)b0, 0x0c0c0400u), 0x05040100u);
+}
 __device__ __forceinline__ v2f qd_erff2(v2f a) {             // qd_erff on two values (same operations, packed)
     const v2f t = {__builtin_fabsf(a.x), __builtin_fabsf(a.y)}, s = a * a;
     v2f r = qd_fma2(qd_splat2(-1.72853470e-5f), t, qd_splat2(3.83197126e-4f));

@@ -797,7 +797,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
             for (int r = 0; r < 16; ++r) {
                 const int rl = crow(r) + 4 * fhalf;
                 const int I = acc[0][j][r] - zc2 - __mul24(zw_n, as[r]);
-                tb[rl * 32 + frow] = __float_as_uint((float)I * sc + bias_n);
+                tb[rl * 32 + frow] = __float_as_uint(__builtin_fmaf((float)I, sc, bias_n));     // the linear epilogue's value, bit for bit
             }
             v4f rs[4];
             if (has_res) {
@@ -851,6 +851,8 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
         const QP qa = qd_load_qp(p.ln_qp[0]);
         const QP qb = nout > 1 ? qd_load_qp(p.ln_qp[1]) : QP{1.f, 0.f, 1.f, false};
         const QP qc = nout > 2 ? qd_load_qp(p.ln_qp[2]) : QP{1.f, 0.f, 1.f, false};
+        const QB ba = qd_bytes_setup(qa, p.ln_qmin[0], p.ln_qmax[0], p.ln_off[0]), bb = qd_bytes_setup(qb, p.ln_qmin[1], p.ln_qmax[1], p.ln_off[1]),
+                 bc = qd_bytes_setup(qc, p.ln_qmin[2], p.ln_qmax[2], p.ln_off[2]);
         auto lnbody = [&](auto ft) __attribute__((always_inline)) {
 #pragma clang fp contract(off)
             constexpr bool FAST = decltype(ft)::value;
@@ -861,14 +863,15 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
                     unsigned u0 = 0, u1 = 0, u2 = 0;
+                    float y[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float tt = (val[ps][j][e] - mean[ps]) * rstd[ps];
-                        const float y = __builtin_fmaf(tt, g4[e], b4[e]);
-                        u0 |= (unsigned)((qd_code_t<FAST>(y, qa, p.ln_qmin[0], p.ln_qmax[0]) - p.ln_off[0]) & 0xff) << (8 * e);
-                        if (nout > 1) u1 |= (unsigned)((qd_code_t<FAST>(y, qb, p.ln_qmin[1], p.ln_qmax[1]) - p.ln_off[1]) & 0xff) << (8 * e);
-                        if (nout > 2) u2 |= (unsigned)((qd_code_t<FAST>(y, qc, p.ln_qmin[2], p.ln_qmax[2]) - p.ln_off[2]) & 0xff) << (8 * e);
+                        y[e] = __builtin_fmaf(tt, g4[e], b4[e]);
                     }
+                    u0 = qd_pack4_t<FAST>(y[0], y[1], y[2], y[3], qa, ba);
+                    if (nout > 1) u1 = qd_pack4_t<FAST>(y[0], y[1], y[2], y[3], qb, bb);
+                    if (nout > 2) u2 = qd_pack4_t<FAST>(y[0], y[1], y[2], y[3], qc, bc);
                     if (mok[ps]) {
                         *reinterpret_cast<unsigned*>(p.ln_out[0] + mrow[ps] * p.ln_ldo + n4) = u0;
                         if (nout > 1) *reinterpret_cast<unsigned*>(p.ln_out[1] + mrow[ps] * p.ln_ldo + n4) = u1;
@@ -923,9 +926,12 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
                     tb[rl * 32 + frow] = __float_as_uint((float)acc[i][j][r] + bias_n);
                 } else {
                     const int I = acc[i][j][r] - zc2 - __mul24(zw_n, as[r]);
-                    float v = (float)I * sc;
-                    if (SPLIT) v += facc[SPLIT ? i : 0][SPLIT ? j : 0][r];
-                    tb[rl * 32 + frow] = __float_as_uint(v + bias_n);
+                    // one fma(I, scale, bias) — written out: the O_F16 pair form, the O_LN epilogue and the split-K finalise
+                    // must produce this value bit for bit and may not depend on where the optimiser contracts
+                    float v;
+                    if (SPLIT) v = __builtin_fmaf((float)I, sc, facc[SPLIT ? i : 0][SPLIT ? j : 0][r]) + bias_n;
+                    else v = __builtin_fmaf((float)I, sc, bias_n);
+                    tb[rl * 32 + frow] = __float_as_uint(v);
                 }
             }
             // phase 2: row-major, 4 columns per lane
@@ -1092,13 +1098,14 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
                 const int rl = crow(r) + 4 * fhalf;
                 const int I0 = acc[i][j][r] - zc0 - __mul24(zw0, as[r]);
                 const int I1 = acc[i][j + 1][r] - zc1 - __mul24(zw1, as[r]);
-                float v0 = (float)I0 * sc0, v1 = (float)I1 * sc1;
+                float v0, v1;
                 if (SPLIT) {
-                    v0 += facc[SPLIT ? i : 0][SPLIT ? j : 0][r];
-                    v1 += facc[SPLIT ? i : 0][SPLIT ? j + 1 : 0][r];
+                    v0 = __builtin_fmaf((float)I0, sc0, facc[SPLIT ? i : 0][SPLIT ? j : 0][r]) + bias0;
+                    v1 = __builtin_fmaf((float)I1, sc1, facc[SPLIT ? i : 0][SPLIT ? j + 1 : 0][r]) + bias1;
+                } else {
+                    v0 = __builtin_fmaf((float)I0, sc0, bias0);
+                    v1 = __builtin_fmaf((float)I1, sc1, bias1);
                 }
-                v0 += bias0;
-                v1 += bias1;
                 if (rb_tile) { v0 += rbv0; v1 += rbv1; }
                 const int pc = frow ^ ((r & 1) << 2);  // (row & 1) == (r & 1) in the C layout
                 tb[rl * 64 + pc] = __float_as_uint(v0);
@@ -1273,8 +1280,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const int32_t* __r
     for (int s = 0; s < nsplit; ++s) I += part[(long)s * MN + e];
     const int kz = zfill ? zfill[1] : 0;
     I = I - (zc ? zc[n] : 0) + (zw ? zw[n] : 0) * kz;
-    float v = (float)I * scale[n];
-    v += bias ? bias[n] : 0.f;
+    float v = __builtin_fmaf((float)I, scale[n], bias ? bias[n] : 0.f);         // the fused epilogue's fma(I, scale, bias)
     if (rowbias) v += rowbias[(m / HoWo) * ldrb + n];
     if constexpr (std::is_same<TO, float>::value) {
         if (residual) v += residual[m * ldr + n];

@@ -256,28 +256,24 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const float* __restr
     if (rawhere) rq = qd_load_qp(s1 ? raw.qp[1] : raw.qp[0]);
     const float rmin = s1 ? raw.qmin[1] : raw.qmin[0], rmax = s1 ? raw.qmax[1] : raw.qmax[0];
     const int roff = s1 ? raw.off[1] : raw.off[0];
+    const QB qb = qd_bytes_setup(q, qmin, qmax, off), rqb = qd_bytes_setup(rq, rmin, rmax, roff);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const float v[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
         const long row = row0 + u;
         unsigned w0 = 0;
-        auto body = [&](auto ft) __attribute__((always_inline)) {
+        float y[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float y = v[j] * a4[j] + s4[j];
-                if (apply_silu) y = y * (1.0f / (1.0f + expf(-y)));
-                w0 |= (unsigned)((qd_code_t<decltype(ft)::value>(y, q, qmin, qmax) - off) & 0xff) << (8 * j);
-            }
-        };
+        for (int j = 0; j < 4; ++j) {
+            y[j] = v[j] * a4[j] + s4[j];
+            if (apply_silu) y[j] = y[j] * (1.0f / (1.0f + expf(-y[j])));
+        }
+        auto body = [&](auto ft) __attribute__((always_inline)) { w0 = qd_pack4_t<decltype(ft)::value>(y[0], y[1], y[2], y[3], q, qb); };
         QD_FAST_DISPATCH(q.fast, body);
         *reinterpret_cast<unsigned*>(out + row * ldo + c) = w0;
         if (rawhere) {
             unsigned w = 0;
-            auto rbody = [&](auto ft) __attribute__((always_inline)) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    w |= (unsigned)((qd_code_t<decltype(ft)::value>(v[j], rq, rmin, rmax) - roff) & 0xff) << (8 * j);
-            };
+            auto rbody = [&](auto ft) __attribute__((always_inline)) { w = qd_pack4_t<decltype(ft)::value>(v[0], v[1], v[2], v[3], rq, rqb); };
             QD_FAST_DISPATCH(rq.fast, rbody);
             *reinterpret_cast<unsigned*>(raw.out + row * raw.ldo + roc0 + (c - rc0)) = w;
         }
@@ -318,6 +314,7 @@ __global__ __launch_bounds__(256) void gn_apply_rows_h8_kernel(const __half* __r
     if (rawhere) rq = qd_load_qp(s1 ? raw.qp[1] : raw.qp[0]);
     const float rmin = s1 ? raw.qmin[1] : raw.qmin[0], rmax = s1 ? raw.qmax[1] : raw.qmax[0];
     const int roff = s1 ? raw.off[1] : raw.off[0];
+    const QB qb = qd_bytes_setup(q, qmin, qmax, off), rqb = qd_bytes_setup(rq, rmin, rmax, roff);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         v4f lo, hi;
@@ -325,25 +322,23 @@ __global__ __launch_bounds__(256) void gn_apply_rows_h8_kernel(const __half* __r
         const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         const long row = row0 + u;
         unsigned w0 = 0, w1 = 0;
-        auto body = [&](auto ft) __attribute__((always_inline)) {
+        float y[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float y = v[j] * a8[j] + s8[j];
-                if (apply_silu) y = y * (1.0f / (1.0f + expf(-y)));
-                const unsigned cb = (unsigned)((qd_code_t<decltype(ft)::value>(y, q, qmin, qmax) - off) & 0xff) << (8 * (j & 3));
-                if (j < 4) w0 |= cb; else w1 |= cb;
-            }
+        for (int j = 0; j < 8; ++j) {
+            y[j] = v[j] * a8[j] + s8[j];
+            if (apply_silu) y[j] = y[j] * (1.0f / (1.0f + expf(-y[j])));
+        }
+        auto body = [&](auto ft) __attribute__((always_inline)) {
+            w0 = qd_pack4_t<decltype(ft)::value>(y[0], y[1], y[2], y[3], q, qb);
+            w1 = qd_pack4_t<decltype(ft)::value>(y[4], y[5], y[6], y[7], q, qb);
         };
         QD_FAST_DISPATCH(q.fast, body);
         *reinterpret_cast<uint2*>(out + row * ldo + c) = make_uint2(w0, w1);
         if (rawhere) {
             unsigned r0 = 0, r1 = 0;
             auto rbody = [&](auto ft) __attribute__((always_inline)) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const unsigned cb = (unsigned)((qd_code_t<decltype(ft)::value>(v[j], rq, rmin, rmax) - roff) & 0xff) << (8 * (j & 3));
-                    if (j < 4) r0 |= cb; else r1 |= cb;
-                }
+                r0 = qd_pack4_t<decltype(ft)::value>(v[0], v[1], v[2], v[3], rq, rqb);
+                r1 = qd_pack4_t<decltype(ft)::value>(v[4], v[5], v[6], v[7], rq, rqb);
             };
             QD_FAST_DISPATCH(rq.fast, rbody);
             *reinterpret_cast<uint2*>(raw.out + row * raw.ldo + roc0 + (c - rc0)) = make_uint2(r0, r1);
@@ -421,6 +416,7 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(const T* __restrict__ x, 
     const QP qa = qd_load_qp(qp0);
     const QP qb = nout > 1 ? qd_load_qp(qp1) : QP{1.f, 0.f, 1.f, false};
     const QP qc = nout > 2 ? qd_load_qp(qp2) : QP{1.f, 0.f, 1.f, false};
+    const QB ba = qd_bytes_setup(qa, qmin.x, qmax.x, off.x), bb = qd_bytes_setup(qb, qmin.y, qmax.y, off.y), bc = qd_bytes_setup(qc, qmin.z, qmax.z, off.z);
     auto lnbody = [&](auto ft) __attribute__((always_inline)) {
     constexpr bool FAST = decltype(ft)::value;
 #pragma unroll
@@ -433,13 +429,12 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(const T* __restrict__ x, 
             const int idx = lane + 64 * k;
             if (idx < nv) {
                 unsigned u0 = 0, u1 = 0, u2 = 0;
+                float y[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float y = (v[r][k][j] - mean[r]) * rstd[r] * g[k][j] + bt[k][j];
-                    u0 |= (unsigned)((qd_code_t<FAST>(y, qa, qmin.x, qmax.x) - off.x) & 0xff) << (8 * j);
-                    if (nout > 1) u1 |= (unsigned)((qd_code_t<FAST>(y, qb, qmin.y, qmax.y) - off.y) & 0xff) << (8 * j);
-                    if (nout > 2) u2 |= (unsigned)((qd_code_t<FAST>(y, qc, qmin.z, qmax.z) - off.z) & 0xff) << (8 * j);
-                }
+                for (int j = 0; j < 4; ++j) y[j] = (v[r][k][j] - mean[r]) * rstd[r] * g[k][j] + bt[k][j];
+                u0 = qd_pack4_t<FAST>(y[0], y[1], y[2], y[3], qa, ba);
+                if (nout > 1) u1 = qd_pack4_t<FAST>(y[0], y[1], y[2], y[3], qb, bb);
+                if (nout > 2) u2 = qd_pack4_t<FAST>(y[0], y[1], y[2], y[3], qc, bc);
                 *reinterpret_cast<unsigned*>(o0 + row * ldo + idx * 4) = u0;
                 if (nout > 1) *reinterpret_cast<unsigned*>(o1 + row * ldo + idx * 4) = u1;
                 if (nout > 2) *reinterpret_cast<unsigned*>(o2 + row * ldo + idx * 4) = u2;
@@ -495,6 +490,7 @@ __global__ __launch_bounds__(256) void ln_quant_rows8_kernel(const T* __restrict
     const QP qa = qd_load_qp(qp0);
     const QP qb = nout > 1 ? qd_load_qp(qp1) : QP{1.f, 0.f, 1.f, false};
     const QP qc = nout > 2 ? qd_load_qp(qp2) : QP{1.f, 0.f, 1.f, false};
+    const QB ba = qd_bytes_setup(qa, qmin.x, qmax.x, off.x), bb = qd_bytes_setup(qb, qmin.y, qmax.y, off.y), bc = qd_bytes_setup(qc, qmin.z, qmax.z, off.z);
     auto lnbody = [&](auto ft) __attribute__((always_inline)) {
 #pragma clang fp contract(off)
         constexpr bool FAST = decltype(ft)::value;
@@ -503,14 +499,15 @@ __global__ __launch_bounds__(256) void ln_quant_rows8_kernel(const T* __restrict
             const float4 g4 = *reinterpret_cast<const float4*>(gamma + j * 32 + c4), b4 = *reinterpret_cast<const float4*>(beta + j * 32 + c4);
             const float g[4] = {g4.x, g4.y, g4.z, g4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
             unsigned u0 = 0, u1 = 0, u2 = 0;
+            float y[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float tt = (v[j][e] - mean) * rstd;
-                const float y = __builtin_fmaf(tt, g[e], b[e]);
-                u0 |= (unsigned)((qd_code_t<FAST>(y, qa, qmin.x, qmax.x) - off.x) & 0xff) << (8 * e);
-                if (nout > 1) u1 |= (unsigned)((qd_code_t<FAST>(y, qb, qmin.y, qmax.y) - off.y) & 0xff) << (8 * e);
-                if (nout > 2) u2 |= (unsigned)((qd_code_t<FAST>(y, qc, qmin.z, qmax.z) - off.z) & 0xff) << (8 * e);
+                y[e] = __builtin_fmaf(tt, g[e], b[e]);
             }
+            u0 = qd_pack4_t<FAST>(y[0], y[1], y[2], y[3], qa, ba);
+            if (nout > 1) u1 = qd_pack4_t<FAST>(y[0], y[1], y[2], y[3], qb, bb);
+            if (nout > 2) u2 = qd_pack4_t<FAST>(y[0], y[1], y[2], y[3], qc, bc);
             if (ok) {
                 *reinterpret_cast<unsigned*>(o0 + row * ldo + j * 32 + c4) = u0;
                 if (nout > 1) *reinterpret_cast<unsigned*>(o1 + row * ldo + j * 32 + c4) = u1;
@@ -591,6 +588,7 @@ __global__ __launch_bounds__(256) void ln_quant_h8_kernel(const __half* __restri
     const QP qa = qd_load_qp(qp0);
     const QP qb = nout > 1 ? qd_load_qp(qp1) : QP{1.f, 0.f, 1.f, false};
     const QP qc = nout > 2 ? qd_load_qp(qp2) : QP{1.f, 0.f, 1.f, false};
+    const QB ba = qd_bytes_setup(qa, qmin.x, qmax.x, off.x), bb = qd_bytes_setup(qb, qmin.y, qmax.y, off.y), bc = qd_bytes_setup(qc, qmin.z, qmax.z, off.z);
     auto lnbody = [&](auto ft) __attribute__((always_inline)) {
     constexpr bool FAST = decltype(ft)::value;
 #pragma unroll
@@ -603,12 +601,14 @@ __global__ __launch_bounds__(256) void ln_quant_h8_kernel(const __half* __restri
             const int idx = lane + 64 * k;
             if (idx < nv) {
                 unsigned u0[2] = {0, 0}, u1[2] = {0, 0}, u2[2] = {0, 0};
+                float y[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float y = (v[r][k][j] - mean[r]) * rstd[r] * g[k][j] + bt[k][j];
-                    u0[j >> 2] |= (unsigned)((qd_code_t<FAST>(y, qa, qmin.x, qmax.x) - off.x) & 0xff) << (8 * (j & 3));
-                    if (nout > 1) u1[j >> 2] |= (unsigned)((qd_code_t<FAST>(y, qb, qmin.y, qmax.y) - off.y) & 0xff) << (8 * (j & 3));
-                    if (nout > 2) u2[j >> 2] |= (unsigned)((qd_code_t<FAST>(y, qc, qmin.z, qmax.z) - off.z) & 0xff) << (8 * (j & 3));
+                for (int j = 0; j < 8; ++j) y[j] = (v[r][k][j] - mean[r]) * rstd[r] * g[k][j] + bt[k][j];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    u0[h] = qd_pack4_t<FAST>(y[4 * h], y[4 * h + 1], y[4 * h + 2], y[4 * h + 3], qa, ba);
+                    if (nout > 1) u1[h] = qd_pack4_t<FAST>(y[4 * h], y[4 * h + 1], y[4 * h + 2], y[4 * h + 3], qb, bb);
+                    if (nout > 2) u2[h] = qd_pack4_t<FAST>(y[4 * h], y[4 * h + 1], y[4 * h + 2], y[4 * h + 3], qc, bc);
                 }
                 *reinterpret_cast<uint2*>(o0 + row * ldo + idx * 8) = make_uint2(u0[0], u0[1]);
                 if (nout > 1) *reinterpret_cast<uint2*>(o1 + row * ldo + idx * 8) = make_uint2(u1[0], u1[1]);

@@ -374,13 +374,19 @@ def upsample_fold_ok(plan, H, W):
     return bool(plan.pack.tiled and plan.kh * plan.kw > 1 and plan.stride == 1 and H % 2 == 0 and W % 2 == 0)
 
 
-LN_FUSE = os.environ.get("QDIFF_LN_FUSE", "1") != "0"      # A/B knob: LayerNorm + quantisers in the producing GEMM's epilogue (C = 320)
+# LayerNorm + the next sub-layer's quantisers in the producing GEMM's epilogue (qd_ln_fuse, 320 channels).  OFF by default:
+# built, bit-identical to the unfused path, and measured no faster — 20.36 / 20.29 ms fused vs 20.29 / 20.31 unfused per SD step
+# (fp32 stream), 19.62 vs 19.48 (fp16 stream), profiles/r05_ln_fuse_ab.md: the stand-alone LayerNorm is VALU-bound (statistics,
+# normalisation and up to three quantisers per element), not bound by its re-read of the rows, so moving that work into the
+# GEMM's epilogue moves its time with it.  QDIFF_LN_FUSE=1 switches it on.
+LN_FUSE = os.environ.get("QDIFF_LN_FUSE", "0") == "1"
 
 
 def ln_fusable(plan, ln, consumers):
     """The Linear `plan` can layer-normalise and quantise its own output rows for `consumers` (ConvPlans of the Linears behind
-    LayerNorm `ln`): qd_ln_fuse — the 320-channel level of SD, where a 128 x 320 tile owns whole rows."""
-    return bool(LN_FUSE and plan.pack.tiled and plan.pack.wbits == 4 and len(plan.segs) == 1 and plan.Cout == 320
+    LayerNorm `ln`): qd_ln_fuse — the 320-channel level of SD, where a 128 x 320 tile owns whole rows.  (Capability only:
+    whether the model USES it is engine.LN_FUSE, checked by quant_block._ln_fuse.)"""
+    return bool(plan.pack.tiled and plan.pack.wbits == 4 and len(plan.segs) == 1 and plan.Cout == 320
                 and tuple(ln.normalized_shape) == (320,) and ln.weight is not None and ln.bias is not None
                 and 1 <= len(consumers) <= 3 and all(len(p.segs) == 1 and p.ldx == consumers[0].ldx and p.ldx >= 320 for p in consumers))
 

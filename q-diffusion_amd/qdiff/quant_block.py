@@ -242,8 +242,11 @@ _CTX_PIN = os.environ.get("QDIFF_CTX_PIN", "1") != "0"
 # (default: QuantModel.forward prepares a context it has not seen — the unmodified reference samplers never announce theirs)
 _CTX_PINS = max(1, int(os.environ.get("QDIFF_CTX_PINS", "2")))
 _CTX_AUTO = os.environ.get("QDIFF_CTX_AUTO", "1") != "0"
-# QDIFF_CTX_SPECULATE=0: every fresh context tensor is compared BEFORE its evaluation is enqueued (a host read-back per step)
-_CTX_SPECULATE = os.environ.get("QDIFF_CTX_SPECULATE", "1") != "0"
+# QDIFF_CTX_SPECULATE=1: a fresh context tensor that follows a value match is ASSUMED equal; the replay is enqueued behind the
+# comparison kernel and verified afterwards (default: compared BEFORE its evaluation is enqueued, a host read-back per step)
+# (default off: measured 20.93 vs 20.39 ms per evaluation over a 51-evaluation run of a new prompt, profiles/r05_ln_fuse_ab.md —
+#  enqueueing a replay costs 0.15 ms, nothing to hide, and every prompt change wastes one speculative evaluation)
+_CTX_SPECULATE = os.environ.get("QDIFF_CTX_SPECULATE", "0") == "1"
 _FUSE_SKIP_QUANT = os.environ.get("QDIFF_FUSE_SKIP_QUANT", "1") != "0"     # A/B knob: skip-connection rows from the GroupNorm pass
 CAT_SLOTS = os.environ.get("QDIFF_CAT_SLOTS", "1") != "0"         # A/B knob: planned skip-concatenation buffers (engine.CatSlot)
 
@@ -302,7 +305,7 @@ class ContextKV:
         tok = self._live()
         ver = engine.tensor_version(context)                       # None: an inference tensor, identity proves nothing
         cands = [e for e in reversed(self._pins) if e["token"] == tok and e["shape"] == tuple(context.shape)
-                 and e["dtype"] == context.dtype and e["device"] == context.device]
+                 and e["dtype"] == context.dtype and e["device"] == context.device and e["stream"] == engine.STREAM_DTYPE]
         if ver is not None:
             for e in cands:
                 a = e["alias"].get(id(context))
@@ -341,7 +344,7 @@ class ContextKV:
         tok = self._live()
         e = self._pins[-1] if self._pins else None
         if (e is None or e["token"] != tok or e.get("streak", 0) < 1 or e["shape"] != tuple(context.shape)
-                or e["dtype"] != context.dtype or e["device"] != context.device):
+                or e["dtype"] != context.dtype or e["device"] != context.device or e["stream"] != engine.STREAM_DTYPE):
             return None
         return e
 
@@ -424,8 +427,10 @@ class ContextKV:
         copy = self._bufs_for(("pin-copy", slot, tuple(context.shape), context.dtype, context.device),
                               lambda: torch.empty(tuple(context.shape), dtype=context.dtype, device=context.device))
         copy.copy_(context.detach())
+        # `stream`: the projections of the chain emitted rows of this type (fp32 / fp16 activation stream) — the codes of another
+        # stream type differ at ties, so an entry serves evaluations of its own stream type only
         e = dict(slot=slot, gen=self._slot_gen[slot], token=tok, copy=copy, shape=tuple(context.shape), dtype=context.dtype,
-                 device=context.device, alias={}, out=out, locked=locked)
+                 device=context.device, alias={}, out=out, locked=locked, stream=engine.STREAM_DTYPE)
         self._alias(e, context, engine.tensor_version(context))
         self._pins.append(e)
         return e

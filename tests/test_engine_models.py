@@ -325,6 +325,7 @@ def test_default_graph_replay_and_value_matched_context(cuda, monkeypatch):
         want = [ref(xx, t, c).clone() for xx in xs]
         want2 = [ref(xx, t, c2).clone() for xx in xs]
     monkeypatch.setattr(qb, "_CTX_AUTO", True)
+    monkeypatch.setattr(qb, "_CTX_SPECULATE", True)        # also exercise the speculative replay (off by default: no gain measured)
     qnn = _resume(fx, cuda)                                # defaults: graph replay on (second sight), contexts prepared on first sight
     ckv = qnn.__dict__["_ctx_kv"]
     assert qnn._graphs == {} and not ckv._pins
