@@ -709,7 +709,10 @@ def main():
             # dt = one sample through one UNet evaluation; an image needs `evals` evaluations of 2 samples (CFG) or 1
             per_image = evals * (2 if guide != 1.0 else 1) * dt
             out["cpu_baseline"] = {"value": round(1.0 / per_image, 6), "unit": "images/s", "cores": cpu_threads,
-                                   "kind": "port", "sample": f"UNet evaluations of one sample on the host cores: 1 warm-up, one evaluation per "
+                                   "kind": "port", "what": "oracle/unet_ref.py — the CPU PORT of the reference's fake-quant forward (pinned bit for bit to the "
+                                                           "reference's outputs; /root/reference does not exist on the GPU box), at BATCH 1, at the best "
+                                                           "thread count of a sweep; the unmodified reference on 8 build-container cores: profiles/r02_cpu_reference_time.json",
+                                   "sample": f"UNet evaluations of one sample on the host cores: 1 warm-up, one evaluation per "
                                                              f"thread count {cpu_sweep} (seconds), then 2 timed at the best ({cpu_threads} of "
                                                              f"{torch.get_num_threads()} threads): {dt:.1f} s each; extrapolated to {evals} evaluations x "
                                                              f"{2 if guide != 1.0 else 1} samples per image"}

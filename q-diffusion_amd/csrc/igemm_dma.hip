@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
 
     // The epilogue re-uses the (dead) ring as per-wave transposition tiles + the GroupNorm partials behind them: 4 KB per wave,
     // 8 KB for the fp16 stream (two MFMA tiles = 64 columns = one 128-byte line of halves per row, see the epilogue)
-    constexpr int TBW = (OUT == O_F16 && !BF) ? 8192 : 4096;
+    constexpr int TBW = ((OUT == O_F16 || OUT == O_HROWS) && !BF) ? 8192 : 4096;
     constexpr int EPI_BYTES = 4 * TBW + 4 * WCOLS * 8;
     constexpr int RING = 3 * STAGE > EPI_BYTES ? 3 * STAGE : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[RING + 2 * BM * 4 + 4 * BN * 4];
@@ -648,8 +648,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
         const bool res16 = p.res_f16 != 0;             // the residual stream is fp16 (8-byte loads of four halves)
         auto epi = [&](auto ft) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(ft)::value;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        auto tile1 = [&](const int j) __attribute__((always_inline)) {
             const int cl = wn * WCOLS + j * 32 + frow;
             const float sc = sScale[cl];
             const int zw_n = sZw[cl];
@@ -669,7 +668,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
                 for (int r = 0; r < 16; ++r) {
                     const int rl = crow(r) + 4 * fhalf;
                     const int I = acc[i][j][r] - zc2 - __mul24(zw_n, as[r]);
-                    tb[rl * 32 + frow] = __float_as_uint((float)I * sc + bias_n);
+                    tb[rl * 32 + frow] = __float_as_uint(__builtin_fmaf((float)I, sc, bias_n));
                 }
                 v4f rs[4];
                 if (hres) {
@@ -685,14 +684,73 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
                     const int rl = ps * 8 + rr0;
                     v4f v = *reinterpret_cast<const v4f*>(tb + rl * 32 + c4);
                     if (hres) v += rs[ps];
-                    int b0, b1, b2, b3;
-                    qd_bytes2_t<FAST>(v2f{v[0], v[1]} * qd_splat2(p.oqpre), oqp, oqb, b0, b1);
-                    qd_bytes2_t<FAST>(v2f{v[2], v[3]} * qd_splat2(p.oqpre), oqp, oqb, b2, b3);
-                    const unsigned w = __builtin_amdgcn_perm(__builtin_amdgcn_perm((unsigned)b3, (unsigned)b2, 0x0c0c0400u),
-                                                             __builtin_amdgcn_perm((unsigned)b1, (unsigned)b0, 0x0c0c0400u), 0x05040100u);
+                    const unsigned w = qd_pack4_t<FAST>(v[0] * p.oqpre, v[1] * p.oqpre, v[2] * p.oqpre, v[3] * p.oqpre, oqp, oqb);
                     if (nok) *reinterpret_cast<unsigned*>(ob + (long)(rbase + rl) * p.hddpad) = w;
                 }
             }
+        };
+        // head dims that are multiples of 8 (40 / 80 / 160; one "head" as wide as the layer): TWO tiles per transposition
+        // (the 8-KB swizzled LDS tile of the fp16 stream's full-line epilogue), 8 columns and ONE 8-byte store per lane — half
+        // the phase-2 instructions per code; these launches are instruction-bound (a K = 320 q projection that writes 21 MB of
+        // codes took longer than the same GEMM writing 84 MB of fp32).  Same values, same codes.
+        auto tile2 = [&](const int j) __attribute__((always_inline)) {
+            const int cl0 = wn * WCOLS + j * 32 + frow, cl1 = cl0 + 32;
+            const float sc0 = sScale[cl0], sc1 = sScale[cl1];
+            const int zw0 = sZw[cl0], zw1 = sZw[cl1];
+            const int zc0 = sZc[cl0] - zw0 * kz, zc1 = sZc[cl1] - zw1 * kz;
+            const float bias0 = sBias[cl0], bias1 = sBias[cl1];
+            const int k8 = lane & 7, sw = (lane >> 3) & 1;
+            const int n8 = wcol0 + j * 32 + k8 * 8;
+            const bool nok = n8 < p.Cout;              // Cout % 8 == 0 (host)
+            const int nn = nok ? n8 : 0;
+            const int h = (int)__umulhi((unsigned)nn, p.hdrcp), dd = nn - h * p.hdd;     // 8 columns never straddle a head (hdd % 8 == 0)
+            int8_t* ob = o8 + (((long)bidx * p.hdH + h) * p.hdTpad + t0) * p.hddpad + dd;
+            const int rd_lo = ((2 * k8) ^ sw) * 4, rd_hi = ((2 * k8 + 1) ^ sw) * 4;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int rbase = wrow0 + i * 32;
+                int as[16];
+                row_terms(rbase, as);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = crow(r) + 4 * fhalf;
+                    const int I0 = acc[i][j][r] - zc0 - __mul24(zw0, as[r]);
+                    const int I1 = acc[i][j + 1][r] - zc1 - __mul24(zw1, as[r]);
+                    const int pc = frow ^ ((r & 1) << 2);
+                    tb[rl * 64 + pc] = __float_as_uint(__builtin_fmaf((float)I0, sc0, bias0));
+                    tb[rl * 64 + 32 + pc] = __float_as_uint(__builtin_fmaf((float)I1, sc1, bias1));
+                }
+#pragma unroll
+                for (int pb = 0; pb < 4; pb += 2) {
+                    v4f ra[2], rb2[2];
+                    if (hres) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const long ro = (long)(m0 + rbase + (pb + u) * 8 + rr0) * p.ldr + nn;
+                            if (res16) qd_h8_to_f(*reinterpret_cast<const v4i*>(rh16 + ro), ra[u], rb2[u]);
+                            else { ra[u] = *reinterpret_cast<const v4f*>(rf + ro); rb2[u] = *reinterpret_cast<const v4f*>(rf + ro + 4); }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int rl = (pb + u) * 8 + rr0;
+                        v4f lo = *reinterpret_cast<const v4f*>(tb + rl * 64 + rd_lo);
+                        v4f hi = *reinterpret_cast<const v4f*>(tb + rl * 64 + rd_hi);
+                        if (hres) { lo += ra[u]; hi += rb2[u]; }
+                        const unsigned w0 = qd_pack4_t<FAST>(lo[0] * p.oqpre, lo[1] * p.oqpre, lo[2] * p.oqpre, lo[3] * p.oqpre, oqp, oqb);
+                        const unsigned w1 = qd_pack4_t<FAST>(hi[0] * p.oqpre, hi[1] * p.oqpre, hi[2] * p.oqpre, hi[3] * p.oqpre, oqp, oqb);
+                        if (nok) *reinterpret_cast<uint2*>(ob + (long)(rbase + rl) * p.hddpad) = make_uint2(w0, w1);
+                    }
+                }
+            }
+        };
+        if (p.vec == 2) {
+#pragma unroll
+            for (int q2 = 0; q2 < NT / 2; ++q2) tile2(2 * q2);
+            if constexpr (NT % 2 == 1) tile1(NT - 1);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) tile1(j);
         }
         };
         QD_FAST_DISPATCH(oqp.fast, epi);
@@ -1461,6 +1519,10 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
         QD_REQUIRE(!d->rowbias && (!d->residual || (d->epilogue == QD_EPI_HEADS_I8 && d->ldr % 4 == 0 && qd_aligned(d->residual, 4 * esz))),
                    "qd_conv2d_i8: heads epilogue takes no rowbias; a residual (fp32 or fp16 as out_dtype says, 4-element aligned rows) only with QD_EPI_HEADS_I8");
         k.res_f16 = d->out_dtype == QD_F16 ? 1 : 0;
+        // head rows written 8 codes per lane (two tiles per transposition): head dim, padded head dim and the residual rows 8-aligned
+        static const bool heads8 = !(getenv("QD_HEADS8") && atoi(getenv("QD_HEADS8")) == 0);          // A/B knob
+        k.vec = (heads8 && d->epilogue == QD_EPI_HEADS_I8 && d->hd_d % 8 == 0 && d->hd_dpad % 8 == 0 && d->Cout % 8 == 0 && qd_aligned(d->out, 8) &&
+                 (!d->residual || (d->ldr % 8 == 0 && qd_aligned(d->residual, 16)))) ? 2 : 1;
         k.oq = d->oq_params; k.oqmin = (float)d->oq_min; k.oqmax = (float)d->oq_max; k.oqoff = d->oq_off;
         k.hdH = d->hd_H; k.hdd = d->hd_d; k.hdT = d->hd_T; k.hdTpad = d->hd_Tpad; k.hddpad = d->hd_dpad;
         k.oqpre = d->oq_prescale; k.hdsum = d->hd_sum;

@@ -859,10 +859,11 @@ def test_attention_keyterm_table(cuda):
         assert torch.equal(got.cpu(), want)
 
 
-@pytest.mark.parametrize("T,N,K", [(128, 320, 320), (256, 640, 640), (512, 320, 1280)])
+@pytest.mark.parametrize("T,N,K", [(128, 320, 320), (256, 640, 640), (512, 320, 1280), (128, 288, 320), (256, 1280, 320), (128, 256, 640)])
 def test_projection_heads_epilogue_matches_quantize_heads(cuda, T, N, K):
     """q/k/v projections that write attention operand bytes from the GEMM epilogue (QD_EPI_HEADS_*) produce
-    exactly the bytes (and V column sums) of the fp32 projection followed by qd_quantize_heads."""
+    exactly the bytes (and V column sums) of the fp32 projection followed by qd_quantize_heads.  Round 5: head dims that are
+    multiples of 8 (40 / 80 / 160 / 32) leave 8 codes per lane (two tiles per transposition); d = 36 keeps the 4-code form."""
     from qdiff import engine
     B, H = 2, 8
     d = N // H
