@@ -1446,7 +1446,8 @@ int choose_splitk(const qd_conv_desc* d, int* it_per) {
     if (blocks0 > 256) return 1;
     const long mn = M * N;
     const int min_steps = mn <= (1L << 18) ? 2 : (mn <= (3L << 19) ? 4 : 16);
-    long S = 512 / blocks0;
+    static const long target = getenv("QD_SPLITK_TARGET") ? atol(getenv("QD_SPLITK_TARGET")) : 512;       // blocks the split should reach (A/B knob)
+    long S = target / blocks0;
     if (S > total / min_steps) S = total / min_steps;
     if (S > 32) S = 32;
     if (S < 2) return 1;

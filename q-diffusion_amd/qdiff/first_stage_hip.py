@@ -276,7 +276,7 @@ def adopt_reference_decoder():
             if not _ADOPT_LOGGED[0]:
                 _ADOPT_LOGGED[0] = True
                 logger.info("first-stage Decoder.forward runs on qdiff's fp16-operand MFMA kernels (QDIFF_ADOPT_DECODER=%s)", ADOPT_DECODER)
-            return out.to(torch.get_autocast_gpu_dtype()) if (z.is_cuda and torch.is_autocast_enabled()) else out
+            return out.to(torch.get_autocast_dtype('cuda')) if (z.is_cuda and torch.is_autocast_enabled()) else out
         return ref_forward(self, z)
 
     cls.forward = forward
