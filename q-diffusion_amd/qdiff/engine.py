@@ -127,7 +127,8 @@ def geglu_row_perm(F, device):
 def pack_module_weights(weight, quantizers, split, row_perm=None):
     """weight: fp32 [Cout, Cin, *k] on the GPU; quantizers: [wq] or [wq, wq_0] (UniformAffine- or
     AdaRound-like objects with delta/zero_point[/alpha]/n_levels).  row_perm: optional output-row
-    permutation applied to the weight and to every per-row quantity.  Returns a WeightPack."""
+    permutation — or selection: fewer indices than rows (QuantModule.head_plans) — applied to the weight and to every
+    per-row quantity.  Returns a WeightPack."""
     dev = weight.device
     w = weight.detach().float().contiguous()
     if row_perm is not None:
@@ -141,7 +142,7 @@ def pack_module_weights(weight, quantizers, split, row_perm=None):
         raise hip.HipEngineError("split / quantiser count mismatch")
     levels = _w_levels(quantizers[0])
     zps = [q.zero_point.detach().float().reshape(-1).to(dev) if torch.is_tensor(q.zero_point)
-           else torch.full((Cout,), float(q.zero_point), device=dev) for q in quantizers]
+           else torch.full((weight.shape[0],), float(q.zero_point), device=dev) for q in quantizers]
     if row_perm is not None:
         zps = [z.index_select(0, row_perm) for z in zps]
     zall = torch.cat(zps)
@@ -174,7 +175,7 @@ def pack_module_weights(weight, quantizers, split, row_perm=None):
     pk.wq = torch.zeros(kstep * ntiles * (1024 if mode == 4 else 2048), dtype=torch.uint8, device=dev)
     for sg, q, z in zip(segs, quantizers, zps):
         delta = q.delta.detach().float().reshape(-1).to(dev).contiguous()
-        if delta.numel() != Cout:
+        if delta.numel() != weight.shape[0]:
             raise hip.HipEngineError("weight quantiser must be channel-wise (per output channel)")
         alpha = getattr(q, "alpha", None)
         if alpha is not None:
@@ -226,6 +227,30 @@ def pack_from_dict(d, device):
         sg.update({k: dev(e.get(k)) for k in _PACK_SEG_TENSORS})
         pk.segs.append(sg)
     return pk
+
+
+def pack_select_tiles(pk, rows):
+    """Sub-pack of the output rows `rows` (index tensor, whole 32-row tiles at tile-aligned positions) of a tile-ordered
+    pack: the [kstep][n/32][1 KB | 2 KB] operand is gathered tile by tile, the per-row constants row by row — nothing is
+    re-quantised, so this also works on the frozen pack of a packed checkpoint whose fp32 weights are gone."""
+    n = int(rows.numel())
+    if not pk.tiled or pk.row_perm is not None or n % 32 != 0:
+        return None
+    r = rows.view(-1, 32)
+    if bool((r[:, 0] % 32 != 0).any()) or not torch.equal(r, r[:, :1] + torch.arange(32, device=rows.device)):
+        return None
+    tile_bytes = 1024 if pk.mode == 4 else 2048
+    ntiles = (pk.Cout + 31) // 32
+    sub = WeightPack()
+    sub.ldk, sub.wbits, sub.mode, sub.taps, sub.Cin, sub.tiled = pk.ldk, pk.wbits, pk.mode, pk.taps, pk.Cin, True
+    sub.Cout, sub.row_perm = n, rows
+    sub.wq = pk.wq.view(-1, ntiles, tile_bytes).index_select(1, (r[:, 0] // 32).to(pk.wq.device)).reshape(-1).contiguous()
+    sub.segs = []
+    for sg in pk.segs:
+        e = {k: sg[k] for k in _PACK_SEG_INTS if k in sg}
+        e.update({k: (None if sg.get(k) is None else sg[k].index_select(0, rows.to(sg[k].device)).contiguous()) for k in _PACK_SEG_TENSORS})
+        sub.segs.append(e)
+    return sub
 
 
 # ------------------------------------------------------------------------------------------------

@@ -248,6 +248,7 @@ _CTX_AUTO = os.environ.get("QDIFF_CTX_AUTO", "1") != "0"
 #  enqueueing a replay costs 0.15 ms, nothing to hide, and every prompt change wastes one speculative evaluation)
 _CTX_SPECULATE = os.environ.get("QDIFF_CTX_SPECULATE", "0") == "1"
 _FUSE_SKIP_QUANT = os.environ.get("QDIFF_FUSE_SKIP_QUANT", "1") != "0"     # A/B knob: skip-connection rows from the GroupNorm pass
+QKV_HEADS = os.environ.get("QDIFF_QKV_HEADS", "1") != "0"         # A/B knob: the LDM AttentionBlock's qkv as three GEMMs with operand epilogues
 CAT_SLOTS = os.environ.get("QDIFF_CAT_SLOTS", "1") != "0"         # A/B knob: planned skip-concatenation buffers (engine.CatSlot)
 
 
@@ -875,6 +876,10 @@ class QuantAttentionBlock(BaseQuantBlock, _AttnQuant):
     def _forward(self, x, out_slot=None):
         b, c, *spatial = x.shape
         if x.dim() == 4 and self._fusable():
+            T = x.shape[2] * x.shape[3]
+            plans = self.qkv.head_plans(self.num_heads) if (QKV_HEADS and T % 128 == 0 and self.qkv.act_quantizer.inited) else None
+            if plans is not None and all(engine.heads_fusable(p, T, self.num_heads) for p in plans):
+                return self._forward_heads(x, plans, out_slot)
             return self._forward_int(x, out_slot)
         xf = x.reshape(b, c, -1)
         h = self.proj_out(self.attention(self.qkv(self.norm(xf))))
@@ -897,6 +902,34 @@ class QuantAttentionBlock(BaseQuantBlock, _AttnQuant):
         strides = (T * ld, ld, 3 * d, 1)
         att = engine.attention(ap, qkv, qkv[:, d:], qkv[:, 2 * d:], B, T, T, nh, d, strides, strides, strides)
         out = _linear_like_conv1d(self.proj_out, att, B, T, residual=rows, gn_stats=True, slot=out_slot)
+        return _rows_to_nchw(out, B, H, W)
+
+    def _forward_heads(self, x, plans, out_slot=None):
+        """The same block with the qkv projection run as three GEMMs (QuantModule.head_plans) whose epilogues write the
+        attention operand bytes: no fp32 [B*T, 3C] round trip, no separate head quantisers; the attention epilogue
+        quantises for proj_out where its quantiser is ready."""
+        B, C, H, W = x.shape
+        T, nh = H * W, self.num_heads
+        d = C // nh
+        rows = _nhwc_rows(x)
+        xq = _gn_silu_to(self.qkv, rows, B, T, C, self.norm, silu=False)
+        qk, smv = self.attention.qkv_matmul, self.attention.smv_matmul
+        holder = self.__dict__.setdefault("_aq_view", type("V", (), {})())
+        holder.act_quantizer_q, holder.act_quantizer_k = qk.act_quantizer_q, qk.act_quantizer_k
+        holder.act_quantizer_v, holder.act_quantizer_w = smv.act_quantizer_v, smv.act_quantizer_w
+        scale = float(qk.scale) if qk.scale is not None else d ** -0.25
+        ap = self._attn_plan(holder, 1.0, scale, x.device)
+        q8, k8, v8, vsum = engine.head_buffers(x.device, B * nh, T, T, d)
+        vsum = engine.vsum_slice(id(self), x.device, tuple(vsum.shape))
+        for which, (plan, buf) in enumerate(zip(plans, (q8, k8, v8))):
+            engine.project_heads(plan, xq, B, T, nh, ap, which, buf, vsum)
+        po = self.proj_out
+        if po.act_quantizer.inited and po.split == 0 and po.conv_plan().ldx == C and len(po.conv_plan().segs) == 1:
+            o8 = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, T, nh, d, out_plan=po.conv_plan())
+            out = po.forward_codes(o8, B, 1, T, residual=rows, gn_stats=True, slot=out_slot)
+        else:
+            att = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, T, nh, d)
+            out = _linear_like_conv1d(po, att, B, T, residual=rows, gn_stats=True, slot=out_slot)
         return _rows_to_nchw(out, B, H, W)
 
 

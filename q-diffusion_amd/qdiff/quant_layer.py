@@ -448,6 +448,7 @@ class QuantModule(nn.Module):
         engine.bump_state()
         self._pack_key = self._plan_key = self._wdq_key = None
         self.__dict__.pop('_geglu_cache', None)
+        self.__dict__.pop('_heads_cache', None)
         self.__dict__.pop('_frozen_pack', None)
         self.__dict__.pop('_frozen_geglu_pack', None)
 
@@ -460,6 +461,7 @@ class QuantModule(nn.Module):
         self.__dict__['_frozen_geglu_pack'] = geglu_pack
         self._pack_key = self._plan_key = None
         self.__dict__.pop('_geglu_cache', None)
+        self.__dict__.pop('_heads_cache', None)
 
     def plan_keys(self):
         """(wkey, akey): identity of everything the packed weights resp. the whole plan are made from — quantiser objects and
@@ -566,6 +568,40 @@ class QuantModule(nn.Module):
             pack = engine.pack_module_weights(self.weight, [wq], 0, row_perm=engine.geglu_row_perm(F, self.weight.device))
             cache[1] = engine.build_conv_plan(pack, [aq], 1, 1, 1, 0, self.bias) if (pack.tiled and pack.wbits == 4) else None
             cache[0] = key
+        return cache[1]
+
+    def head_plans(self, heads):
+        """Three plans (q, k, v) of a fused qkv 1x1 projection whose output channels are ordered [head][q | k | v][d] (the
+        QKVAttentionLegacy layout of the LDM AttentionBlock, reference quant_block.py:163-187 / openaimodel.py qkv conv1d):
+        the rows of each role gathered head-major, so that each role runs as its own GEMM with the attention-operand
+        epilogue (engine.project_heads) — per-output-channel weight quantisers make the row subsets exact.  With heads of
+        a multiple of 32 channels the three operands are gathered tile by tile from the layer's own pack (also the frozen
+        one of a packed checkpoint); otherwise the rows are packed again from the live weight.  None when the layer does
+        not qualify (split input, a kernel wider than one tap, channels not divisible, frozen weights with ragged heads)."""
+        if self.split != 0 or self.kind not in ('conv1d', 'linear'):
+            return None
+        pack = self.conv_plan().pack
+        C3 = pack.Cout
+        if C3 % (3 * heads) != 0 or pack.taps != 1 or not pack.tiled:
+            return None
+        d = C3 // (3 * heads)
+        frozen = self.__dict__.get('_frozen_pack') is not None
+        if frozen and d % 32 != 0:
+            return None
+        wkey, akey = self.plan_keys()
+        key = (heads, akey)
+        cache = self.__dict__.setdefault('_heads_cache', [None, None])
+        if cache[0] != key:
+            dev = pack.wq.device
+            base = (torch.arange(heads, device=dev) * (3 * d))[:, None] + torch.arange(d, device=dev)[None, :]
+            plans = []
+            for role in range(3):
+                rows = (base + role * d).reshape(-1)
+                sub = engine.pack_select_tiles(pack, rows) if d % 32 == 0 else None
+                if sub is None and not frozen:
+                    sub = engine.pack_module_weights(self.weight, [self.weight_quantizer], 0, row_perm=rows)
+                plans.append(None if sub is None else engine.build_conv_plan(sub, [self.act_quantizer], 1, 1, 1, 0, self.bias))
+            cache[0], cache[1] = key, (plans if all(p is not None and p.pack.tiled for p in plans) else None)
         return cache[1]
 
     def forward_codes(self, xq, B, H, W, Ho=None, Wo=None, rowbias=None, residual=None, pad_tl=None, gn_stats=False, slot=None,

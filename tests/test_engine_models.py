@@ -213,6 +213,54 @@ def test_packed_checkpoint_round_trip_on_gpu(cuda, name, tmp_path):
     assert d <= 1.5 * dself + 1e-3 * ref.abs().max().item() and cos >= 0.995, (d, dself, cos)
 
 
+@pytest.mark.parametrize("name", ["ldm_tiny", "ldm_full"])
+def test_ldm_attention_qkv_operand_projections_on_gpu(cuda, name, monkeypatch, tmp_path):
+    """The LDM AttentionBlock's qkv conv1d as three GEMMs with attention-operand epilogues (QuantModule.head_plans,
+    QuantAttentionBlock._forward_heads; reference quant_block.py:163-187): the same quantiser inputs (I*scale + bias in one
+    fma, times the q / k prescale) as the fp32 projection + qd_quantize_heads route, so the UNet output is the same bit for
+    bit; the route is taken where the token count is a multiple of 128 and survives a packed checkpoint when the heads are
+    whole 32-row tiles (LDM-4: 32 channels per head)."""
+    import qdiff
+    from qdiff import hip, quant_block
+    from qdiff.utils import load_packed_ckpt, save_packed_ckpt
+    fx = load_fixture(f"model_{name}.pt")
+    qnn = _resume(fx, cuda)
+    calls = {"heads": 0, "float": 0}
+    real_conv, real_qh = hip.conv2d_i8, hip.quantize_heads
+
+    def counting_conv(cc, acc_out=None):
+        calls["heads"] += cc.epilogue in (hip.EPI_HEADS_I8, hip.EPI_HEADS_T_I8) and cc.heads["H"] > 1
+        return real_conv(cc, acc_out)
+
+    def counting_qh(*a, **k):
+        calls["float"] += 1
+        return real_qh(*a, **k)
+    monkeypatch.setattr(hip, "conv2d_i8", counting_conv)
+    monkeypatch.setattr(hip, "quantize_heads", counting_qh)
+    qnn.enable_hip_graphs(False)
+    monkeypatch.setattr(quant_block, "QKV_HEADS", False)
+    want = _run(qnn, fx, cuda)
+    assert calls["heads"] == 0 and calls["float"] > 0
+    n_float = calls["float"]
+    monkeypatch.setattr(quant_block, "QKV_HEADS", True)
+    calls.update(heads=0, float=0)
+    got = _run(qnn, fx, cuda)
+    assert calls["heads"] > 0 and calls["heads"] + calls["float"] == n_float, calls
+    assert torch.equal(got, want)
+    if name == "ldm_full":
+        n_heads = calls["heads"]
+        path = str(tmp_path / "packed.pth")
+        save_packed_ckpt(qnn, path)
+        spec = fx["spec"]
+        wq, aq = quant_params(spec)
+        q2 = qdiff.QuantModel(build_engine_model(spec).to(cuda), wq, aq, sm_abit=spec["sm_abit"]).to(cuda).eval()
+        load_packed_ckpt(q2, path)
+        q2.enable_hip_graphs(False)
+        calls.update(heads=0, float=0)
+        assert torch.equal(_run(q2, fx, cuda), want)
+        assert calls["heads"] == n_heads, calls
+
+
 @pytest.mark.parametrize("name", ["sd_tiny", "ldm_tiny"])
 def test_hip_graph_replay_equals_eager(cuda, name):
     """bench.py measures HIP-graph replay: the replayed evaluation must equal the eager one bit for bit, for inputs

@@ -859,13 +859,18 @@ def test_attention_keyterm_table(cuda):
         assert torch.equal(got.cpu(), want)
 
 
-@pytest.mark.parametrize("T,N,K", [(128, 320, 320), (256, 640, 640), (512, 320, 1280), (128, 288, 320), (256, 1280, 320), (128, 256, 640)])
-def test_projection_heads_epilogue_matches_quantize_heads(cuda, T, N, K):
+@pytest.mark.parametrize("T,N,K,H", [(128, 320, 320, 8), (256, 640, 640, 8), (512, 320, 1280, 8), (128, 288, 320, 8), (256, 1280, 320, 8),
+                                     (128, 256, 640, 8),
+                                     # the LDM AttentionBlock's role projections (QuantModule.head_plans): LDM-4 beds, 32 channels
+                                     # per head at 448 / 672 / 896 channels; LSUN-churches LDM-8, 8 heads of 24 / 48 / 96
+                                     (256, 448, 448, 14), (128, 672, 672, 21), (128, 896, 896, 28), (256, 192, 192, 8), (128, 384, 384, 8),
+                                     (128, 768, 768, 8)])
+def test_projection_heads_epilogue_matches_quantize_heads(cuda, T, N, K, H):
     """q/k/v projections that write attention operand bytes from the GEMM epilogue (QD_EPI_HEADS_*) produce
     exactly the bytes (and V column sums) of the fp32 projection followed by qd_quantize_heads.  Round 5: head dims that are
     multiples of 8 (40 / 80 / 160 / 32) leave 8 codes per lane (two tiles per transposition); d = 36 keeps the 4-code form."""
     from qdiff import engine
-    B, H = 2, 8
+    B = 2
     d = N // H
     g = torch.Generator().manual_seed(31)
     x = torch.randn(B * T, K, generator=g)

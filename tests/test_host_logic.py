@@ -638,6 +638,90 @@ def test_layernorm_in_the_producing_epilogue_changes_nothing(emu, monkeypatch):
     assert calls["ln"] == 0 and calls["fused"] == n_ln, calls
 
 
+def test_ldm_attention_block_qkv_as_three_operand_projections(emu, monkeypatch):
+    """The LDM AttentionBlock's fused qkv conv1d (output channels [head][q | k | v][d], reference quant_block.py:163-187) runs as
+    three GEMMs over row subsets of its weight whose epilogues write the attention operand bytes (QuantModule.head_plans,
+    quant_block.QuantAttentionBlock._forward_heads): per-output-channel weight quantisers make the subsets exact, so the
+    UNet output is the one of the fp32-round-trip route bit for bit; the route is taken where the token count allows it
+    (256 tokens at the first level of the tiny model, not the 64 of the second) and not after a packed checkpoint froze the
+    layer's weights."""
+    from qdiff import engine, hip, quant_block
+    fx = load_fixture("model_ldm_tiny.pt")
+    qnn = _resume_cpu(fx)
+    x, t, _ = fixture_inputs(fx, "test")
+    calls = {"heads": 0, "float": 0}
+    real_conv, real_qh = hip.conv2d_i8, hip.quantize_heads
+
+    def counting_conv(cc, acc_out=None):
+        calls["heads"] += cc.epilogue in (hip.EPI_HEADS_I8, hip.EPI_HEADS_T_I8) and cc.heads["H"] > 1
+        return real_conv(cc, acc_out)
+
+    def counting_qh(*a, **k):
+        calls["float"] += 1
+        return real_qh(*a, **k)
+    monkeypatch.setattr(hip, "conv2d_i8", counting_conv)
+    monkeypatch.setattr(hip, "quantize_heads", counting_qh)
+    blocks = [m for m in qnn.modules() if isinstance(m, quant_block.QuantAttentionBlock)]
+    assert blocks
+    monkeypatch.setattr(quant_block, "QKV_HEADS", False)
+    with torch.no_grad():
+        want = qnn(x, t)
+    assert calls["heads"] == 0 and calls["float"] == 3 * len(blocks)
+    monkeypatch.setattr(quant_block, "QKV_HEADS", True)
+    calls.update(heads=0, float=0)
+    with torch.no_grad():
+        got = qnn(x, t)
+    fused = [b for b in blocks if b.qkv.__dict__.get("_heads_cache", [None, None])[1] is not None]
+    assert 0 < len(fused) < len(blocks)
+    assert calls["heads"] == 3 * len(fused) and calls["float"] == 3 * (len(blocks) - len(fused)), calls
+    assert torch.equal(got, want)
+    # the three plans hold exactly the rows of their role, head-major
+    b = fused[0]
+    nh, C = b.num_heads, b.channels
+    d = C // nh
+    for role, plan in enumerate(b.qkv.head_plans(nh)):
+        rows = torch.cat([torch.arange(d) + h * 3 * d + role * d for h in range(nh)])
+        assert torch.equal(plan.pack.row_perm.cpu(), rows) and plan.Cout == C
+        assert torch.equal(plan.bias.cpu(), b.qkv.bias.detach().float()[rows])
+    # a re-assigned quantiser rebuilds them
+    before = b.qkv.head_plans(nh)
+    b.qkv.act_quantizer.delta = torch.nn.Parameter(b.qkv.act_quantizer.delta.detach() * 1.5)
+    assert b.qkv.head_plans(nh) is not before
+
+
+def test_head_plans_gathered_from_the_pack_equal_a_fresh_packing(emu):
+    """Heads of a multiple of 32 channels (LDM-4: 32): the q / k / v operands are whole 32-row tiles of the layer's own pack
+    (engine.pack_select_tiles) — the same bytes and per-row constants as packing the row subset from the fp32 weight, and
+    available when a packed checkpoint froze the layer (the fp32 weight is gone then)."""
+    import qdiff
+    from qdiff import engine
+    torch.manual_seed(3)
+    heads, d, cin = 2, 32, 48
+    m = qdiff.QuantModule(torch.nn.Conv1d(cin, 3 * heads * d, 1), dict(n_bits=4, channel_wise=True, scale_method="max"),
+                          dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True))
+    m.set_quant_state(True, True)
+    m._init_act_quantizers(torch.randn(2, cin, 128))
+    plans = m.head_plans(heads)
+    assert plans is not None and len(plans) == 3
+    for role, plan in enumerate(plans):
+        rows = torch.cat([torch.arange(d) + h * 3 * d + role * d for h in range(heads)])
+        fresh = engine.pack_module_weights(m.weight, [m.weight_quantizer], 0, row_perm=rows)
+        assert plan.pack.Cout == fresh.Cout == heads * d and plan.pack.ldk == fresh.ldk
+        assert torch.equal(plan.pack.wq, fresh.wq)
+        for a, b in zip(plan.pack.segs, fresh.segs):
+            assert all(a[k] == b[k] for k in engine._PACK_SEG_INTS if k in b)
+            assert all(torch.equal(a[k], b[k]) for k in ("wsum", "delta_w", "zw"))
+        assert torch.equal(plan.bias, m.bias.detach()[rows])
+    # ragged selections are refused, frozen layers still serve tile-aligned heads
+    assert engine.pack_select_tiles(m.conv_plan().pack, torch.arange(16)) is None
+    assert engine.pack_select_tiles(m.conv_plan().pack, torch.arange(32) + 16) is None
+    m.load_packed(engine.pack_from_dict(engine.pack_to_dict(m.conv_plan().pack), "cpu"))
+    m.weight.data = torch.empty(0)
+    frozen = m.head_plans(heads)
+    assert frozen is not None and all(torch.equal(a.pack.wq, b.pack.wq) for a, b in zip(frozen, plans))
+    assert m.head_plans(3) is None                        # 192 channels do not divide into 3 x 3 groups
+
+
 def test_sampling_under_inference_mode_and_value_match_of_inference_tensors(emu):
     """tensors created under torch.inference_mode() carry no version counter (`t._version` raises); the prepared-
     context bookkeeping and the plan caches must not touch it.  An inference tensor is recognised by value only."""
