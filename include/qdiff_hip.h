@@ -173,7 +173,8 @@ typedef struct {
      * HEADS_I8 also accepts an fp32 `residual` (added before the quantiser): with hd_H = 1, hd_d = Cout it is
      * "Linear + residual -> int8 rows of the next Linear" (transformer FF output feeding SpatialTransformer.proj_out).
  * Pad bytes are not written: out must be zero-initialised once (it can then be reused).
-     * hd_T must be a multiple of 128 (a tile of rows never straddles two samples).                         */
+     * hd_T must be a multiple of 128 (a tile of rows never straddles two samples).  Weights: int4 tiles of any width,
+     * or int8 tiles with Cout > 64 (the 1x1 q / k / v convolutions of the pixel-space AttnBlock, quant_block.py:354-386). */
     int32_t        hd_H, hd_d, hd_T, hd_Tpad, hd_dpad;
     float          oq_prescale;
     int32_t*       hd_sum;

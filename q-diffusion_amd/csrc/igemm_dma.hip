@@ -1422,7 +1422,8 @@ int dispatch(ConvD& k, bool split, int out, hipStream_t st, int nsplit = 1) {
         QD_CASE(false, O_F32)
         QD_CASE(false, O_F16)
         if constexpr (MT == 1 && WM == 4) { QD_CASE(false, O_I32) QD_CASE(true, O_F32) QD_CASE(true, O_F16) QD_CASE(false, O_PART) }
-        if constexpr (WB == 4 && WM == 4) { QD_CASE(false, O_HROWS) QD_CASE(false, O_HTR) }
+        // (int8 weights: the 128 x 128 tile only — the CIFAR attention block's q / k / v, 256 channels)
+        if constexpr ((WB == 4 && WM == 4) || (WB == 8 && MT == 1 && NT == 4)) { QD_CASE(false, O_HROWS) QD_CASE(false, O_HTR) }
         if constexpr (NT == 4 && WB == 4 && WM == 4) { QD_CASE(false, O_GEGLU) }
         if constexpr (MT == 1 && NT == 10 && WB == 4 && WM == 4) { QD_CASE(false, O_LN) }
     }
@@ -1468,7 +1469,8 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
     QD_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->kh * d->kw <= 32, "qd_conv2d_i8: bad kernel/stride (at most 32 taps)");
     QD_REQUIRE((long)d->B * d->Ho * d->Wo < (1L << 31), "qd_conv2d_i8: M overflows int32");
     const bool w8 = d->wbits == 8;
-    QD_REQUIRE(!w8 || d->epilogue == QD_EPI_LINEAR, "qd_conv2d_i8: the fused GEGLU / head-layout epilogues are int4-weight only");
+    QD_REQUIRE(!w8 || d->epilogue == QD_EPI_LINEAR || ((d->epilogue == QD_EPI_HEADS_I8 || d->epilogue == QD_EPI_HEADS_T_I8) && d->Cout > 64),
+               "qd_conv2d_i8: int8 weights take the linear epilogue, or the head-layout epilogues on more than 64 output channels");
     QD_REQUIRE(d->ldx % 16 == 0 && qd_aligned(d->x, 16) && qd_aligned(d->w, 16), "qd_conv2d_i8: x/w must be 16-byte aligned, ldx %% 16 == 0");
     ConvD k{};
     k.x = d->x; k.wt = d->w; k.out = d->out; k.iout = iout;

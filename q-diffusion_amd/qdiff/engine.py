@@ -722,8 +722,9 @@ def _vsum_prepare(vsum):
 
 def heads_fusable(plan, T, H):
     """The projection `plan` can write its output directly as attention operand bytes (QD_EPI_HEADS_*)."""
-    return bool(plan.pack.tiled and plan.pack.wbits == 4 and len(plan.segs) == 1 and T % 128 == 0 and plan.Cout % H == 0
-                and (plan.Cout // H) % 4 == 0)
+    # int4 weights on every tile width; int8 weights (CIFAR W8A8) on the 128-wide tile, i.e. more than 64 output channels
+    return bool(plan.pack.tiled and (plan.pack.wbits == 4 or (plan.pack.wbits == 8 and plan.Cout > 64)) and len(plan.segs) == 1
+                and T % 128 == 0 and plan.Cout % H == 0 and (plan.Cout // H) % 4 == 0)
 
 
 def project_heads(plan, xq, B, T, H, ap, which, out8, vsum=None):

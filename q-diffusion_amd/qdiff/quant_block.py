@@ -248,7 +248,7 @@ _CTX_AUTO = os.environ.get("QDIFF_CTX_AUTO", "1") != "0"
 #  enqueueing a replay costs 0.15 ms, nothing to hide, and every prompt change wastes one speculative evaluation)
 _CTX_SPECULATE = os.environ.get("QDIFF_CTX_SPECULATE", "0") == "1"
 _FUSE_SKIP_QUANT = os.environ.get("QDIFF_FUSE_SKIP_QUANT", "1") != "0"     # A/B knob: skip-connection rows from the GroupNorm pass
-QKV_HEADS = os.environ.get("QDIFF_QKV_HEADS", "1") != "0"         # A/B knob: the LDM AttentionBlock's qkv as three GEMMs with operand epilogues
+QKV_HEADS = os.environ.get("QDIFF_QKV_HEADS", "1") != "0"         # A/B knob: the LDM AttentionBlock's qkv as three GEMMs with operand epilogues; q / k / v of the DDIM AttnBlock likewise
 CAT_SLOTS = os.environ.get("QDIFF_CAT_SLOTS", "1") != "0"         # A/B knob: planned skip-concatenation buffers (engine.CatSlot)
 
 
@@ -1216,10 +1216,30 @@ class QuantAttnBlock(BaseQuantBlock, _AttnQuant):
         ws_plan = None
         _, y = engine.groupnorm_silu_quant(rows, B, T, C, self.norm, False, plan=ws_plan, want_float=True,
                                            part=getattr(rows, "qd_gn_part", None))
+        ap = self._attn_plan(self, int(C) ** (-0.5), 1.0, x.device)
+        po = self.proj_out
+        if QKV_HEADS and T % 128 == 0:
+            # q / k / v write the attention operand bytes from their epilogues (one head as wide as the layer), the attention
+            # epilogue quantises for proj_out: no fp32 projections, no qd_quantize_heads, no zero fills
+            for m in (self.q, self.k, self.v):
+                m._init_act_quantizers(y)
+            plans = [m.conv_plan() for m in (self.q, self.k, self.v)]
+            if all(engine.heads_fusable(p, T, 1) and p.Cout == C for p in plans):
+                q8, k8, v8, vsum = engine.head_buffers(x.device, B, T, T, C)
+                vsum = engine.vsum_slice(id(self), x.device, tuple(vsum.shape))
+                for which, (plan, buf) in enumerate(zip(plans, (q8, k8, v8))):
+                    xq = engine.quantize_rows(y, plan, 1, C, B * T, (0, y.stride(1), y.stride(0)))
+                    engine.project_heads(plan, xq, B, T, 1, ap, which, buf, vsum)
+                if po.act_quantizer.inited and po.split == 0 and po.conv_plan().ldx == C and len(po.conv_plan().segs) == 1:
+                    o8 = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, T, 1, C, out_plan=po.conv_plan())
+                    out = po.forward_codes(o8, B, H, W, residual=rows, gn_stats=True, slot=out_slot)
+                else:
+                    o = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, T, 1, C)
+                    out = _linear_like_conv2d(po, o, B, H, W, residual=rows, gn_stats=True, slot=out_slot)
+                return _rows_to_nchw(out, B, H, W)
         q = _linear_like_conv2d(self.q, y, B, H, W)
         k = _linear_like_conv2d(self.k, y, B, H, W)
         v = _linear_like_conv2d(self.v, y, B, H, W)
-        ap = self._attn_plan(self, int(C) ** (-0.5), 1.0, x.device)
         st = (T * C, C, C, 1)
         o = engine.attention(ap, q, k, v, B, T, T, 1, C, st, st, st)
         out = _linear_like_conv2d(self.proj_out, o, B, H, W, residual=rows, gn_stats=True, slot=out_slot)

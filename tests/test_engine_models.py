@@ -213,13 +213,14 @@ def test_packed_checkpoint_round_trip_on_gpu(cuda, name, tmp_path):
     assert d <= 1.5 * dself + 1e-3 * ref.abs().max().item() and cos >= 0.995, (d, dself, cos)
 
 
-@pytest.mark.parametrize("name", ["ldm_tiny", "ldm_full"])
+@pytest.mark.parametrize("name", ["ldm_tiny", "ldm_full", "cifar_full"])
 def test_ldm_attention_qkv_operand_projections_on_gpu(cuda, name, monkeypatch, tmp_path):
     """The LDM AttentionBlock's qkv conv1d as three GEMMs with attention-operand epilogues (QuantModule.head_plans,
     QuantAttentionBlock._forward_heads; reference quant_block.py:163-187): the same quantiser inputs (I*scale + bias in one
     fma, times the q / k prescale) as the fp32 projection + qd_quantize_heads route, so the UNet output is the same bit for
     bit; the route is taken where the token count is a multiple of 128 and survives a packed checkpoint when the heads are
-    whole 32-row tiles (LDM-4: 32 channels per head)."""
+    whole 32-row tiles (LDM-4: 32 channels per head).  cifar_full: the q / k / v convolutions of the DDIM AttnBlock (int8 weights,
+    one 256-channel head, 256 tokens; reference quant_block.py:354-386) through the same epilogues."""
     import qdiff
     from qdiff import hip, quant_block
     from qdiff.utils import load_packed_ckpt, save_packed_ckpt
@@ -229,7 +230,7 @@ def test_ldm_attention_qkv_operand_projections_on_gpu(cuda, name, monkeypatch, t
     real_conv, real_qh = hip.conv2d_i8, hip.quantize_heads
 
     def counting_conv(cc, acc_out=None):
-        calls["heads"] += cc.epilogue in (hip.EPI_HEADS_I8, hip.EPI_HEADS_T_I8) and cc.heads["H"] > 1
+        calls["heads"] += cc.epilogue in (hip.EPI_HEADS_I8, hip.EPI_HEADS_T_I8) and (cc.heads["H"] > 1 or cc.wbits == 8)
         return real_conv(cc, acc_out)
 
     def counting_qh(*a, **k):

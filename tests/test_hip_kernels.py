@@ -866,6 +866,17 @@ def test_attention_keyterm_table(cuda):
                                      (256, 448, 448, 14), (128, 672, 672, 21), (128, 896, 896, 28), (256, 192, 192, 8), (128, 384, 384, 8),
                                      (128, 768, 768, 8)])
 def test_projection_heads_epilogue_matches_quantize_heads(cuda, T, N, K, H):
+    _heads_epilogue_case(cuda, T, N, K, H, 4)
+
+
+@pytest.mark.parametrize("T,N,K,H", [(256, 256, 256, 1), (128, 128, 256, 1), (128, 256, 128, 2), (384, 192, 64, 1)])
+def test_projection_heads_epilogue_with_int8_weights(cuda, T, N, K, H):
+    """The same epilogues behind int8 weights (128-wide tiles; the q / k / v convolutions of the CIFAR W8A8 attention block:
+    one head as wide as the layer, 256 channels)."""
+    _heads_epilogue_case(cuda, T, N, K, H, 8)
+
+
+def _heads_epilogue_case(cuda, T, N, K, H, wbits):
     """q/k/v projections that write attention operand bytes from the GEMM epilogue (QD_EPI_HEADS_*) produce
     exactly the bytes (and V column sums) of the fp32 projection followed by qd_quantize_heads.  Round 5: head dims that are
     multiples of 8 (40 / 80 / 160 / 32) leave 8 codes per lane (two tiles per transposition); d = 36 keeps the 4-code form."""
@@ -876,12 +887,12 @@ def test_projection_heads_epilogue_matches_quantize_heads(cuda, T, N, K, H):
     x = torch.randn(B * T, K, generator=g)
     w = torch.randn(N, K, generator=g) * 0.05
     bias = torch.randn(N, generator=g) * 0.1
-    q = _weight_quantizer(w, 4, True, g)
+    q = _weight_quantizer(w, wbits, True, g)
     dx, zx = R.uaq_init_scale(x, 8, False, False, "max")
     aq = _aq(dx, zx)
     pack = engine.pack_module_weights(w.to(cuda), [q], 0)
     plan = engine.build_conv_plan(pack, [aq], 1, 1, 1, 0, bias.to(cuda))
-    assert pack.tiled and engine.heads_fusable(plan, T, H)
+    assert pack.tiled and pack.wbits == wbits and engine.heads_fusable(plan, T, H)
     xq = engine.quantize_rows(x.to(cuda), plan, 1, K, B * T, (0, 1, K))
     y = engine.conv_forward(plan, xq, 1, 1, B * T)                       # fp32 projection [B*T][N]
 

@@ -689,6 +689,66 @@ def test_ldm_attention_block_qkv_as_three_operand_projections(emu, monkeypatch):
     assert b.qkv.head_plans(nh) is not before
 
 
+def test_ddim_attn_block_operand_projections_with_int8_weights(emu, monkeypatch):
+    """The pixel-space DDIM AttnBlock (reference quant_block.py:354-386; CIFAR W8A8): q / k / v are 1x1 convolutions with int8
+    weights; where the token count is a multiple of 128 and the layer has more than 64 channels their epilogues write the
+    attention operand bytes (one head as wide as the layer) and the attention epilogue quantises for proj_out — the block's
+    output is the one of the fp32-projection route bit for bit."""
+    import qdiff
+    from qdiff import hip, quant_block
+    from qdiff.arch import ddim_unet
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.in_channels = 128
+            self.attn = ddim_unet.AttnBlock(128)
+
+        def forward(self, x, t=None, c=None):
+            return self.attn(x)
+    torch.manual_seed(11)
+    net = Net()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    wq = dict(n_bits=8, channel_wise=True, scale_method="max")
+    aq = dict(n_bits=8, channel_wise=False, scale_method="max", leaf_param=True)
+    qnn = qdiff.QuantModel(net, wq, aq, sm_abit=8).eval()
+    assert isinstance(qnn.model.attn, quant_block.QuantAttnBlock)
+    x = torch.randn(2, 128, 16, 8)
+    qnn.set_quant_state(True, True)
+    with torch.no_grad():
+        qnn(x)                                            # initialises every quantiser (fp32 simulation)
+    calls = {"heads": 0, "float": 0}
+    real_conv, real_qh = hip.conv2d_i8, hip.quantize_heads
+
+    def counting_conv(cc, acc_out=None):
+        calls["heads"] += cc.epilogue in (hip.EPI_HEADS_I8, hip.EPI_HEADS_T_I8) and cc.wbits == 8
+        return real_conv(cc, acc_out)
+
+    def counting_qh(*a, **k):
+        calls["float"] += 1
+        return real_qh(*a, **k)
+    monkeypatch.setattr(hip, "conv2d_i8", counting_conv)
+    monkeypatch.setattr(hip, "quantize_heads", counting_qh)
+    x2 = torch.randn(2, 128, 16, 8)
+    monkeypatch.setattr(quant_block, "QKV_HEADS", False)
+    with torch.no_grad():
+        want = qnn(x2)
+    assert calls == {"heads": 0, "float": 3}
+    monkeypatch.setattr(quant_block, "QKV_HEADS", True)
+    calls.update(heads=0, float=0)
+    with torch.no_grad():
+        got = qnn(x2)
+    assert calls == {"heads": 3, "float": 0}
+    assert torch.equal(got, want)
+    # 64 tokens (8 x 8): the fp32-projection route
+    calls.update(heads=0, float=0)
+    with torch.no_grad():
+        qnn(torch.randn(2, 128, 8, 8))
+    assert calls == {"heads": 0, "float": 3}
+
+
 def test_head_plans_gathered_from_the_pack_equal_a_fresh_packing(emu):
     """Heads of a multiple of 32 channels (LDM-4: 32): the q / k / v operands are whole 32-row tiles of the layer's own pack
     (engine.pack_select_tiles) — the same bytes and per-row constants as packing the row subset from the fp32 weight, and
