@@ -1447,7 +1447,10 @@ int choose_splitk(const qd_conv_desc* d, int* it_per) {
     if (blocks0 > 256) return 1;
     const long mn = M * N;
     const int min_steps = mn <= (1L << 18) ? 2 : (mn <= (3L << 19) ? 4 : 16);
-    static const long target = getenv("QD_SPLITK_TARGET") ? atol(getenv("QD_SPLITK_TARGET")) : 512;       // blocks the split should reach (A/B knob)
+    // blocks the split should reach.  One block per CU (256), not two: measured on one box (profiles/r05_c9_splitk_target_sweep.txt)
+    // 512 -> 256 is -7 % on a CIFAR W8A8 evaluation (3.74 -> 3.48 ms: fewer finalise passes, and an unsplit layer hands its
+    // GroupNorm statistics to the consumer from its epilogue), -0.12 ms on SD, equal on LDM-4; 128 is worse on SD and LDM-4.
+    static const long target = getenv("QD_SPLITK_TARGET") ? atol(getenv("QD_SPLITK_TARGET")) : 256;
     long S = target / blocks0;
     if (S > total / min_steps) S = total / min_steps;
     if (S > 32) S = 32;
