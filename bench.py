@@ -399,7 +399,7 @@ def as_script_line(a, dev):
     return {"metric": "denoising images/sec, SD-v1.4 W4A8, the unmodified sampler's call pattern", "value": round(n / dt, 4), "unit": "images/s",
             "ms_per_step": round(ms, 4), "evals_timed": evals, "images": n,
             "context_chain_runs_in_run": ckv.chain_runs - runs0, "contexts_recognised_by_value": ckv.value_matches - vm0,
-            "graphs_captured": len(qnn._graphs or {}), "wrong_speculations": ckv.__dict__.get("speculation_misses", 0),
+            "graphs_captured": len(qnn._graphs or {}),
             "graph_replay_enqueue_ms": round(replay_enqueue_ms, 3),
             "explicit_calls": "none (no enable_hip_graphs, no prepare_context)",
             "config": {"workload": f"sd UNet eval batch {2 * n}, fresh torch.cat of x / t / context per step (plms.py:184-187), 50 PLMS steps = {evals} evaluations of a new prompt"}}

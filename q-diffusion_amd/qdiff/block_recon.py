@@ -1,7 +1,7 @@
 """block_reconstruction — counterpart of the reference's qdiff/block_recon.py:13-166 (same signature, same arithmetic per
 iteration); the loop itself lives in qdiff/recon.py, shared with layer_reconstruction."""
 from .quant_block import BaseQuantBlock
-from .recon import LinearTempDecay, LossFunction, reconstruct  # noqa: F401  (re-exported under the reference's names)
+from .recon import reconstruct
 
 
 def block_reconstruction(model, block: BaseQuantBlock, cali_data, batch_size: int = 32, iters: int = 20000,

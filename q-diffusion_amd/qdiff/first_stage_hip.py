@@ -240,6 +240,12 @@ def _on_device(z):
     return bool(z.is_cuda)
 
 
+def _autocast_gpu_dtype():
+    """torch >= 2.4 spells it get_autocast_dtype('cuda'); the builds the reference's environment pins only have the old name."""
+    get = getattr(torch, 'get_autocast_dtype', None)
+    return get('cuda') if get is not None else torch.get_autocast_gpu_dtype()
+
+
 def adopt_reference_decoder():
     """Unmodified reference scripts never call this package's first-stage code: `model.decode_first_stage(samples)`
     (ldm/models/diffusion/ddpm.py:710-770) ends in `AutoencoderKL.decode` -> `self.decoder(z)` (autoencoder.py:330-333), an
@@ -276,7 +282,7 @@ def adopt_reference_decoder():
             if not _ADOPT_LOGGED[0]:
                 _ADOPT_LOGGED[0] = True
                 logger.info("first-stage Decoder.forward runs on qdiff's fp16-operand MFMA kernels (QDIFF_ADOPT_DECODER=%s)", ADOPT_DECODER)
-            return out.to(torch.get_autocast_dtype('cuda')) if (z.is_cuda and torch.is_autocast_enabled()) else out
+            return out.to(_autocast_gpu_dtype()) if (z.is_cuda and torch.is_autocast_enabled()) else out
         return ref_forward(self, z)
 
     cls.forward = forward

@@ -10,10 +10,13 @@ import torch
 
 
 class GraphedUNet:
-    def __init__(self, qnn, x, t, context=None, warmup=2, pinned=False):
+    def __init__(self, qnn, x, t, context=None, warmup=2, pinned=False, pool=None):
         """pinned: `context` is the tensor QuantModel.prepare_context pinned — the evaluation never reads its data (the
         cross-attention operands come from the pinned buffers), only its identity: it is passed through as is, not copied.
-        The graph stays valid across re-preparation (the pinned buffers are rewritten in place)."""
+        The graph stays valid across re-preparation (the pinned buffers are rewritten in place).
+        pool: a torch.cuda.graph_pool_handle() shared with the other captures of this model — they replay one after another on
+        one stream, so their activations can live in the same bytes; the OUTPUT of a replay is therefore only valid until the
+        next replay of any graph of the pool (QuantModel.forward copies it out at once)."""
         self.qnn = qnn
         self.pinned = bool(pinned)
         self.sx, self.st = x.detach().clone(), t.detach().clone()
@@ -25,7 +28,7 @@ class GraphedUNet:
                 self._eval()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        with torch.cuda.graph(self.graph, pool=pool), torch.no_grad():
             self.out = self._eval()
 
     def _eval(self):

@@ -1,7 +1,7 @@
 """layer_reconstruction — counterpart of the reference's qdiff/layer_recon.py:13-119 (the first / last convolutions and any
 QuantModule outside a block); the loop lives in qdiff/recon.py."""
 from .quant_layer import QuantModule
-from .recon import LinearTempDecay, LossFunction, reconstruct  # noqa: F401
+from .recon import reconstruct
 
 
 def layer_reconstruction(model, layer: QuantModule, cali_data, batch_size: int = 32, iters: int = 20000,

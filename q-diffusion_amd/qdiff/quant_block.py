@@ -242,11 +242,6 @@ _CTX_PIN = os.environ.get("QDIFF_CTX_PIN", "1") != "0"
 # (default: QuantModel.forward prepares a context it has not seen — the unmodified reference samplers never announce theirs)
 _CTX_PINS = max(1, int(os.environ.get("QDIFF_CTX_PINS", "2")))
 _CTX_AUTO = os.environ.get("QDIFF_CTX_AUTO", "1") != "0"
-# QDIFF_CTX_SPECULATE=1: a fresh context tensor that follows a value match is ASSUMED equal; the replay is enqueued behind the
-# comparison kernel and verified afterwards (default: compared BEFORE its evaluation is enqueued, a host read-back per step)
-# (default off: measured 20.93 vs 20.39 ms per evaluation over a 51-evaluation run of a new prompt, profiles/r05_ln_fuse_ab.md —
-#  enqueueing a replay costs 0.15 ms, nothing to hide, and every prompt change wastes one speculative evaluation)
-_CTX_SPECULATE = os.environ.get("QDIFF_CTX_SPECULATE", "0") == "1"
 _FUSE_SKIP_QUANT = os.environ.get("QDIFF_FUSE_SKIP_QUANT", "1") != "0"     # A/B knob: skip-connection rows from the GroupNorm pass
 QKV_HEADS = os.environ.get("QDIFF_QKV_HEADS", "1") != "0"         # A/B knob: the LDM AttentionBlock's qkv as three GEMMs with operand epilogues; q / k / v of the DDIM AttnBlock likewise
 CAT_SLOTS = os.environ.get("QDIFF_CAT_SLOTS", "1") != "0"         # A/B knob: planned skip-concatenation buffers (engine.CatSlot)
@@ -323,60 +318,9 @@ class ContextKV:
         for e, same in zip(cands, flags):
             if same:
                 self.value_matches += 1
-                e["streak"] = e.get("streak", 0) + 1
                 self._alias(e, context, ver)
                 return self._touch(e)
-        for e in cands:
-            e["streak"] = 0
         return None
-
-    # ---- speculative recognition (graph replay only) ----------------------------------------------------------------------
-    # `match` by value costs a host read-back, i.e. the host sits idle until the GPU has drained everything queued before the
-    # comparison — and only THEN enqueues the ~530 kernel nodes of the graph: the launch latency that graph replay normally
-    # hides behind the previous evaluation (the host runs one step ahead) is exposed at every step, 1.5 ms per SD step
-    # (profiles/r05_streams_ab.md).  So, once a fresh tensor has matched an entry by value (streak >= 1), the next fresh tensor
-    # of that shape is ASSUMED to hold the same bytes: the comparison kernel and the graph are enqueued back to back, the flag
-    # travels to the host on a side stream, and the host waits for the flag only — the graph is already queued behind it.  A
-    # wrong guess (a new prompt) costs one wasted evaluation: the caller (QuantModel.forward) drops the speculative output
-    # and takes the ordinary path.
-    def speculation_candidate(self, context):
-        if not self._pins or not torch.is_tensor(context) or not context.is_cuda:
-            return None
-        tok = self._live()
-        e = self._pins[-1] if self._pins else None
-        if (e is None or e["token"] != tok or e.get("streak", 0) < 1 or e["shape"] != tuple(context.shape)
-                or e["dtype"] != context.dtype or e["device"] != context.device or e["stream"] != engine.STREAM_DTYPE):
-            return None
-        return e
-
-    def compare_async(self, context, e):
-        """Enqueue `context == e.copy` on the current stream and the flag's trip to pinned host memory on a side stream."""
-        st = self.__dict__.get("_cmp")
-        if st is None or st["dev"].device != context.device:
-            st = self.__dict__["_cmp"] = dict(dev=torch.zeros(1, dtype=torch.uint8, device=context.device),
-                                             host=torch.zeros(1, dtype=torch.uint8).pin_memory(),
-                                             side=torch.cuda.Stream(device=context.device),
-                                             ev1=torch.cuda.Event(), ev2=torch.cuda.Event())
-        st["dev"].copy_((context == e["copy"]).all().reshape(1))
-        main = torch.cuda.current_stream()
-        st["ev1"].record(main)
-        with torch.cuda.stream(st["side"]):
-            st["side"].wait_event(st["ev1"])
-            st["host"].copy_(st["dev"], non_blocking=True)
-            st["ev2"].record(st["side"])
-        return st
-
-    def compare_result(self, st, context, e):
-        st["ev2"].synchronize()
-        same = bool(st["host"][0])
-        if same:
-            self.value_matches += 1
-            e["streak"] = e.get("streak", 0) + 1
-            self._alias(e, context, engine.tensor_version(context))
-        else:
-            e["streak"] = 0
-            self.speculation_misses = self.__dict__.get("speculation_misses", 0) + 1
-        return same
 
     def _touch(self, e):
         if self._pins and self._pins[-1] is not e:
@@ -401,9 +345,8 @@ class ContextKV:
         tok = self._live()
         e = self.match(context)
         if e is not None:
-            slot = e["slot"]
-            self._pins.remove(e)
-        else:
+            slot = e["slot"]                           # same bytes again: the entry (a handle lock_context may have handed out) is
+        else:                                          # refreshed IN PLACE below, its lock count stays with it
             used = {p["slot"] for p in self._pins}
             free = [p for p in self._pins if not p["locked"]]
             if len(self._pins) >= _CTX_PINS and free:
@@ -411,7 +354,6 @@ class ContextKV:
                 self._pins.remove(free[0])
             else:
                 slot = next(i for i in range(len(used) + 1) if i not in used)
-        locked = e["locked"] if e is not None else 0
         out = self._work(context, tag=("pin", slot))
         for blk in self.members:
             att = blk.attn2
@@ -430,10 +372,15 @@ class ContextKV:
         copy.copy_(context.detach())
         # `stream`: the projections of the chain emitted rows of this type (fp32 / fp16 activation stream) — the codes of another
         # stream type differ at ties, so an entry serves evaluations of its own stream type only
-        e = dict(slot=slot, gen=self._slot_gen[slot], token=tok, copy=copy, shape=tuple(context.shape), dtype=context.dtype,
-                 device=context.device, alias={}, out=out, locked=locked, stream=engine.STREAM_DTYPE)
+        fresh = dict(slot=slot, gen=self._slot_gen[slot], token=tok, copy=copy, shape=tuple(context.shape), dtype=context.dtype,
+                     device=context.device, alias={}, out=out, stream=engine.STREAM_DTYPE)
+        if e is None:
+            e = dict(fresh, locked=0)
+            self._pins.append(e)
+        else:
+            e.update(fresh)
+            self._touch(e)
         self._alias(e, context, engine.tensor_version(context))
-        self._pins.append(e)
         return e
 
     def unpin(self):

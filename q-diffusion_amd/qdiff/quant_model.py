@@ -24,7 +24,7 @@ from .arch import ddim_unet, ldm_unet
 
 logger = logging.getLogger(__name__)
 
-_MAX_GRAPHS = max(1, int(os.environ.get("QDIFF_HIP_GRAPH_MAX", "8")))       # captured evaluations kept per model (oldest dropped)
+_MAX_GRAPHS = max(1, int(os.environ.get("QDIFF_HIP_GRAPH_MAX", "4")))       # captured evaluations kept per model (oldest dropped)
 
 
 class QuantModel(nn.Module):
@@ -223,11 +223,16 @@ class QuantModel(nn.Module):
             elif ref.get("Upsample") is not None and type(m) is ref["Upsample"] and getattr(m, "dims", 2) == 2:
                 m.qd_takes_out_slot = True
 
-    def _hook_census(self):
+    def _hook_census(self, refresh=True):
         """Forward (pre-)hooks registered below the wrapped model.  Calibration and the tests' recorders hook sub-modules and
-        expect every evaluation to run them; a HIP-graph replay runs no Python at all, so an evaluation is captured only while
-        the census is the one this wrapper left behind (its own hooks)."""
-        return sum(len(m._forward_hooks) + len(m._forward_pre_hooks) for m in self.model.modules())
+        expect every evaluation to run them; a HIP-graph replay runs no Python at all, so an evaluation is captured — AND
+        replayed — only while the census is the one this wrapper left behind (its own hooks).  refresh=False counts over the
+        hook tables collected last time (the per-replay check: ~3k `len` calls, no module walk; a module swapped in since
+        moves the state token, which drops the graphs and refreshes the tables)."""
+        d = self.__dict__
+        if refresh or d.get("_hook_tables") is None:
+            d["_hook_tables"] = [t for m in self.model.modules() for t in (m._forward_hooks, m._forward_pre_hooks)]
+        return sum(map(len, d["_hook_tables"]))
 
     # ---- state token: "the whole model is on the integer path, and these are the tensors its plans were made from" ------------
     # HIP graphs and prepared contexts bake device pointers and quantiser values in; they are valid for as long as the token
@@ -371,23 +376,13 @@ class QuantModel(nn.Module):
                 self._graphs.clear()
                 self._graph_seen.clear()
                 self._graph_tok = tok
+                self.__dict__["_hook_tables"] = None
+            # a replay runs no Python: with a foreign hook below the model (calibration capture, recorders — registered at any
+            # time, also AFTER a graph of this signature was captured) the evaluation stays eager
+            graphs = self._hook_census(refresh=False) == self._own_hooks
         if tok >= 0 and ckv is not None and torch.is_tensor(context) and qb._CTX_PIN:
             # the run's conditioning: prepared before (same tensor, or the same BYTES in a fresh tensor), or prepared now
             entry = ckv.match(context, by_value=False)
-            if entry is None and graphs and qb._CTX_SPECULATE:
-                # a fresh tensor right after one that matched by value: replay the prepared graph speculatively, verify behind it
-                cand = ckv.speculation_candidate(context)
-                g = self._graphs.get(signature(x, timesteps, context) + (engine.STREAM_DTYPE, cand["slot"])) if cand is not None else None
-                if g is not None:
-                    cmp = ckv.compare_async(context, cand)
-                    ckv.select(cand, context)
-                    try:
-                        y = g(x, timesteps, context).to(x.dtype, copy=True)
-                    finally:
-                        ckv.select(None, None)
-                    if ckv.compare_result(cmp, context, cand):
-                        return y
-                    del y                                  # a new prompt: the guess was wrong, the ordinary path follows
             if entry is None:
                 entry = ckv.match(context)
             if entry is None and qb._CTX_AUTO:
@@ -399,12 +394,22 @@ class QuantModel(nn.Module):
                 key = signature(x, timesteps, context) + (engine.STREAM_DTYPE, None if entry is None else entry["slot"])
                 g = self._graphs.get(key)
                 if g is None:
+                    if len(self._graph_seen) > 256:
+                        self._graph_seen.clear()
                     seen = self._graph_seen.get(key, 0)
                     self._graph_seen[key] = seen + 1
                     if seen >= self._graph_after and self._hook_census() == self._own_hooks:
                         while len(self._graphs) >= _MAX_GRAPHS:
-                            self._graphs.pop(next(iter(self._graphs)))
-                        g = self._graphs[key] = GraphedUNet(self, x, timesteps, context, pinned=entry is not None)
+                            old = next(iter(self._graphs))
+                            logger.info("HIP graph of signature %s dropped (QDIFF_HIP_GRAPH_MAX=%d)", old[:5], _MAX_GRAPHS)
+                            self._graphs.pop(old)
+                        # ONE private memory pool for all captures of this model: replays are serialised on the launch stream,
+                        # so the activations of different signatures may share the same bytes
+                        pool = self.__dict__.get("_graph_pool")
+                        if pool is None:
+                            pool = self.__dict__["_graph_pool"] = torch.cuda.graph_pool_handle()
+                        g = self._graphs[key] = GraphedUNet(self, x, timesteps, context, pinned=entry is not None, pool=pool)
+                        logger.info("HIP graph captured for signature %s (%d kept)", key[:5], len(self._graphs))
                 if g is not None:
                     return g(x, timesteps, context).to(x.dtype, copy=True)
             y = self.model(x, timesteps, context)

@@ -147,6 +147,15 @@ def plms_sample(unet, x_T, table, cond=None, uncond=None, scale=1.0, callback=No
     return x
 
 
+def _capture_token(unet):
+    """What a whole-step graph was captured under: the model's state token (plans, packed weights, quantiser constants) AND
+    the activation-stream type in force (engine.set_stream_dtype changes the kernels an evaluation launches and the rows a
+    prepared context holds without moving the state token)."""
+    from . import engine
+    tokf = getattr(unet, "state_token", None)
+    return (tokf() if tokf is not None else None, engine.STREAM_DTYPE)
+
+
 class DevicePLMS:
     """PLMS sampling with a device-resident loop state: the step counter, the per-step coefficients
     and the multistep history live in device tensors, so a whole sampler step — UNet evaluation on the CFG-doubled batch,
@@ -227,10 +236,13 @@ class DevicePLMS:
         nold = min(k, 3)
         if not self.use_graph:
             return self._step(nold)
-        tokf = getattr(self.unet, "state_token", None)
-        tok = tokf() if tokf is not None else None
+        tok = _capture_token(self.unet)
         if tok != self._tok:                     # packed weights / quantiser constants were rebuilt: the captured pointers are stale
             self.graphs.clear()
+            if self._tok is not None and self._lock is not None:
+                # the locked entry holds operands made under the old plans / stream type: prepare and lock them afresh
+                self.unet.unlock_context(self._lock)
+                self._lock = self.unet.lock_context(self.ctx2 if self.ctx2 is not None else self.cond)
             self._tok = tok
         g = self.graphs.get(nold)
         if g is None:
@@ -440,8 +452,7 @@ class DeviceGeneralizedSteps:
     def step(self):
         if not self.use_graph:
             return self._step()
-        tokf = getattr(self.unet, "state_token", None)
-        tok = tokf() if tokf is not None else None
+        tok = _capture_token(self.unet)
         if tok != self._tok:
             self.graph, self._tok = None, tok
         if self.graph is None:

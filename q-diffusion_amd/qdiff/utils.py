@@ -2,10 +2,12 @@
 `convert_adaround`, `resume_cali_model`, plus `export_cali_state_dict` — the save sequence the
 reference scripts spell out inline (sample_diffusion_ddim.py:223-234, txt2img.py:477-488).
 
-Calibration-time data capture (`save_inp_oup_data`, `save_grad_data`, `GetLayerInpOut`, `GetLayerGrad`,
-`quantize_model_till`: reference :18-322) feeds qdiff/recon.py.
+Calibration-time data capture (`save_inp_oup_data`, `save_grad_data` over the `tap_unit` context manager: reference
+:18-322) feeds qdiff/recon.py.
 """
+import contextlib
 import logging
+import types
 from typing import Union
 
 import numpy as np
@@ -262,65 +264,68 @@ def load_packed_ckpt(qnn, ckpt, free_weights=True):
 
 
 # ------------------------------------------------------------------------------------------------
-# calibration-time capture of a unit's inputs / outputs / output gradients  (reference utils.py:18-322)
+# calibration-time capture of what flows through one reconstruction unit (reference utils.py:18-322: `save_inp_oup_data`
+# and `save_grad_data` are the names block_recon / layer_recon call; the taps below are this package's own)
 # ------------------------------------------------------------------------------------------------
-class StopForwardException(Exception):
-    """Raised by the capture hook to abandon the rest of the UNet evaluation (reference :183-187)."""
+class _UnitReached(Exception):
+    """Unwinds a UNet evaluation once the tapped unit has run: nothing downstream of it is needed."""
 
 
-class DataSaverHook:
-    """Forward hook keeping the (positional) inputs and the output of a unit (reference :190-210)."""
+@contextlib.contextmanager
+def tap_unit(unit, *, backward=False):
+    """Record what passes through `unit` while the body runs.  Forward tap: `rec.args` / `rec.out` are taken on every call
+    of the unit (`rec.keep_out = False` freezes the output for a later pass) and the evaluation is abandoned right after;
+    backward tap: `rec.grad` is the gradient w.r.t. the unit's (first) output, the backward pass runs to its end."""
+    rec = types.SimpleNamespace(args=None, out=None, grad=None, keep_out=True)
+    if backward:
+        handle = unit.register_full_backward_hook(lambda _m, _gin, gout: setattr(rec, "grad", gout[0]))
+    else:
+        def on_forward(_m, args, out):
+            rec.args = args
+            if rec.keep_out:
+                rec.out = out
+            raise _UnitReached
+        handle = unit.register_forward_hook(on_forward)
+    try:
+        yield rec
+    finally:
+        handle.remove()
 
-    def __init__(self, store_input=False, store_output=False, stop_forward=False):
-        self.store_input, self.store_output, self.stop_forward = store_input, store_output, stop_forward
-        self.input_store = None
-        self.output_store = None
 
-    def __call__(self, module, input_batch, output_batch):
-        if self.store_input:
-            self.input_store = input_batch
-        if self.store_output:
-            self.output_store = output_batch
-        if self.stop_forward:
-            raise StopForwardException
+def _evaluate_up_to_tap(model, args):
+    try:
+        model(*args)
+    except _UnitReached:
+        pass
 
 
-class GetLayerInpOut:
-    """(input[, second input]), output of `layer` for one calibration batch (reference :213-255): the output always
-    comes from the full-precision network; with `asym` the input is re-captured from the network quantised up to here
-    (weights, and activations when act_quant) — BRECQ's asymmetric reconstruction."""
+def _hand_back(model, unit, act_quant):
+    """State every capture leaves behind (reference :248-250, :306-308): only `unit` quantised, model in train mode."""
+    model.set_quant_state(False, False)
+    unit.set_quant_state(True, act_quant)
+    model.train()
 
-    def __init__(self, model, layer, device, asym: bool = False, act_quant: bool = False):
-        self.model, self.layer, self.device, self.asym, self.act_quant = model, layer, device, asym, act_quant
-        self.data_saver = DataSaverHook(store_input=True, store_output=True, stop_forward=True)
 
-    def _run(self, x, timesteps, context):
-        try:
-            self.model(x, timesteps, context)
-        except StopForwardException:
-            pass
+def unit_inputs_and_target(model, unit, args, asym=False, act_quant=False):
+    """One calibration batch through the network up to `unit` (reference GetLayerInpOut, :213-255).  The target is the
+    unit's output in the FULL-PRECISION network; the inputs come from the same pass, or — `asym`, BRECQ's asymmetric
+    reconstruction — from a second pass with everything quantised (weights, activations too when `act_quant`).
+    Returns (x | (x, second), target), detached; `second` is the embedding / context of two-tensor units."""
+    model.eval()
+    with torch.no_grad(), tap_unit(unit) as rec:
+        model.set_quant_state(False, False)
+        _evaluate_up_to_tap(model, args)
+        if asym:
+            rec.keep_out = False
+            model.set_quant_state(weight_quant=True, act_quant=act_quant)
+            _evaluate_up_to_tap(model, args)
+    _hand_back(model, unit, act_quant)
+    ins = [a.detach() for a in rec.args[:2] if torch.is_tensor(a)]
+    return (tuple(ins) if len(ins) == 2 else ins[0]), rec.out.detach()
 
-    def __call__(self, x, timesteps, context=None):
-        self.model.eval()
-        self.model.set_quant_state(False, False)
-        handle = self.layer.register_forward_hook(self.data_saver)
-        try:
-            with torch.no_grad():
-                self._run(x, timesteps, context)
-                if self.asym:
-                    self.data_saver.store_output = False
-                    self.model.set_quant_state(weight_quant=True, act_quant=self.act_quant)
-                    self._run(x, timesteps, context)
-                    self.data_saver.store_output = True
-        finally:
-            handle.remove()
-        self.model.set_quant_state(False, False)
-        self.layer.set_quant_state(True, self.act_quant)
-        self.model.train()
-        inp, out = self.data_saver.input_store, self.data_saver.output_store
-        if len(inp) > 1 and torch.is_tensor(inp[1]):
-            return (inp[0].detach(), inp[1].detach()), out.detach()
-        return inp[0].detach(), out.detach()
+
+def _is_attention_map(t):
+    return torch.is_tensor(t) and t.dim() > 2 and t.shape[1] == t.shape[2] == 4096
 
 
 def save_inp_oup_data(model, layer: Union[QuantModule, BaseQuantBlock], cali_data, asym: bool = False, act_quant: bool = False,
@@ -330,120 +335,69 @@ def save_inp_oup_data(model, layer: Union[QuantModule, BaseQuantBlock], cali_dat
     attention map only a random half of the calibration samples is kept (the reference's memory guard, :38-70 — kept
     because it decides WHICH samples the unit is calibrated on)."""
     device = next(model.parameters()).device
-    get_inp_out = GetLayerInpOut(model, layer, device=device, asym=asym, act_quant=act_quant)
-    if cond:
-        cali_xs, cali_ts, cali_conds = cali_data
-    else:
-        (cali_xs, cali_ts), cali_conds = cali_data, None
+    columns = tuple(cali_data[:3]) if cond else tuple(cali_data[:2])     # xs, ts[, conds]
+    n = columns[0].size(0)
 
-    def capture(sel):
-        args = [cali_xs[sel].to(device), cali_ts[sel].to(device)]
-        if cond:
-            args.append(cali_conds[sel].to(device))
-        return get_inp_out(*args)
+    def batch(sel):
+        return unit_inputs_and_target(model, layer, [c[sel].to(device) for c in columns], asym, act_quant)
 
-    inds = None
+    order = None
     if is_sm:
-        test_inp, test_out = capture(slice(0, 1))
-        is_sm = False
-        if isinstance(test_inp, tuple) and test_inp[0].dim() > 2 and test_inp[0].shape[1] == test_inp[0].shape[2] == 4096:
-            is_sm = True
-        if test_out.dim() > 2 and test_out.shape[1] == test_out.shape[2] == 4096:
-            is_sm = True
-        if is_sm:
+        probe_in, probe_out = batch(slice(0, 1))
+        if _is_attention_map(probe_in[0] if isinstance(probe_in, tuple) else None) or _is_attention_map(probe_out):
             logger.info("attention-map unit: calibrating on a random half of the samples")
-            inds = np.random.choice(cali_xs.size(0), cali_xs.size(0) // 2, replace=False)
-    num = int(cali_xs.size(0) / batch_size)
-    if is_sm:
-        num //= 2
-    store = (lambda t: t) if keep_gpu else (lambda t: t.cpu())
-    ins0, ins1, outs = [], [], []
-    for i in range(num):
-        sel = slice(i * batch_size, (i + 1) * batch_size)
-        cur_inp, cur_out = capture(torch.as_tensor(inds[sel]) if inds is not None else sel)
-        if isinstance(cur_inp, tuple):
-            ins0.append(store(cur_inp[0]))
-            ins1.append(store(cur_inp[1]))
-        else:
-            ins0.append(store(cur_inp))
-        outs.append(store(cur_out))
-    cached_inps = [torch.cat(ins0), torch.cat(ins1)] if ins1 else torch.cat(ins0)
-    cached_outs = torch.cat(outs)
+            order = torch.as_tensor(np.random.choice(n, n // 2, replace=False))
+    nbatch = int(n / batch_size) // (2 if order is not None else 1)
+    keep = (lambda t: t) if keep_gpu else (lambda t: t.cpu())
+    firsts, seconds, targets = [], [], []
+    for b in range(nbatch):
+        sel = slice(b * batch_size, (b + 1) * batch_size)
+        got, target = batch(order[sel] if order is not None else sel)
+        if isinstance(got, tuple):
+            seconds.append(keep(got[1]))
+            got = got[0]
+        firsts.append(keep(got))
+        targets.append(keep(target))
     if device.type == 'cuda':
         torch.cuda.empty_cache()
-    return cached_inps, cached_outs
+    xs = torch.cat(firsts)
+    return ([xs, torch.cat(seconds)] if seconds else xs), torch.cat(targets)
 
 
-class GradSaverHook:
-    """Backward hook keeping the gradient w.r.t. a unit's output (reference :258-268)."""
-
-    def __init__(self, store_grad=True):
-        self.store_grad = store_grad
-        self.stop_backward = False
-        self.grad_out = None
-
-    def __call__(self, module, grad_input, grad_output):
-        if self.store_grad:
-            self.grad_out = grad_output[0]
-        if self.stop_backward:
-            raise StopForwardException
-
-
-def quantize_model_till(model, layer, act_quant: bool = False):
-    """Quantise every unit up to and including `layer`, in module order (reference :313-322)."""
+def quantize_up_to(model, last, act_quant=False):
+    """Only the units that precede `last` in module order — and `last` itself — are quantised (reference :313-322)."""
     model.set_quant_state(False, False)
-    for _, module in model.named_modules():
-        if isinstance(module, (QuantModule, BaseQuantBlock)):
-            module.set_quant_state(True, act_quant)
-        if module is layer:
-            break
+    for m in model.modules():
+        if isinstance(m, (QuantModule, BaseQuantBlock)):
+            m.set_quant_state(True, act_quant)
+        if m is last:
+            return
 
 
-class GetLayerGrad:
-    """Gradient of KL(quantised-up-to-here || full precision) w.r.t. the unit's output: the Fisher-information weights
-    of opt_mode 'fisher_diag' / 'fisher_full' (reference :271-310)."""
-
-    def __init__(self, model, layer, device, act_quant: bool = False):
-        self.model, self.layer, self.device, self.act_quant = model, layer, device, act_quant
-        self.data_saver = GradSaverHook(True)
-
-    def __call__(self, model_input):
-        self.model.eval()
-        handle = self.layer.register_full_backward_hook(self.data_saver)
-        try:
-            with torch.enable_grad():
-                try:
-                    self.model.zero_grad()
-                    inputs = tuple(t.to(self.device) for t in model_input) if isinstance(model_input, (tuple, list)) else (model_input.to(self.device),)
-                    self.model.set_quant_state(False, False)
-                    out_fp = self.model(*inputs)
-                    quantize_model_till(self.model, self.layer, self.act_quant)
-                    out_q = self.model(*inputs)
-                    loss = F.kl_div(F.log_softmax(out_q, dim=1), F.softmax(out_fp, dim=1), reduction='batchmean')
-                    loss.backward()
-                except StopForwardException:
-                    pass
-        finally:
-            handle.remove()
-        self.model.set_quant_state(False, False)
-        self.layer.set_quant_state(True, self.act_quant)
-        self.model.train()
-        return self.data_saver.grad_out.data
+def unit_output_gradient(model, unit, args, act_quant=False):
+    """d KL(softmax(full precision) || softmax(quantised up to `unit`)) / d(output of `unit`): the Fisher weights of
+    opt_mode 'fisher_diag' / 'fisher_full' (reference GetLayerGrad, :271-310)."""
+    model.eval()
+    with torch.enable_grad(), tap_unit(unit, backward=True) as rec:
+        model.zero_grad()
+        model.set_quant_state(False, False)
+        target = F.softmax(model(*args), dim=1)
+        quantize_up_to(model, unit, act_quant)
+        F.kl_div(F.log_softmax(model(*args), dim=1), target, reduction='batchmean').backward()
+    _hand_back(model, unit, act_quant)
+    return rec.grad.detach()
 
 
 def save_grad_data(model, layer, cali_data, damping: float = 1., act_quant: bool = False, batch_size: int = 32, keep_gpu: bool = True):
     """|dL/d(output)| + 1 of `layer` over the calibration set (reference :152-180).  `cali_data` may be the (xs, ts[, conds])
     tuple of the diffusion scripts (the reference indexes a single tensor here, a leftover of its classification origin)."""
     device = next(model.parameters()).device
-    get_grad = GetLayerGrad(model, layer, device, act_quant=act_quant)
-    n = cali_data[0].size(0) if isinstance(cali_data, (tuple, list)) else cali_data.size(0)
+    columns = tuple(cali_data) if isinstance(cali_data, (tuple, list)) else (cali_data,)
     grads = []
-    for i in range(int(n / batch_size)):
-        sel = slice(i * batch_size, (i + 1) * batch_size)
-        batch = tuple(t[sel] for t in cali_data) if isinstance(cali_data, (tuple, list)) else cali_data[sel]
-        g = get_grad(batch)
+    for b in range(int(columns[0].size(0) / batch_size)):
+        sel = slice(b * batch_size, (b + 1) * batch_size)
+        g = unit_output_gradient(model, layer, [c[sel].to(device) for c in columns], act_quant)
         grads.append(g if keep_gpu else g.cpu())
-    cached = torch.cat(grads).abs() + 1.0
     if device.type == 'cuda':
         torch.cuda.empty_cache()
-    return cached
+    return torch.cat(grads).abs() + 1.0

@@ -121,9 +121,9 @@ def _calibration_vs_reference_fixture(name, dev, on_gpu=False):
 
 
 def test_temperature_schedule_and_loss_terms():
-    """LinearTempDecay / LossFunction against closed forms (reference block_recon.py:169-252)."""
-    from qdiff.block_recon import LinearTempDecay, LossFunction
-    td = LinearTempDecay(100, rel_start_decay=0.2, start_b=20, end_b=2)
+    """rounding_temperature / ReconstructionObjective against closed forms (reference block_recon.py:169-252)."""
+    from qdiff.recon import ReconstructionObjective, rounding_temperature
+    td = lambda t: rounding_temperature(t, 100, hold=0.2, b_first=20, b_last=2)
     assert td(0) == 20 and td(19) == 20 and td(100) == 2
     assert abs(td(60) - (2 + 18 * (1 - 40 / 80))) < 1e-12
 
@@ -134,13 +134,14 @@ def test_temperature_schedule_and_loss_terms():
     m = qdiff.QuantModule(torch.nn.Linear(4, 4), dict(n_bits=4, channel_wise=True, scale_method="max"),
                           dict(n_bits=8, channel_wise=False, scale_method="max"))
     m.weight_quantizer = Q()
-    lf = LossFunction(m, round_loss='relaxation', weight=0.5, max_count=10, rec_loss='mse', b_range=(20, 2), warmup=0.2, p=2.0)
+    lf = ReconstructionObjective(m, 10, weight=0.5, kind='mse', b_range=(20, 2), warmup=0.2, p=2.0)
     pred, tgt = torch.ones(2, 3), torch.zeros(2, 3)
-    assert float(lf(pred, tgt)) == 3.0                               # count 1 < warm-up: reconstruction term only
-    lf.count = 5
-    b = lf.temp_decay(6)
+    assert float(lf(pred, tgt)) == 3.0                               # call 1 < warm-up: reconstruction term only
+    lf.calls = 5
+    b = rounding_temperature(6, 10, 0.2, 20, 2)
     want = 3.0 + 0.5 * float((1 - ((torch.tensor([0.0, 0.25, 0.5, 1.0]) - .5).abs() * 2).pow(b)).sum())
     assert abs(float(lf(pred, tgt)) - want) < 1e-6
+    assert float(ReconstructionObjective(m, 10, regularise=False)(pred, tgt)) == 3.0     # activation phase: no regulariser
 
 
 def test_capture_hooks_see_both_block_inputs():
@@ -164,6 +165,42 @@ def test_capture_hooks_see_both_block_inputs():
     assert torch.equal(out_fp, out_q)                       # outputs always come from the full-precision network
     assert not torch.equal(inp_fp[0], inp_q[0]) and not torch.equal(inp_fp[1], inp_q[1])   # (the time embedding is quantised too)
     assert qnn.training and blocks[2].use_weight_quant and not blocks[0].use_weight_quant
+
+
+def test_output_gradient_tap_is_the_hand_written_kl_gradient():
+    """save_grad_data (Fisher weights, reference utils.py:152-180, 271-310): the backward tap on a unit returns the gradient of
+    KL(quantised up to the unit || full precision) w.r.t. the unit's output — compared with autograd.grad on a retained
+    output of the same two passes; the hook is gone and the hand-back state is the reference's afterwards."""
+    import qdiff
+    from qdiff import engine
+    from qdiff.quant_block import QuantResnetBlock
+    from qdiff.utils import quantize_up_to, save_grad_data
+    fx = load_fixture("recon_cifar_tiny.pt")
+    spec = fx["spec"]
+    wq, aq = quant_params(spec)
+    qnn = qdiff.QuantModel(build_engine_model(spec), wq, aq, sm_abit=spec["sm_abit"]).eval()
+    xs, ts, _ = _inputs(spec, 4, 300)
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(xs, ts)
+    unit = [m for m in qnn.modules() if isinstance(m, QuantResnetBlock)][1]
+    with engine.simulation():
+        got = save_grad_data(qnn, unit, (xs, ts), act_quant=False, batch_size=4)
+        assert got.shape[0] == 4 and float(got.min()) >= 1.0 and not unit._backward_hooks
+        assert qnn.training and unit.use_weight_quant
+        # the same quantity by hand: the LAST backward through the unit is the full-precision pass (autograd runs the later
+        # pass first), whose output gradient is what the reference's hook keeps
+        kept = []
+        h = unit.register_forward_hook(lambda _m, _a, out: kept.append(out))
+        qnn.eval()
+        with torch.enable_grad():
+            qnn.set_quant_state(False, False)
+            tgt = torch.nn.functional.softmax(qnn(xs, ts), dim=1)
+            quantize_up_to(qnn, unit, False)
+            loss = torch.nn.functional.kl_div(torch.nn.functional.log_softmax(qnn(xs, ts), dim=1), tgt, reduction='batchmean')
+            want = torch.autograd.grad(loss, kept[0])[0]
+        h.remove()
+    assert torch.allclose(got, want.abs() + 1.0, rtol=1e-5, atol=1e-7)
 
 
 def test_calibrate_then_resume_round_trip(tmp_path):

@@ -374,7 +374,6 @@ def test_default_graph_replay_and_value_matched_context(cuda, monkeypatch):
         want = [ref(xx, t, c).clone() for xx in xs]
         want2 = [ref(xx, t, c2).clone() for xx in xs]
     monkeypatch.setattr(qb, "_CTX_AUTO", True)
-    monkeypatch.setattr(qb, "_CTX_SPECULATE", True)        # also exercise the speculative replay (off by default: no gain measured)
     qnn = _resume(fx, cuda)                                # defaults: graph replay on (second sight), contexts prepared on first sight
     ckv = qnn.__dict__["_ctx_kv"]
     assert qnn._graphs == {} and not ckv._pins
@@ -382,12 +381,10 @@ def test_default_graph_replay_and_value_matched_context(cuda, monkeypatch):
         runs = ckv.chain_runs
         got = [qnn(xx, t, c.clone()).clone() for xx in xs]          # a fresh context tensor per call
         assert ckv.chain_runs == runs + 1 and ckv.value_matches >= len(xs) - 1 and len(qnn._graphs) == 1
-        assert ckv.__dict__.get("speculation_misses", 0) == 0      # calls 3.. replayed speculatively, verified behind the graph
         y_id = qnn(xs[1], t, c).clone()                              # the same bytes through another object ...
         y_id2 = qnn(xs[1], t, c).clone()                             # ... which is then recognised by identity
         got2 = [qnn(xx, t, c2.clone()).clone() for xx in xs]        # second prompt: second slot, its own graph
         assert ckv.chain_runs == runs + 2 and len(qnn._graphs) == 2 and len(ckv._pins) == 2
-        assert ckv.__dict__.get("speculation_misses", 0) == 1      # the new prompt's first call: one wasted replay, the right result
         back = qnn(xs[2], t, c.clone()).clone()                      # the first prompt is still prepared
         assert ckv.chain_runs == runs + 2
         torch.cuda.synchronize()
@@ -404,6 +401,55 @@ def test_default_graph_replay_and_value_matched_context(cuda, monkeypatch):
         w_new = ref(xs[0], t, c).clone()
         torch.cuda.synchronize()
         assert torch.equal(y_new, w_new) and not torch.equal(w_new, want[0])
+
+
+def test_hooks_registered_after_capture_keep_the_model_eager(cuda):
+    """a replayed graph runs no Python, so a forward hook registered on a sub-module AFTER a graph of the
+    call signature exists (the reference's calibration capture, reference qdiff/utils.py:190-255; any recorder) must switch the
+    evaluation back to the eager walk — and the graph is used again once the hook is gone."""
+    from qdiff.quant_layer import QuantModule
+    fx = load_fixture("model_sd_tiny.pt")
+    x, t, c = (a.to(cuda) for a in fixture_inputs(fx, "test"))
+    qnn = _resume(fx, cuda)
+    with torch.no_grad():
+        ys = [qnn(x, t, c).clone() for _ in range(3)]
+        assert len(qnn._graphs) == 1
+        g = next(iter(qnn._graphs.values()))
+        replays = []
+        orig = g.graph.replay
+        g.graph.replay = lambda: (replays.append(1), orig())[1]
+        fired = []
+        mod = [m for m in qnn.modules() if isinstance(m, QuantModule)][5]
+        h = mod.register_forward_hook(lambda _m, _a, _o: fired.append(1))
+        y_hooked = qnn(x, t, c).clone()
+        assert fired and not replays and len(qnn._graphs) == 1
+        h.remove()
+        y_back = qnn(x, t, c).clone()
+        assert replays and len(fired) == 1
+    torch.cuda.synchronize()
+    assert all(torch.equal(y, ys[0]) for y in ys[1:] + [y_hooked, y_back])
+
+
+def test_repreparing_a_locked_context_keeps_the_handle(cuda):
+    """ContextKV.pin of bytes that are already prepared refreshes the entry IN PLACE — the handle lock_context
+    handed out earlier stays the live entry, unlock_context releases it, and no slot is leaked."""
+    fx = load_fixture("model_sd_tiny.pt")
+    x, t, c = (a.to(cuda) for a in fixture_inputs(fx, "test"))
+    qnn = _resume(fx, cuda)
+    ckv = qnn.__dict__["_ctx_kv"]
+    with torch.no_grad():
+        qnn(x, t, c)
+        h = qnn.lock_context(c)
+        assert h is not None and h["locked"] == 1
+        gen = h["gen"]
+        assert qnn.prepare_context(c.clone())                      # the same prompt again (plms_sample / a second sampler)
+        assert len(ckv._pins) == 1 and ckv._pins[0] is h and h["locked"] == 1 and h["gen"] == gen + 1
+        qnn.unlock_context(h)
+        assert ckv._pins[0]["locked"] == 0
+        for i in range(4):                                        # unlocked entries are evicted again: the slots do not pile up
+            qnn.prepare_context(torch.randn_like(c))
+        assert len(ckv._pins) <= 2
+    torch.cuda.synchronize()
 
 
 def test_two_whole_step_samplers_share_one_model(cuda):
