@@ -15,7 +15,11 @@ Extra objects on the JSON line:
   roofline     — the dominant kernel class (igemm int8 MFMA contraction): algorithmic int ops of every
                  launch of one UNet evaluation / their HIP-event durations on the launch stream; fractions against
                  the nominal 5.0 POP/s and the 4.404 POP/s micro-benchmark ceiling; whole_step_* = all integer ops of
-                 the evaluation / wall time of the sampler step.
+                 the evaluation / wall time of the sampler step.  by_class = EVERY library launch of the evaluation by class
+                 (igemm / attention / producers / other, ms per evaluation, attention with its own fraction of the MFMA peak);
+                 frac_of_box_ubench = the igemm class against what THIS box sustains (box.mfma_ubench_tops).
+  box          — ~50 ms of issue loops in this run (qd_box_probe): dense int8 MFMA TOP/s, v_exp_f32 G wave-instructions/s and
+                 the shader clock under each load: tells box speed from code speed when two lines are compared.
   gpu_denominators — the same UNet at the same batch on the same GPU with quantisation off (fp32 PyTorch-ROCm) and as
                  the reference's fp32 fake-quant simulation (rank 0, N=1 only).
   cpu_baseline — the oracle (CPU port of the reference fake-quant forward, oracle/unet_ref.py) timed on
@@ -112,21 +116,36 @@ def build_skeleton(kind, device, seed=777):
     return qnn, dict(w_bits=wq["n_bits"], a_bits=8, a_sym=bool(aq.get("symmetric", False)), sm_abit=sm_abit)
 
 
-def measure_igemm(qnn, args):
-    """HIP events around every qd_conv2d_i8 launch of one eager UNet evaluation, on the launch stream.
-    The stream is first parked behind a ~100 ms spin kernel so that the host finishes enqueueing the whole
-    evaluation before the GPU starts it: the event intervals are then back-to-back GPU time of the kernels
-    (what rocprofv3 --kernel-trace reports), not host launch latency of the eager Python path."""
-    from qdiff import hip
-    records = []
-    orig = hip.conv2d_i8
+PRODUCER_ENTRIES = ("groupnorm_silu_quant", "layernorm_quant", "geglu_quant", "quantize_act", "quantize_heads", "temb_mlp")
 
-    def timed(call, acc_out=None):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        st = torch.cuda.current_stream()
-        e0.record(st)
-        orig(call, acc_out)
-        e1.record(st)
+
+def measure_classes(qnn, args):
+    """HIP events around EVERY library launch of one eager UNet evaluation, on the launch stream, by class:
+      igemm      qd_conv2d_i8 (the integer contractions; sub-classes by epilogue / K as before),
+      attention  qd_attn_i8 (+ the key-term table it builds for a self-attention),
+      producers  the row producers between them (GroupNorm / LayerNorm / GEGLU / activation / head-layout quantisers, the
+                 timestep-embedding MLP group),
+      other      whatever else the evaluation enqueues (torch glue: the sinusoid table, views that copy) = the evaluation's own
+                 first-to-last interval minus the three classes.
+    The stream is first parked behind a ~100 ms spin kernel so that the host finishes enqueueing the whole evaluation before
+    the GPU starts it: the event intervals are then back-to-back GPU time of the kernels (what rocprofv3 --kernel-trace
+    reports), not host launch latency of the eager Python path."""
+    from qdiff import hip
+    records = []                                       # (e0, e1, class, sub-class, integer ops)
+    saved = {}
+
+    def bracket(fn, classify):
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st = torch.cuda.current_stream()
+            e0.record(st)
+            r = fn(*a, **k)
+            e1.record(st)
+            records.append((e0, e1) + classify(*a, **k))
+            return r
+        return timed
+
+    def conv_class(call, acc_out=None):
         k = call.kh * call.kw * sum(s["clen"] for s in call.segs)
         m = call.B * call.Ho * call.Wo
         epi = getattr(call, "epilogue", 0) or 0
@@ -142,20 +161,44 @@ def measure_igemm(qnn, args):
             cls = "long_k_f32_out"
         else:
             cls = "short_k_f32_out"
-        records.append((e0, e1, 2.0 * m * k * call.Cout, m, call.Cout, k, cls))
+        return ("igemm", cls, 2.0 * m * k * call.Cout)
+
+    def group_class(calls):
+        ops, cls = 0.0, "heads_i8_out"
+        for c in calls:
+            _, cls, o = conv_class(c)
+            ops += o
+        return ("igemm", cls, ops)
+
+    def attn_class(q, k, vt, vsum, BH, H, T, S, d, *a, **kw):
+        return ("attention", f"T{T}_S{S}_d{d}", 4.0 * T * S * d * BH)
+
     # per-launch kernel time is measured with the launches one after another: the cross-attention K / V branch, which the
     # timed steps run CONCURRENTLY with the stem (quant_block.ContextKV, fork point "start"), is serialised into the main
     # stream here ("late") — overlapping event intervals of two streams would count the same wall time twice
     from qdiff import quant_block as qb
     fork0 = qb._CTX_FORK
-    hip.conv2d_i8, qb._CTX_FORK = timed, "late"
+    wrap = {"conv2d_i8": conv_class, "attn_i8": attn_class}
+    if hasattr(hip, "conv2d_i8_group"):
+        wrap["conv2d_i8_group"] = group_class
+    for name in PRODUCER_ENTRIES:
+        wrap[name] = (lambda nm: (lambda *a, **k: ("producers", nm, 0.0)))(name)
+    for name, classify in wrap.items():
+        saved[name] = getattr(hip, name)
+        setattr(hip, name, bracket(saved[name], classify))
+    qb._CTX_FORK = "late"
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     try:
         with torch.no_grad():
             torch.cuda._sleep(int(2.5e8))
+            ev0.record(torch.cuda.current_stream())
             qnn.model(*args)
+            ev1.record(torch.cuda.current_stream())
         torch.cuda.synchronize()
     finally:
-        hip.conv2d_i8, qb._CTX_FORK = orig, fork0
+        for name, fn in saved.items():
+            setattr(hip, name, fn)
+        qb._CTX_FORK = fork0
     # an (e0, e1) pair with nothing in between still measures the event-record packets themselves:
     # calibrate that on the same parked stream and take it off every interval
     torch.cuda._sleep(int(2.5e7))
@@ -168,19 +211,64 @@ def measure_igemm(qnn, args):
         empty.append((e0, e1))
     torch.cuda.synchronize()
     overhead = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
-    ms = sum(max(a.elapsed_time(b) - overhead, 0.0) for a, b, *_ in records)
-    ops = sum(r[2] for r in records)
-    classes = {}
-    for a, b, o, *_rest, cls in records:
-        c = classes.setdefault(cls, dict(launches=0, ms=0.0, GOP=0.0))
-        c["launches"] += 1
-        c["ms"] += max(a.elapsed_time(b) - overhead, 0.0)
-        c["GOP"] += o / 1e9
-    for c in classes.values():
-        c["TOPs"] = round(c["GOP"] / max(c["ms"], 1e-9), 1)                 # GOP / ms == TOP/s
-        c["frac"] = round(c["TOPs"] / I8_MFMA_PEAK_TOPS, 4)
-        c["ms"], c["GOP"] = round(c["ms"], 3), round(c["GOP"], 1)
-    return dict(launches=len(records), total_ms=ms, ops=ops, event_overhead_us=1000.0 * overhead, classes=classes)
+    dur = lambda a, b: max(a.elapsed_time(b) - overhead, 0.0)
+    by_class, sub = {}, {}
+    for a, b, cls, sc, ops in records:
+        for table, key in ((by_class, cls), (sub, (cls, sc))):
+            c = table.setdefault(key, dict(launches=0, ms=0.0, GOP=0.0))
+            c["launches"] += 1
+            c["ms"] += dur(a, b)
+            c["GOP"] += ops / 1e9
+    # the evaluation's own interval carries one event pair per bracketed launch inside it: take those packets off as well
+    eval_ms = max(ev0.elapsed_time(ev1) - overhead * (len(records) + 1), 0.0)
+    for table in (by_class, sub):
+        for c in table.values():
+            if c["GOP"] > 0:
+                c["TOPs"] = round(c["GOP"] / max(c["ms"], 1e-9), 1)               # GOP / ms == TOP/s
+                c["frac"] = round(c["TOPs"] / I8_MFMA_PEAK_TOPS, 4)
+            else:
+                c.pop("GOP")
+            c["ms"] = round(c["ms"], 3)
+            if "GOP" in c:
+                c["GOP"] = round(c["GOP"], 1)
+    ig = by_class.get("igemm", dict(launches=0, ms=0.0, GOP=0.0))
+    known = sum(c["ms"] for c in by_class.values())
+    by_class["other"] = dict(ms=round(max(eval_ms - known, 0.0), 3),
+                             what="the eager evaluation's first-to-last interval minus the classes: torch glue kernels (~0.07 ms per SD evaluation in "
+                                  "the kernel traces) + the inter-launch gaps of EAGER launches with an event pair around each; a graph replay "
+                                  "keeps only the ~1.5 us dependent-launch boundary per dispatch (see graph_replay_eval_ms)")
+    return dict(launches=ig["launches"], total_ms=ig["ms"], ops=ig.get("GOP", 0.0) * 1e9, event_overhead_us=1000.0 * overhead,
+                classes={k[1]: v for k, v in sub.items() if k[0] == "igemm"}, by_class=by_class, eval_ms=round(eval_ms, 3),
+                attention_calls={k[1]: v for k, v in sub.items() if k[0] == "attention"},
+                producer_entries={k[1]: v for k, v in sub.items() if k[0] == "producers"}, library_launches=len(records))
+
+
+def measure_igemm(qnn, args):
+    return measure_classes(qnn, args)
+
+
+def box_calibration(dev):
+    """~50 ms of issue loops (qd_box_probe): what THIS box sustains on the two instruction classes the evaluation is bound by —
+    dense v_mfma_i32_32x32x32_i8 (two waves per SIMD) and v_exp_f32 (four) — and the shader clock under each load."""
+    from qdiff import hip
+    out = {}
+    try:
+        ms, ticks = hip.box_probe(dev, 0, 512, 60000)
+        out["mfma_ubench_tops"] = round(512 * 4 * 60000 * 8 * 65536.0 / (ms * 1e-3) / 1e12, 1)
+        # one v_mfma_i32_32x32x32_i8 occupies a SIMD's matrix pipe for 32 cycles (MI355X_MICROARCH.md): MFMAs per SIMD per second x 32
+        out["sclk_mhz_observed"] = round(2 * 60000 * 8 * 32 / (ms * 1e3), 1)
+        out["memtime_ticks_per_us_mfma"] = round(ticks / (ms * 1e3), 1)
+        out["mfma_probe_ms"] = round(ms, 3)
+        ms, ticks = hip.box_probe(dev, 1, 1024, 40000)
+        out["exp_ginst_s"] = round(1024 * 4 * 40000 * 32 / (ms * 1e-3) / 1e9, 2)              # wave-instructions per second, chip-wide
+        out["memtime_ticks_per_us_exp"] = round(ticks / (ms * 1e3), 1)
+        out["exp_probe_ms"] = round(ms, 3)
+        out["what"] = ("qd_box_probe in this run: dense v_mfma_i32_32x32x32_i8 at two waves per SIMD (TOP/s; sclk_mhz_observed = its "
+                       "per-SIMD rate x 32 cycles), v_exp_f32 at four waves per SIMD (G wave-instructions/s); memtime_ticks = s_memtime "
+                       "ticks of a wave / event time, reported as read")
+    except Exception as exc:  # noqa: BLE001 - never lose the line over the calibration
+        out["error"] = repr(exc)[:200]
+    return out
 
 
 def gpu_denominators(qnn, margs, k=2):
@@ -412,12 +500,26 @@ def extra_lines(a):
     out = {}
     common = ["--no-cpu-baseline", "--no-denominators", "--no-extras", "--steps", "10", "--warmup", "2"]
     for kind, n in (("cifar", 64), ("ldm", 64)):
-        # SURVEY.md §8d names batch 10 for C3 (README.md:47-49 `-n 10`); batch 64 is the throughput point: both from one child
+        # BASELINE configs[2] (LDM-4) is quoted at `-n 10 -e 1.0` (README.md:47-49): batch 10 is that line's headline, batch 64 the
+        # throughput point; both from one child (same model, same process)
         d = _child(["--model", kind, "--images-per-gpu", str(n)] + (["--extra-batch", "10"] if kind == "ldm" else []) + common, 240, f"{kind} line")
-        out[kind] = d if "error" in d else {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "wall_s") if k in d} | \
-            {"workload": d["config"]["workload"], "igemm_frac": d.get("roofline", {}).get("frac"),
-             "launches_per_eval_igemm": d.get("roofline", {}).get("launches_per_eval")} | \
-            {k: d["config"][k] for k in ("whole_step_graph_ms", "whole_step_graph_images_per_s", "extra_batch") if k in d["config"]}
+        if "error" in d:
+            out[kind] = d
+            continue
+        line = {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "wall_s") if k in d} | \
+            {"workload": d["config"]["workload"], "eta": d["config"].get("eta"), "igemm_frac": d.get("roofline", {}).get("frac"),
+             "launches_per_eval_igemm": d.get("roofline", {}).get("launches_per_eval"),
+             "library_launches_per_eval": d.get("roofline", {}).get("library_launches_per_eval"),
+             "by_class_ms": {k: v.get("ms") for k, v in (d.get("roofline", {}).get("by_class") or {}).items()}} | \
+            {k: d["config"][k] for k in ("whole_step_graph_ms", "whole_step_graph_images_per_s") if k in d["config"]}
+        xb = d["config"].get("extra_batch")
+        if kind == "ldm" and isinstance(xb, dict) and "ms_per_step" in xb:
+            out[kind] = {"metric": line["metric"], "value": xb["images_per_s"], "unit": "images/s", "ms_per_step": xb["ms_per_step"],
+                         "whole_step_frac": xb.get("whole_step_frac"), "dtype": line.get("dtype"), "eta": line.get("eta"),
+                         "workload": f"ldm UNet eval batch 10 (README.md:47-49 `-n 10 -e 1.0 -c 200`), per-step noise drawn full-batch-then-sliced inside the step",
+                         "batch_64": line}
+        else:
+            out[kind] = line
     # the SD workload driven exactly like the reference's unmodified sampler drives it (no graph / context calls by the caller)
     out["sd_as_script"] = _child(["--as-script", "--images-per-gpu", str(a.images_per_gpu)], 300, "sd line, the unmodified sampler's call pattern")
     out["first_stage_decode_sd"] = first_stage_decode("sd", a.images_per_gpu, legs=("hip",), cap_s=240)["hip"]
@@ -521,6 +623,8 @@ def main():
     stream_name = "fp16" if engine.STREAM_DTYPE == torch.float16 else "fp32"
 
     kind, n = a.model, a.images_per_gpu
+    if kind == "sd" and not a.no_extras and a.extra_batch == 0 and n > 5:
+        a.extra_batch = 5                              # BASELINE configs[3]: `--n_samples 5` (README.md:59-61) = evaluation batch 10, next to the headline
     # rank 0 owns the calibrated model (synthetic here: data-dependent init + AdaRound conversion); every other rank
     # builds the bare architecture with unrelated weights and receives the packed state — the ONLY collective of the run
     qnn, qspec = build_quantised_unet(kind, dev) if rank == 0 else build_skeleton(kind, dev)
@@ -543,7 +647,11 @@ def main():
         shape, ctx_shape, guide, evals = (3, 32, 32), None, 1.0, 100
         betas = sampling.ddpm_betas()
         ocfg = dict(ch=128, ch_mult=[1, 2, 2, 2], num_res_blocks=2, attn_resolutions=[16], resolution=32)
-    table = sampling.StepTable(betas, {"sd": 50, "ldm": 200, "churches": 400}.get(kind, 100), eta=0.0)
+    # BASELINE configs as the reference states them: LDM-4 LSUN-beds runs DDIM with `-e 1.0` (README.md:47-49) — sigma_t > 0, i.e.
+    # a fresh noise tensor per step (ddim.py:216), drawn full-batch-then-sliced on every rank INSIDE the timed
+    # step; SD (PLMS, plms.py:216), CIFAR (denoising.py:29, eta 0) and churches (`-e 0.0`, README.md:53-55) have sigma = 0
+    eta = 1.0 if kind == "ldm" else 0.0
+    table = sampling.StepTable(betas, {"sd": 50, "ldm": 200, "churches": 400}.get(kind, 100), eta=eta)
     gb = n * world
     x = sampling.sharded_noise((gb,) + shape, seed=0, world_size=world, rank=rank, device=dev)
     cond = uncond = None
@@ -556,14 +664,16 @@ def main():
     def unet(xx, tt, cc=None):
         return qnn(xx, tt, cc) if cc is not None else qnn(xx, tt.float() if kind == "cifar" else tt)
 
-    state = dict(x=x, old=[], i=0)
+    state = dict(x=x, old=[], i=0, cond=cond, uncond=uncond, ctx2=None, noise=None)
+    if eta > 0.0:
+        state["noise"] = sampling.ShardedStepNoise(gb, shape, 4321, world, rank, dev)
     # The conditioning of a sampling run is constant (plms.py:184-187 rebuilds the same torch.cat([uncond, c]) at every step):
     # build it once and let the model compute its cross-attention K / V^T operands ONCE per run (QuantModel.prepare_context,
     # QDIFF_CTX_PIN=0 restores the per-evaluation computation).  The one-off cost is measured here and charged to every step
     # as prepare_ms / evals (one preparation per image batch of `evals` evaluations).
     ctx2, prepare_ms, ctx_prepared = None, 0.0, False
     if ctx_shape:
-        ctx2 = torch.cat([uncond, cond])
+        ctx2 = state["ctx2"] = torch.cat([uncond, cond])
         with torch.no_grad():
             qnn(torch.cat([x] * 2), torch.full((2 * x.shape[0],), 500, device=dev, dtype=torch.long), ctx2)   # plans, packs, graph of the unprepared shape
             ctx_prepared = bool(qnn.prepare_context(ctx2))
@@ -579,13 +689,14 @@ def main():
         i = state["i"] % len(table)
         index = len(table) - i - 1
         t = torch.full((state["x"].shape[0],), int(table.timesteps[index]), device=dev, dtype=torch.long)
-        e = sampling.guided_eps(unet, state["x"], t, cond, uncond, guide, ctx2)
+        e = sampling.guided_eps(unet, state["x"], t, state["cond"], state["uncond"], guide, state["ctx2"])
         old = state["old"]
         if kind == "sd" and len(old) >= 3:
             e_prime = (55 * e - 59 * old[-1] + 37 * old[-2] - 9 * old[-3]) / 24
         else:
             e_prime = e
-        state["x"], _ = table.update(state["x"], e_prime, index)
+        noise = state["noise"]() if state["noise"] is not None else None      # eta > 0: the whole batch's draw, this rank's slice
+        state["x"], _ = table.update(state["x"], e_prime, index, noise)
         old.append(e)
         if len(old) >= 4:
             old.pop(0)
@@ -635,7 +746,7 @@ def main():
                                f"W{qspec['w_bits']}A8 sm_abit={qspec['sm_abit']}{'' if kind == 'churches' else ' split'}, hip-graph={'off' if a.no_graph else 'on'}"
                                + (f", cross-attention K/V of the run's context prepared once per image batch ({prepare_ms:.2f} ms, charged as /{evals} per step)"
                                   if ctx_prepared else (", cross-attention K/V recomputed per evaluation" if ctx_shape else "")),
-                   "images_per_gpu": n, "global_batch": gb, "single_unet_step_ms": round(ms_per_step, 4),
+                   "images_per_gpu": n, "global_batch": gb, "single_unet_step_ms": round(ms_per_step, 4), "eta": eta,
                    "context_prepare_ms": round(prepare_ms, 3), "context_prepared": ctx_prepared,
                    "parallelism": f"batch-sharded x{world}, quant-state broadcast {nbytes} B"},
     }
@@ -665,8 +776,21 @@ def main():
             margs = [torch.cat([xb] * 2), torch.cat([tb] * 2), ctx2]
         else:
             margs = [xb, tb.float() if kind == "cifar" else tb]
-        measure_igemm(qnn, margs)                      # warm (eager path, caches)
-        r = measure_igemm(qnn, margs)
+        box = box_calibration(dev)                     # what this box sustains, taken right after the timed steps
+        # the captured evaluation alone (no guidance / sampler update around it): ms per replay, back to back
+        replay_ms = None
+        if qnn._graphs:
+            g0 = list(qnn._graphs.values())[-1]
+            for _ in range(2):
+                g0.graph.replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                g0.graph.replay()
+            torch.cuda.synchronize()
+            replay_ms = round(1000.0 * (time.perf_counter() - t1) / 10, 4)
+        measure_classes(qnn, margs)                    # warm (eager path, caches)
+        r = measure_classes(qnn, margs)
         ach = r["ops"] / (r["total_ms"] * 1e-3) / 1e12
         # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs of this command,
         # tools/final_measure.sh); bench.py cannot collect counters itself, so it reports the committed summary of the
@@ -694,7 +818,17 @@ def main():
                            "event_pair_overhead_us": round(r["event_overhead_us"], 2),
                            "isolation": "per-launch times taken with the context K/V branch serialised into the launch stream "
                                         "(QDIFF_CTX_FORK=late); the timed steps run it concurrently with the stem (start)",
-                           "by_launch_class": r["classes"]}
+                           "by_launch_class": r["classes"],
+                           # every library launch of the evaluation by class (ms per evaluation, eager launches back to back on a
+                           # parked stream); their sum + other = eval_ms_eager, to be read against ms_per_step (graph replay +
+                           # guidance / sampler update glue)
+                           "by_class": r["by_class"], "eval_ms_eager": r["eval_ms"], "library_launches_per_eval": r["library_launches"],
+                           "graph_replay_eval_ms": replay_ms,
+                           "sampler_glue_ms": (round(ms_per_step - prepare_ms / evals - replay_ms, 4) if replay_ms is not None else None),
+                           "attention_calls": r["attention_calls"], "producer_entries": r["producer_entries"],
+                           "frac_of_box_ubench": (round(ach / box["mfma_ubench_tops"], 4) if box.get("mfma_ubench_tops") else None),
+                           "whole_step_frac_of_box_ubench": (round(step_top / box["mfma_ubench_tops"], 4) if box.get("mfma_ubench_tops") else None)}
+        out["box"] = box
         if world == 1 and not a.no_denominators:
             # same UNet, same batch, same GPU, same run: the denominators of north_star's ">= 4x the reference fp32
             # PyTorch-ROCm UNet" target
@@ -718,17 +852,40 @@ def main():
                                                              f"{2 if guide != 1.0 else 1} samples per image"}
         if a.decode and kind in ("sd", "ldm", "churches"):
             out["first_stage_decode"] = first_stage_decode(kind, n)
-        if a.extra_batch and 0 < a.extra_batch < n and world == 1 and not ctx_shape:
-            # the same loop at another batch (BASELINE configs[2] is quoted at `-n 10`): extra key, same process, same model
+        if a.extra_batch and 0 < a.extra_batch < n and world == 1:
+            # the same loop at another batch — BASELINE configs[2] is quoted at `-n 10` (README.md:47-49), configs[3] at
+            # `--n_samples 5` = evaluation batch 10 (README.md:59-61): extra key, same process, same model
+            keep = {k: state[k] for k in ("x", "cond", "uncond", "ctx2", "noise")}
             try:
-                xs = state["x"]
-                state["x"] = xs[:a.extra_batch].clone()
-                ms_b = retime()
-                out["config"]["extra_batch"] = {"images_per_gpu": a.extra_batch, "ms_per_step": round(ms_b, 4),
-                                                "images_per_s": round(a.extra_batch / (evals * ms_b / 1000.0), 4)}
-                state["x"] = xs
+                nb = a.extra_batch
+                state["x"] = keep["x"][:nb].clone()
+                prep_b = 0.0
+                if ctx_shape:
+                    state["cond"], state["uncond"] = keep["cond"][:nb].clone(), keep["uncond"][:nb].clone()
+                    state["ctx2"] = torch.cat([state["uncond"], state["cond"]])
+                    with torch.no_grad():
+                        qnn(torch.cat([state["x"]] * 2), torch.full((2 * nb,), 500, device=dev, dtype=torch.long), state["ctx2"])
+                        if qnn.prepare_context(state["ctx2"]):
+                            torch.cuda.synchronize()
+                            t1 = time.perf_counter()
+                            for _ in range(3):
+                                qnn.prepare_context(state["ctx2"])
+                            torch.cuda.synchronize()
+                            prep_b = 1000.0 * (time.perf_counter() - t1) / 3
+                if eta > 0.0:
+                    state["noise"] = sampling.ShardedStepNoise(nb, shape, 4321, 1, 0, dev)
+                ms_b = retime() + prep_b / evals
+                nsamp = nb * (2 if guide != 1.0 else 1)
+                out["config"]["extra_batch"] = {"images_per_gpu": nb, "eval_batch": nsamp, "ms_per_step": round(ms_b, 4),
+                                                "images_per_s": round(nb / (evals * ms_b / 1000.0), 4),
+                                                "whole_step_frac": round(per_sample_gop * 1e9 * nsamp / (ms_b * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, 4)}
             except Exception as exc:  # noqa: BLE001 - never lose the line over an extra
                 out["config"]["extra_batch"] = {"error": repr(exc)[:200]}
+            finally:
+                state.update(keep)
+                if ctx_shape:
+                    with torch.no_grad():
+                        qnn.prepare_context(state["ctx2"])
         if kind == "sd" and world == 1 and not a.no_extras:
             other = {}
             if engine.STREAM_DTYPE == torch.float32:

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 19
+#define QD_ABI_VERSION 20
 
 /* element types of floating-point tensors crossing the ABI */
 enum { QD_F32 = 0, QD_F16 = 1, QD_BF16 = 2 };
@@ -46,6 +46,12 @@ int         qd_abi_version(void);
 const char* qd_last_error(void);
 /* 1 if a gfx950 device is visible to this process, else 0 (never throws). */
 int         qd_device_ok(void);
+
+/* Box calibration (ABI v20; measurement aid of bench.py, not on the product path): `blocks` workgroups of 256 threads run `iters`
+ * iterations of kind 0: 8 dense v_mfma_i32_32x32x32_i8 per wave (four independent accumulators; 8 * 65536 integer ops each), or
+ * kind 1: 32 v_exp_f32 per wave (four independent registers).  ticks[block] = elapsed shader-clock ticks of the block's first wave;
+ * the caller times the launch (HIP events): 512 blocks = two waves per SIMD, 1024 = four.  sink: one int the kernel never writes. */
+int qd_box_probe(int kind, int blocks, int iters, long long* ticks, int* sink, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Quantiser parameters.  Every entry point below that takes `qparams` / `oq_params` expects a device float[4]
@@ -118,25 +124,6 @@ typedef struct {
                                 or NULL (= zeros)                                                  */
 } qd_conv_seg;
 
-/* LayerNorm fused into the epilogue (ABI v19; qd_conv_desc.ln): the Linear's output row (after bias and residual, as stored:
- * rounded to fp16 when out_dtype = QD_F16) is layer-normalised over its Cout = 320 columns and quantised with up to three
- * activation quantisers — `norm2(x)` -> to_q's input codes, `norm3(x)` -> the GEGLU projection's, `norm1(x)` -> to_q / to_k /
- * to_v's (ldm/modules/attention.py:229-231, qdiff/quant_block.py:193-199) — in the launch that produces the row: the
- * separate qd_layernorm_quant pass over the fp32 tensor disappears.  Needs w_tiled, one segment, QD_EPI_LINEAR, Cout == 320
- * (a 128 x 320 tile whose waves own whole rows), no split-K.  Codes are those of qd_layernorm_quant on the stored rows,
- * bit for bit (both reduce a row in the same order: eight lanes x 40 columns, butterfly over the lanes). */
-typedef struct {
-    const float*   gamma;    /* [Cout] */
-    const float*   beta;     /* [Cout] */
-    float          eps;
-    int32_t        nout;     /* 1..3 */
-    const float*   qparams[3];
-    int32_t        qmin[3], qmax[3], off[3];
-    int32_t        _pad;
-    int8_t*        out[3];   /* [M][ldo] int8 rows, one per quantiser */
-    int64_t        ldo;
-} qd_ln_fuse;
-
 typedef struct {
     const int8_t*  x;        /* [B][H][W][ldx] stored activation bytes                            */
     const uint8_t* w;        /* MFMA-tile-ordered weights of qd_pack_weights_t4 (wbits=4) / _t8 (wbits=8) */
@@ -192,7 +179,6 @@ typedef struct {
      * replication happens in the im2col source address, no up-sampled tensor exists.  Needs stride 1, kh*kw > 1, even H, W. */
     int32_t        upsample2x;
     int32_t        _pad3;
-    const qd_ln_fuse* ln;    /* optional (ABI v19): LayerNorm + quantisers of the output rows in the epilogue, see qd_ln_fuse */
 } qd_conv_desc;
 
 int qd_conv2d_i8(const qd_conv_desc* d, void* stream);
@@ -348,10 +334,11 @@ int qd_geglu_quant(const void* h, int h_dtype, int64_t M, int F, int64_t ldh,
  *           order; ktab 0 = ignore kterm (constant-operand MFMAs, A/B runs); lean 0 = attn_kernel for every head dim, 1 = lean /
  *           LDS-staged kernels for d < 64 (default), 3 = also d = 80 on the lean kernel (measured slower).  Initial values:
  *           QD_ATTN_PIPE / QD_ATTN_XCD / QD_ATTN_KTAB / QD_ATTN_LEAN, read once.
- *     qd_attn_sync (ABI v19): tiles per block-wide rendezvous of the LDS-staged kernel: 1 (default; QD_ATTN_SYNC) = round 3's
- *           one-barrier-per-tile schedule (4-stage ring), 2 = the four waves of a block meet every second 32-key tile and
- *           prefetch two tiles per meeting (8-stage ring).  Same arithmetic in the same order: bit-identical results;
- *           measured equal in time (profiles/r05_attn_rendezvous.md).
+ *     ws / ws_bytes (ABI v20): scratch of the LDS-staged path, which runs as THREE launches since round 6 — per-query softmax
+ *           statistics first (sweep 1 at up to 6 waves per SIMD), then the probability / P.V sweep for blocks that need only the
+ *           lo operand bytes of the 16-bit codes (4 waves per SIMD) and for the others (3): 16 bytes per padded query + 4 per
+ *           128-query block.  qd_attn_ws_bytes(BH, T, S, d) is the size for a shape (0: the shape runs on a one-kernel path
+ *           and ws may be NULL); contents are undefined afterwards, one buffer may serve every call of a stream.
  * ------------------------------------------------------------------------------------------ */
 int qd_quantize_heads(const void* x, int x_dtype, int B, int T, int H, int d,
                       int64_t sb, int64_t st, int64_t sh, int64_t sd, float prescale,
@@ -361,14 +348,14 @@ int qd_quantize_heads(const void* x, int x_dtype, int B, int T, int H, int d,
 int qd_attn_uses_keyterm(int d, int S, int q_asym);
 int qd_attn_keyterm(const int8_t* k, int BH, int Spad, int dpad, const float* prm, int32_t* kterm, void* stream);
 void qd_attn_config(int pipe_mode, int xcd, int ktab, int lean);
-void qd_attn_sync(int tiles_per_rendezvous);
+int64_t qd_attn_ws_bytes(int BH, int T, int S, int d);
 int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt,
                const int32_t* qsum, const int32_t* kterm, const int32_t* vsum,
                int BH, int H, int T, int S, int d, int Tpad, int Spad, int dpad,
                const float* prm, int wbits, int wmin, int wmax, int q_asym,
                float* out, int64_t ldo,
                int8_t* out8, int64_t ldo8, const float* oq_params, int oq_min, int oq_max, int oq_off,
-               void* stream);
+               void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K7s/K8s  the two attention contractions as standalone batched integer GEMMs, for callers that use

@@ -13,7 +13,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libqdiff_hip.so")
 ARCH = "gfx950"
-SOURCES = ["errors.cpp", "igemm_dma.hip", "quantize.hip", "norm_quant.hip", "attn_i8.hip", "bmm_i8.hip", "temb_mlp.hip", "fakequant.hip"]
+SOURCES = ["errors.cpp", "igemm_dma.hip", "quantize.hip", "norm_quant.hip", "attn_i8.hip", "bmm_i8.hip", "temb_mlp.hip", "fakequant.hip", "boxcal.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "qdiff_hip.h")]
 # correctly-rounded fp32 division / sqrt are hipcc defaults; keep them explicit because the
 # quantisers must reproduce torch's `round(x / delta)` bit for bit.
@@ -46,12 +46,16 @@ def _compile(src):
     return obj
 
 
-def build_variant(name, defines):
-    """A second library with extra -D flags (A/B measurements: QDIFF_HIP_LIB=<path> selects it in qdiff/hip.py)."""
+def build_variant(name, defines, only=None):
+    """A second library with extra -D flags (A/B measurements: QDIFF_HIP_LIB=<path> selects it in qdiff/hip.py).
+    only: the sources the flags concern — the others are linked from the main build's objects (build() first)."""
     objdir = os.path.join(HERE, "build", name)
     os.makedirs(objdir, exist_ok=True)
     objs = []
     for src in SOURCES:
+        if only and src not in only:
+            objs.append(_compile(src))
+            continue
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         path = os.path.join(CSRC, src)
         if _stale(obj, [path] + HEADERS):
@@ -83,8 +87,13 @@ def build(force=False):
 
 
 if __name__ == "__main__":
-    if "--variant" in sys.argv:                  # python build.py --variant occ3 QD_MT1_OCC=3
+    if "--variant" in sys.argv:                  # python build.py --variant occ3 [--only igemm_dma.hip] QD_MT1_OCC=3
         i = sys.argv.index("--variant")
-        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+        rest = sys.argv[i + 2:]
+        only = None
+        if rest and rest[0] == "--only":
+            only, rest = rest[1].split(","), rest[2:]
+        os.makedirs(OBJDIR, exist_ok=True)
+        print(build_variant(sys.argv[i + 1], rest, only))
     else:
         print(build(force="--force" in sys.argv))

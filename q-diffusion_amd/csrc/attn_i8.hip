@@ -679,113 +679,109 @@ template <int N>
 __device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void attn_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// SE (round 5): tiles per block-wide rendezvous.  SE = 1 is round 3's schedule (one s_barrier per 32-key tile: 256 per sweep pair
-// at 4096 keys; the counters charge 0.21 of the wave cycles to s_waitcnt / s_barrier, profiles/r04_pmc_attn_table.txt).  SE = 2:
-// the ring holds 8 tile stages, the waves meet every SECOND tile (in the even iterations of the two-tile software pipeline) and
-// prefetch two tiles per meeting — half the barriers, the same DMA instructions, the same arithmetic in the same order
-// (bit-identical: tests/test_hip_kernels.py::test_attention_lds_equals_lean runs both).  MEASURED EQUAL (1012 / 1013 vs 1022 /
-// 1011 us peaked, 930 / 925 vs 928 / 926 us flat, A/B/A/B on one box, profiles/r05_attn_rendezvous.md): the waiting the
-// counters see is not the rendezvous itself — a wave that arrives early waits just as long for the slowest wave's tile pair as
-// for its tile.  SE = 1 stays the default (QD_ATTN_SYNC=2 / qd_attn_sync(2) select the other).
-template <int DT, bool P16, int KT, int SE>
-__global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
-    // a*b+c written as such stays unfused: hipcc's default -ffp-contract=fast lets the optimiser fuse (or not) depending on the
-    // surrounding code, and the lean and the LDS-staged bodies must produce the same normaliser bit for bit
-#pragma clang fp contract(off)
-    static_assert(SE == 1 || SE == 2, "tiles per rendezvous");
-    constexpr int NST = 4 * SE;                               // ring stages (tiles).  SE = 1: jt+1 in use, jt+2 landed / landing, jt+3 issued
-    constexpr int PD = SE == 1 ? NST - 1 : 6;                 // prefetch distance (tiles ahead of the iteration that issues them)
-    constexpr int KB = 1024 * DT, VB = 1024 * DT;             // K tile: 32 keys x dpad bytes; V^T tile: dpad rows x 32 keys
-    constexpr int TB = KT == 2 ? 128 : 0;                     // the tile's 32 accumulator seeds (per-key zero-point term, qd_attn_keyterm)
-    constexpr int STAGE = KB + VB + TB;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
-    __shared__ int s_flag[1];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int frow = lane & 31, half = lane >> 5;
-    const int lblk = p.xcd ? qd_xcd_remap(blockIdx.x, p.gx * p.BH) : (int)blockIdx.x;
-    const int bh = lblk / p.gx;
-    const int q0r = ((lblk - bh * p.gx) * 4 + wave) * 32;
-    const bool live = q0r < p.T;                              // a wave past the last query still serves the DMA ring and the barriers
-    const int q0 = live ? q0r : 0;
+// ---- round 6: the LDS-staged path as TWO kernels (statistics, then P.V) -------------------------------------------------------
+// What bounds the 4096-token call is in-order VALU ISSUE at low occupancy, not a pipe: one wave issues a vector instruction every
+// ~5.5 cycles, two waves per SIMD one every ~3.2 - 3.9 (v_exp_f32 6.5), three one every ~2.5 (profiles/r03_ubench_issue.txt) —
+// and the one-kernel form (sweep 1 + sweep 2 in one body: 233 VGPRs for the two score sets, the hi + lo output accumulators and
+// the one-tile-deep software pipeline) ran at TWO.  Registers are allocated for the worst moment of a kernel, so the sweeps are
+// separate kernels now:
+//   * attn_stats_kernel  — sweep 1 only: one score set, no output accumulators (~64 VGPRs -> up to 8 waves per SIMD).  Writes
+//     per query {nc, inv, emax} (what attn_finish_stats returns: the sweep-2 reference, 1 / (normaliser * dw), e2 of the row
+//     maximum) and per block whether ANY of its waves needs the upper clamp or the hi operand bytes of the 16-bit codes;
+//   * attn_pv_kernel<.., FULL = false> — sweep 2 for blocks where no wave does (the common case with thousands of keys): lo
+//     bytes only, ONE 32 x 64 accumulator pair, no software pipeline -> <= 128 VGPRs, 4 waves per SIMD;
+//   * attn_pv_kernel<.., FULL = true>  — sweep 2 for the other blocks (hi + lo accumulators, <= 168 VGPRs, 3 waves per SIMD); each
+//     wave picks clamp / hi exactly as the one-kernel form did.  A block runs in exactly one of the two launches (the other one
+//     returns after reading its flag).
+// The latency of a wave's MFMA -> v_exp -> pack -> MFMA chain is covered by the OTHER waves of the SIMD instead of by a second
+// accumulator set of the same wave.  Arithmetic, operand order and summation order are attn_lean_kernel's: bit-identical
+// (tests/test_hip_kernels.py::test_attention_lds_equals_lean).
+struct AttnStat { float nc, inv, emax; int pad; };            // 16 bytes per query: [BH][Tpad]
 
-    const float cs2 = p.prm[0] * 1.4426950408889634f;
-    const int nzq = -(int)p.prm[1];
-    const float dw = p.prm[3], zpw = p.prm[4], oscale = p.prm[5];
-    const int zv = (int)p.prm[6];
-    const int izpw = (int)zpw;
-    const float urange = p.wmax - p.wmin;
-    const float ubias = zpw - p.wmin;
-    constexpr float MAGIC = QD_MAGIC;
-    constexpr int   MAGICI = QD_MAGICI;
-    if (KT == 1 && nzq > 127) {                               // zq' = -128 without a key-term table (block-uniform): the two-constant
-        attn_lean_body<DT, P16, KT>(p);                       // schedule of the plain body
-        return;
-    }
-
-    v4i qf[DT];
-    const int8_t* qrow = p.q + ((long)bh * p.Tpad + q0 + frow) * p.dpad + half * 16;
-#pragma unroll
-    for (int kk = 0; kk < DT; ++kk) qf[kk] = *reinterpret_cast<const v4i*>(qrow + kk * 32);
-    const int c1w = (nzq & 0xff) * 0x01010101;
-    const v4i c1v = {c1w, c1w, c1w, c1w};
-    const int ntile = p.Spad >> 5;
-    const int nfull = (p.S & 31) ? ntile - 1 : ntile;
-
-    // ---- DMA role of this wave: slot s < DT copies 1 KB of the K tile, DT <= s < 2*DT 1 KB of the V^T tile; wave 3 also copies
-    // the 128 bytes of accumulator seeds (lanes 0-7, issued BEFORE its V^T copy: vmcnt retires in order, so the uniform
-    // "all but the newest copy" wait below over-waits on wave 3 by one 128-byte copy issued a whole tile earlier) ---------------
-    // LDS side is lane-linear (chunk c = slot*64 + lane, 16 B each); the bank swizzle lives in the SOURCE chunk index.
-    constexpr int CPRK = 2 * DT;                              // 16-byte chunks per K row (dpad / 16)
-    const bool dma_k = wave < DT, dma_v = wave >= DT && wave < 2 * DT, dma_t = KT == 2 && wave == 3;
-    const int8_t* ksrc;                                       // source of this lane's chunk of tile 0
+template <int DT, int KT, bool WITH_V>
+struct AttnRing {
+    static constexpr int NST = 4;                             // ring stages (tiles)
+    static constexpr int PD = 3;                              // tiles in flight ahead of the one being consumed
+    static constexpr int KB = 1024 * DT;                      // K tile: 32 keys x dpad bytes
+    static constexpr int VB = WITH_V ? 1024 * DT : 0;         // V^T tile: dpad rows x 32 keys
+    static constexpr int TB = KT == 2 ? 128 : 0;              // the tile's 32 accumulator seeds (qd_attn_keyterm)
+    static constexpr int STAGE = KB + VB + TB;
+    static constexpr int CPRK = 2 * DT;                       // 16-byte chunks per K row (dpad / 16)
+    unsigned char* smem;
+    unsigned lds0, dma_dst;
+    const int8_t* ksrc;
     const int8_t* vsrc;
-    const int32_t* tsrc = KT == 2 ? p.kterm + (long)bh * p.Spad + (lane & 7) * 4 : nullptr;
-    {
-        const int c = (dma_k ? wave : 0) * 64 + lane;
-        const int row = c / CPRK, pos = c % CPRK;
-        const int sw = CPRK == 4 ? ((row >> 2) & 3) : ((row >> 3) & 1);
-        ksrc = p.k + ((long)bh * p.Spad + row) * p.dpad + (pos ^ sw) * 16;
-        const int cv = (dma_v ? wave - DT : 0) * 64 + lane;
-        const int vrow = cv >> 1, vpos = cv & 1;
-        const int vsw = (vrow >> 3) & 1;
-        vsrc = (vrow == p.d) ? reinterpret_cast<const int8_t*>(qd_ones_row) + (vpos ^ vsw) * 16        // the padding row d reads ones
-                             : p.vt + ((long)bh * p.dpad + vrow) * p.Spad + (vpos ^ vsw) * 16;
-    }
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)(smem));
-    const unsigned dma_dst = dma_k ? wave * 1024 : KB + (wave - DT) * 1024;      // inside a stage
-    // fragment offsets of this lane inside a stage
-    unsigned koff[DT], voff[DT];
+    const int32_t* tsrc;
+    bool dma_k, dma_v, dma_t, lane8;
+    int ntile;
+    unsigned koff[DT], voff[DT], toff;
+
+    // DMA role of a wave: slot s < DT copies 1 KB of the K tile, DT <= s < 2*DT 1 KB of the V^T tile; wave 3 also copies the 128
+    // bytes of accumulator seeds (lanes 0-7, issued BEFORE its V^T copy: vmcnt retires in order, so the uniform "all but the
+    // newest PD - 1 tiles" wait over-waits on wave 3, which is safe).  The LDS side is lane-linear (chunk c = slot*64 + lane);
+    // the bank swizzle lives in the SOURCE chunk index (igemm_dma.hip does the same).
+    __device__ __forceinline__ AttnRing(const AttnK& p, unsigned char* sm, int bh, int wave, int lane) {
+        smem = sm;
+        ntile = p.Spad >> 5;
+        const int frow = lane & 31, half = lane >> 5;
+        dma_k = wave < DT;
+        dma_v = WITH_V && wave >= DT && wave < 2 * DT;
+        dma_t = KT == 2 && wave == 3;
+        lane8 = lane < 8;
+        tsrc = KT == 2 ? p.kterm + (long)bh * p.Spad + (lane & 7) * 4 : nullptr;
+        {
+            const int c = (dma_k ? wave : 0) * 64 + lane;
+            const int row = c / CPRK, pos = c % CPRK;
+            const int sw = CPRK == 4 ? ((row >> 2) & 3) : ((row >> 3) & 1);
+            ksrc = p.k + ((long)bh * p.Spad + row) * p.dpad + (pos ^ sw) * 16;
+            const int cv = (dma_v ? wave - DT : 0) * 64 + lane;
+            const int vrow = cv >> 1, vpos = cv & 1;
+            const int vsw = (vrow >> 3) & 1;
+            vsrc = (vrow == p.d) ? reinterpret_cast<const int8_t*>(qd_ones_row) + (vpos ^ vsw) * 16        // the padding row d reads ones
+                                 : p.vt + ((long)bh * p.dpad + vrow) * p.Spad + (vpos ^ vsw) * 16;
+        }
+        lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)(sm));
+        dma_dst = dma_k ? wave * 1024 : KB + (wave - DT) * 1024;
 #pragma unroll
-    for (int kk = 0; kk < DT; ++kk) {
-        const int sw = CPRK == 4 ? ((frow >> 2) & 3) : ((frow >> 3) & 1);
-        koff[kk] = frow * (16 * CPRK) + (((kk * 2 + half) ^ sw) * 16);
-        const int vrow = kk * 32 + frow;
-        voff[kk] = KB + vrow * 32 + ((half ^ ((vrow >> 3) & 1)) * 16);
+        for (int kk = 0; kk < DT; ++kk) {
+            const int sw = CPRK == 4 ? ((frow >> 2) & 3) : ((frow >> 3) & 1);
+            koff[kk] = frow * (16 * CPRK) + (((kk * 2 + half) ^ sw) * 16);
+            const int vrow = kk * 32 + frow;
+            voff[kk] = KB + vrow * 32 + ((half ^ ((vrow >> 3) & 1)) * 16);
+        }
+        toff = KB + VB + half * 16;
     }
-    // issue this wave's DMA for tile `jt` (K always; V only in sweep 2); past the end: tile ntile-1 again (harmless)
-    auto issue = [&](int jt, bool with_v) __attribute__((always_inline)) {
+    // Stage of tile jt: jt & (NST - 1) — a compile-time constant ST when the caller unrolls the tile loop NST-fold (the stage
+    // offset then folds into the ds_read / m0 immediates: no address arithmetic per tile), ST = -1: computed.
+    template <int ST>
+    __device__ __forceinline__ unsigned stage_of(int jt) const { return ST >= 0 ? (unsigned)ST * STAGE : (unsigned)(jt & (NST - 1)) * STAGE; }
+    // this wave's copies for tile `jt`; past the end: tile ntile-1 again (harmless, keeps the vmcnt bookkeeping uniform)
+    template <int ST = -1>
+    __device__ __forceinline__ void issue(int jt) const {
         const int j = min(jt, ntile - 1);
-        const unsigned st = lds0 + (unsigned)(jt & (NST - 1)) * STAGE;
-        if (dma_t && lane < 8) attn_glds16(tsrc + (long)j * 32, st + KB + VB);
+        const unsigned st = lds0 + stage_of<ST>(jt);
+        if (dma_t && lane8) attn_glds16(tsrc + (long)j * 32, st + KB + VB);
         if (dma_k) attn_glds16(ksrc + (long)j * KB, st + dma_dst);
-        else if (dma_v && with_v) attn_glds16(vsrc + (long)j * 32, st + dma_dst);
-    };
-    auto read_k = [&](int jt, v4i (&kf)[DT]) __attribute__((always_inline)) {
-        const unsigned char* sp = smem + (jt & (NST - 1)) * STAGE;
+        else if (dma_v) attn_glds16(vsrc + (long)j * 32, st + dma_dst);
+    }
+    template <int ST = -1>
+    __device__ __forceinline__ void read_k(int jt, v4i (&kf)[DT]) const {
+        const unsigned char* sp = smem + stage_of<ST>(jt);
 #pragma unroll
         for (int kk = 0; kk < DT; ++kk) kf[kk] = *reinterpret_cast<const v4i*>(sp + koff[kk]);
-    };
-    auto read_v = [&](int jt, v4i (&vf)[DT]) __attribute__((always_inline)) {
-        const unsigned char* sp = smem + (jt & (NST - 1)) * STAGE;
+    }
+    template <int ST = -1>
+    __device__ __forceinline__ void read_v(int jt, v4i (&vf)[DT]) const {
+        const unsigned char* sp = smem + stage_of<ST>(jt);
 #pragma unroll
         for (int t = 0; t < DT; ++t) vf[t] = *reinterpret_cast<const v4i*>(sp + voff[t]);
-    };
+    }
     // seeds of this lane's 16 accumulator registers for tile jt: register 4g+e <-> key e + 8g + 4*half of the tile, i.e. the
     // 16-byte word 2g + half of the tile's table (two distinct addresses per ds_read_b128: broadcast)
-    auto read_t = [&](int jt, v16i& ti) __attribute__((always_inline)) {
+    template <int ST = -1>
+    __device__ __forceinline__ void read_t(int jt, v16i& ti) const {
         if (KT == 2) {
-            const unsigned char* sp = smem + (jt & (NST - 1)) * STAGE + KB + VB + half * 16;
+            const unsigned char* sp = smem + stage_of<ST>(jt) + toff;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const v4i w = *reinterpret_cast<const v4i*>(sp + g * 32);
@@ -794,245 +790,293 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ti[r] = MAGICI;
+            for (int r = 0; r < 16; ++r) ti[r] = QD_MAGICI;
         }
-    };
-    auto qk = [&](const v4i (&kf)[DT], const v16i& initv, v16i& acc) __attribute__((always_inline)) {
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[0], qf[0], initv, 0, 0, 0);
-        if (KT == 1) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[0], c1v, acc, 0, 0, 0);
+    }
+    // start of a sweep / pass: tiles 0 .. PD-1 in flight, tile 0 landed and visible to every wave
+    __device__ __forceinline__ void prologue() const {
+        attn_wait_vmcnt<0>();                                 // run-ahead copies of a previous pass must not land behind the new tiles
+        __syncthreads();                                      // nobody still reads the ring of the previous pass
 #pragma unroll
-        for (int kk = 1; kk < DT; ++kk) {
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], qf[kk], acc, 0, 0, 0);
-            if (KT == 1) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], c1v, acc, 0, 0, 0);
-        }
-    };
-    auto key_ok = [&](int jt, int r) __attribute__((always_inline)) { return jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half < p.S; };
-    const v2f cs2v = {cs2, cs2};
-    // start of a sweep: tiles 0 .. NST-2 in flight, tile 0 landed and visible
-    auto prologue = [&](bool with_v) __attribute__((always_inline)) {
-        __syncthreads();                                      // nobody still reads the ring of the previous sweep / pass
-#pragma unroll
-        for (int j = 0; j < PD; ++j) issue(j, with_v);
-        attn_wait_vmcnt<PD - 1>();                            // (wave 3 issues two copies per tile: it over-waits, which is safe)
+        for (int j = 0; j < PD; ++j) issue(j);
+        attn_wait_vmcnt<PD - 1>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");                        // no LDS read of the new tiles is hoisted above the barrier
-    };
-    // SE = 1, head of iteration jt: tile jt+1 landed for every wave, the stage of tile jt-1 is free -> tile jt+NST-1 goes there.
-    // SE = 2, head of the EVEN iterations only: iterations jt and jt+1 read K of tiles jt+1, jt+2 and V^T of jt, jt+1 — tiles up to
-    // jt+2 must have landed for every wave (three later ones may be in flight); every wave is past iteration jt-1, i.e. tiles
-    // <= jt-1 are consumed, so tiles jt+6 and jt+7 may overwrite the stages of jt-2 and jt-1.
-    auto step_sync = [&](int jt, bool with_v, bool even) __attribute__((always_inline)) {
-        if (SE == 2 && !even) return;
-        attn_wait_vmcnt<SE == 1 ? NST - 3 : 3>();
+    }
+    // head of iteration jt: tile jt has landed for every wave (the PD - 1 newer ones may still be in flight) and every wave is
+    // past iteration jt-1, whose stage tile jt+PD now overwrites
+    template <int ST = -1>
+    __device__ __forceinline__ void step_sync(int jt) const {
+        attn_wait_vmcnt<PD - 1>();
         attn_wait_lgkm0();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue(jt + PD, with_v);
-        if (SE == 2) issue(jt + PD + 1, with_v);
-    };
-
-    // ---- sweep 1 ----------------------------------------------------------------------------------------------------
-    AttnNorm nrm;
-    {
-        v4i kf[DT];
-        v16i acc[2], ti;
-        prologue(false);
-        read_k(0, kf);
-        read_t(0, ti);
-        qk(kf, ti, acc[0]);
-        int m0 = 0;                                           // raw accumulators are > 0; 0 = masked
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m0 = max(m0, (nfull == 0 && !key_ok(0, r)) ? 0 : acc[0][r]);
-        m0 -= MAGICI;
-        m0 = max(m0, __shfl_xor(m0, 32));                     // one reference for both halves of the query row
-        float l = 0.f;
-        int mxn = 0;
-        AttnRowRef ref0 = attn_rowref(m0, cs2);
-        for (int pass = 0; pass < 2; ++pass) {
-            if (pass) {
-                prologue(false);
-                read_k(0, kf);
-                read_t(0, ti);
-                qk(kf, ti, acc[0]);
-            }
-            const AttnRowRef refp = attn_rowref(m0, cs2);
-            const v2f ncv = {refp.nc, refp.nc};
-            int mxa = 0;
-            v2f a2 = {0.f, 0.f};
-            auto s1_iter = [&](int jt, auto par_tag, auto tail_tag) __attribute__((always_inline)) {
-                constexpr int C = decltype(par_tag)::value, N = 1 - C;
-                constexpr bool tail = decltype(tail_tag)::value;
-                step_sync(jt, false, C == 0);
-                read_k(jt + 1, kf);
-                read_t(jt + 1, ti);
-                if (tail) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) if (!key_ok(jt, r)) acc[C][r] = 0;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    mxa = max(max(mxa, acc[C][r]), acc[C][r + 1]);
-                    const v2f F = {__int_as_float(acc[C][r]), __int_as_float(acc[C][r + 1])};
-                    const v2f x = __builtin_elementwise_fma(F, cs2v, ncv);
-                    v2f e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-                    if (tail) {
-                        if (acc[C][r] == 0) e.x = 0.f;
-                        if (acc[C][r + 1] == 0) e.y = 0.f;
-                    }
-                    a2 += e;
-                }
-                __builtin_amdgcn_sched_barrier(0);            // the chain stays behind the statistics of tile jt, back to back
-                qk(kf, ti, acc[N]);
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            int jt = 0;
-            for (; jt + 2 <= nfull; jt += 2) {
-                s1_iter(jt, std::integral_constant<int, 0>{}, std::false_type{});
-                s1_iter(jt + 1, std::integral_constant<int, 1>{}, std::false_type{});
-            }
-            if (jt < nfull) {
-                s1_iter(jt, std::integral_constant<int, 0>{}, std::false_type{});
-                ++jt;
-                if (jt < ntile) s1_iter(jt, std::integral_constant<int, 1>{}, std::true_type{});
-            } else if (jt < ntile) {
-                s1_iter(jt, std::integral_constant<int, 0>{}, std::true_type{});
-            }
-            const int mxh = mxa ? mxa - MAGICI - m0 : 0;      // this half's maximum relative to m0
-            const int mxm = max(mxh, __shfl_xor(mxh, 32));
-            const bool again = (float)mxm * cs2 > 64.f;       // this row's maximum rose by > 64 octaves over tile 0's
-            if (pass == 0) {
-                l = a2.x + a2.y;
-                mxn = mxh;
-                // the repeat pass runs the ring and the barriers again: the decision is taken for the whole BLOCK; a wave
-                // that did not need it keeps its first-pass statistics (what attn_lean_kernel computes for it)
-                if (threadIdx.x == 0) s_flag[0] = 0;
-                __syncthreads();
-                if (__any(again) && lane == 0) s_flag[0] = 1;
-                __syncthreads();
-                if (!s_flag[0]) break;
-                if (__any(again)) {                            // this wave repeats against the true maximum
-                    m0 += mxm;
-                    l = -1.f;                                  // marker: take the second pass's statistics
-                }
-            } else if (l < 0.f) {
-                l = a2.x + a2.y;
-                mxn = mxh;
-                ref0 = refp;
-            }
-        }
-        nrm = attn_finish_stats(l, mxn, m0, ref0, cs2, dw);
+        issue<(ST >= 0 ? (ST + PD) & (NST - 1) : -1)>(jt + PD);
     }
-    const float inv = nrm.inv, emax = nrm.emax;
+};
 
-    // ---- sweep 2 ----------------------------------------------------------------------------------------------------
-    v16i ol[DT], oh[P16 ? DT : 1];
+template <int DT, int KT>
+__device__ __forceinline__ void attn_qk(const v4i (&kf)[DT], const v4i (&qf)[DT], v16i& acc) {
+    static_assert(KT != 1, "the LDS-staged kernels take the per-key term from the table (or none)");
+#pragma unroll
+    for (int kk = 0; kk < DT; ++kk) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], qf[kk], acc, 0, 0, 0);
+}
+
+#ifndef QD_ATTN_STATS_OCC
+#define QD_ATTN_STATS_OCC 4                                   // waves per SIMD the statistics kernel is compiled for
+#endif
+#ifndef QD_ATTN_PV_OCC
+#define QD_ATTN_PV_OCC 4                                      // ... the lo-only P.V kernel (<= 128 VGPRs)
+#endif
+#ifndef QD_ATTN_PVFULL_OCC
+#define QD_ATTN_PVFULL_OCC 3                                  // ... the hi + lo P.V kernel (<= 168 VGPRs)
+#endif
+#ifndef QD_ATTN_LDS_PAD
+#define QD_ATTN_LDS_PAD 0                                     // measurement-only: extra LDS bytes per block (caps the blocks per CU)
+#endif
+
+template <int DT, int KT>
+__global__ __launch_bounds__(256, QD_ATTN_STATS_OCC) void attn_stats_kernel(const AttnK p, AttnStat* __restrict__ stat, int* __restrict__ blkflag, int p16) {
+    // a*b+c written as such stays unfused: the lean and the LDS-staged bodies must produce the same normaliser bit for bit
+#pragma clang fp contract(off)
+    using Ring = AttnRing<DT, KT, false>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Ring::NST * Ring::STAGE + QD_ATTN_LDS_PAD];
+    __shared__ int s_flag[2];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int frow = lane & 31, half = lane >> 5;
+    const int lblk = p.xcd ? qd_xcd_remap(blockIdx.x, p.gx * p.BH) : (int)blockIdx.x;
+    const int bh = lblk / p.gx;
+    const int q0r = ((lblk - bh * p.gx) * 4 + wave) * 32;
+    const bool live = q0r < p.T;                              // a wave past the last query still serves the DMA ring and the barriers
+    const int q0 = live ? q0r : 0;
+    const float cs2 = p.prm[0] * 1.4426950408889634f;
+    const float dw = p.prm[3], zpw = p.prm[4];
+    const float urange = p.wmax - p.wmin;
+    const float ubias = zpw - p.wmin;
+    constexpr int MAGICI = QD_MAGICI;
+
+    v4i qf[DT];
+    const int8_t* qrow = p.q + ((long)bh * p.Tpad + q0 + frow) * p.dpad + half * 16;
+#pragma unroll
+    for (int kk = 0; kk < DT; ++kk) qf[kk] = *reinterpret_cast<const v4i*>(qrow + kk * 32);
+    const int ntile = p.Spad >> 5;
+    const int nfull = (p.S & 31) ? ntile - 1 : ntile;
+    const Ring ring(p, smem, bh, wave, lane);
+    auto key_ok = [&](int jt, int r) __attribute__((always_inline)) { return jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half < p.S; };
+    const v2f cs2v = {cs2, cs2};
+
+    v4i kf[DT];
+    v16i acc;
+    if (threadIdx.x == 0) s_flag[1] = 0;
+    ring.prologue();
+    ring.read_k(0, kf);
+    ring.read_t(0, acc);
+    attn_qk<DT, KT>(kf, qf, acc);
+    int m0 = 0;                                               // raw accumulators are > 0; 0 = masked
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m0 = max(m0, (nfull == 0 && !key_ok(0, r)) ? 0 : acc[r]);
+    m0 -= MAGICI;
+    m0 = max(m0, __shfl_xor(m0, 32));                         // one reference for both halves of the query row
+    float l = 0.f;
+    int mxn = 0;
+    AttnRowRef ref0 = attn_rowref(m0, cs2);
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) ring.prologue();
+        const AttnRowRef refp = attn_rowref(m0, cs2);
+        const v2f ncv = {refp.nc, refp.nc};
+        int mxa = 0;
+        v2f a2 = {0.f, 0.f};
+        auto tile = [&](int jt, auto tail_tag, auto st_tag) __attribute__((always_inline)) {
+            constexpr bool tail = decltype(tail_tag)::value;
+            constexpr int ST = decltype(st_tag)::value;
+            ring.template step_sync<ST>(jt);
+            ring.template read_k<ST>(jt, kf);
+            ring.template read_t<ST>(jt, acc);
+            attn_qk<DT, KT>(kf, qf, acc);
+            if (tail) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (!key_ok(jt, r)) acc[r] = 0;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                mxa = max(max(mxa, acc[r]), acc[r + 1]);
+                const v2f F = {__int_as_float(acc[r]), __int_as_float(acc[r + 1])};
+                const v2f x = __builtin_elementwise_fma(F, cs2v, ncv);
+                v2f e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                if (tail) {
+                    if (acc[r] == 0) e.x = 0.f;
+                    if (acc[r + 1] == 0) e.y = 0.f;
+                }
+                a2 += e;
+            }
+        };
+        int jt = 0;
+        for (; jt + 4 <= nfull; jt += 4) {                    // four tiles = one turn of the ring: stage offsets are immediates
+            tile(jt, std::false_type{}, std::integral_constant<int, 0>{});
+            tile(jt + 1, std::false_type{}, std::integral_constant<int, 1>{});
+            tile(jt + 2, std::false_type{}, std::integral_constant<int, 2>{});
+            tile(jt + 3, std::false_type{}, std::integral_constant<int, 3>{});
+        }
+        for (; jt < nfull; ++jt) tile(jt, std::false_type{}, std::integral_constant<int, -1>{});
+        if (nfull < ntile) tile(nfull, std::true_type{}, std::integral_constant<int, -1>{});
+        const int mxh = mxa ? mxa - MAGICI - m0 : 0;          // this half's maximum relative to m0
+        const int mxm = max(mxh, __shfl_xor(mxh, 32));
+        const bool again = (float)mxm * cs2 > 64.f;           // this row's maximum rose by > 64 octaves over tile 0's
+        if (pass == 0) {
+            l = a2.x + a2.y;
+            mxn = mxh;
+            // the repeat pass runs the ring and the barriers again: the decision is taken for the whole BLOCK; a wave that did
+            // not need it keeps its first-pass statistics (what attn_lean_kernel computes for it)
+            if (threadIdx.x == 0) s_flag[0] = 0;
+            __syncthreads();
+            if (__any(again) && lane == 0) s_flag[0] = 1;
+            __syncthreads();
+            if (!s_flag[0]) break;
+            if (__any(again)) {                                // this wave repeats against the true maximum
+                m0 += mxm;
+                l = -1.f;                                      // marker: take the second pass's statistics
+            }
+        } else if (l < 0.f) {
+            l = a2.x + a2.y;
+            mxn = mxh;
+            ref0 = refp;
+        }
+    }
+    attn_wait_vmcnt<0>();                                     // the ring's run-ahead copies: nothing may land in LDS after the block retires
+    const AttnNorm nrm = attn_finish_stats(l, mxn, m0, ref0, cs2, dw);
+    // what sweep 2 decides per WAVE (attn_pv_kernel evaluates the same two expressions on the stored values)
+    const bool need_clamp = __any(!(nrm.emax * nrm.inv * 1.0001f + ubias + 0.5f <= urange)) || (((int)ubias) & 1);
+    const bool hi_live = p16 && (need_clamp || __any(!(nrm.emax * nrm.inv * 1.0001f + ubias + 0.5f < 256.f)));
+    if (live && (need_clamp || hi_live) && lane == 0) s_flag[1] = 1;
+    if (live && half == 0) stat[(long)bh * p.Tpad + q0 + frow] = AttnStat{nrm.ref.nc, nrm.inv, nrm.emax, 0};
+    __syncthreads();
+    if (threadIdx.x == 0) blkflag[lblk] = s_flag[1];
+}
+
+template <int DT, bool P16, int KT, bool FULL>
+__global__ __launch_bounds__(256, FULL ? QD_ATTN_PVFULL_OCC : QD_ATTN_PV_OCC) void attn_pv_kernel(const AttnK p, const AttnStat* __restrict__ stat,
+                                                                                                     const int* __restrict__ blkflag) {
+#pragma clang fp contract(off)
+    using Ring = AttnRing<DT, KT, true>;
+    constexpr bool HIK = FULL && P16;                         // this kernel owns hi accumulators
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Ring::NST * Ring::STAGE + QD_ATTN_LDS_PAD];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int frow = lane & 31, half = lane >> 5;
+    const int lblk = p.xcd ? qd_xcd_remap(blockIdx.x, p.gx * p.BH) : (int)blockIdx.x;
+    if ((blkflag[lblk] != 0) != FULL) return;                 // block-uniform: the other launch owns this block
+    const int bh = lblk / p.gx;
+    const int q0r = ((lblk - bh * p.gx) * 4 + wave) * 32;
+    const bool live = q0r < p.T;
+    const int q0 = live ? q0r : 0;
+    const float cs2 = p.prm[0] * 1.4426950408889634f;
+    const float dw = p.prm[3], zpw = p.prm[4], oscale = p.prm[5];
+    const int zv = (int)p.prm[6];
+    const float urange = p.wmax - p.wmin;
+    const float ubias = zpw - p.wmin;
+    constexpr float MAGIC = QD_MAGIC;
+
+    v4i qf[DT];
+    const int8_t* qrow = p.q + ((long)bh * p.Tpad + q0 + frow) * p.dpad + half * 16;
+#pragma unroll
+    for (int kk = 0; kk < DT; ++kk) qf[kk] = *reinterpret_cast<const v4i*>(qrow + kk * 32);
+    const AttnStat st = stat[(long)bh * p.Tpad + q0 + frow];
+    const float inv = st.inv, emax = st.emax;
+    const int ntile = p.Spad >> 5;
+    const int nfull = (p.S & 31) ? ntile - 1 : ntile;
+    const Ring ring(p, smem, bh, wave, lane);
+    auto key_ok = [&](int jt, int r) __attribute__((always_inline)) { return jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half < p.S; };
+    const v2f cs2v = {cs2, cs2};
+
+    v16i ol[DT], oh[HIK ? DT : 1];
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             ol[t][r] = 0;
-            if (P16) oh[P16 ? t : 0][r] = 0;
+            if (HIK) oh[HIK ? t : 0][r] = 0;
         }
     const int t1 = p.d >> 5, frow1 = p.d & 31;
-    const bool need_clamp = __any(!(emax * inv * 1.0001f + ubias + 0.5f <= urange)) || (((int)ubias) & 1);
-    const bool hi_live = P16 && (need_clamp || __any(!(emax * inv * 1.0001f + ubias + 0.5f < 256.f)));
+    const bool need_clamp = FULL && (__any(!(emax * inv * 1.0001f + ubias + 0.5f <= urange)) || (((int)ubias) & 1));
+    const bool hi_live = HIK && (need_clamp || __any(!(emax * inv * 1.0001f + ubias + 0.5f < 256.f)));
     {
-        v4i kf[DT], vfr[2][DT];
-        v16i acc[2];
-        v4i plo[2], phi[2];
-        plo[1] = v4i{0, 0, 0, 0};                                  // "tile -1": operand bytes 0 contribute nothing
-        phi[1] = v4i{0, 0, 0, 0};
-#pragma unroll
-        for (int t = 0; t < DT; ++t) vfr[1][t] = v4i{0, 0, 0, 0};
-        v16i ti;
-        const v2f ncv = {nrm.ref.nc, nrm.ref.nc};
+        const v2f ncv = {st.nc, st.nc};
         const v2f invv = {inv, inv}, ubv = {ubias, ubias}, magic = {MAGIC, MAGIC}, ubm = {ubias + MAGIC, ubias + MAGIC};
-        prologue(true);
-        read_k(0, kf);
-        read_t(0, ti);
-        qk(kf, ti, acc[0]);
-        // iteration jt: V^T fragments of tile jt and K fragments of tile jt+1 from the ring; the P.V MFMAs of tile jt-1
-        // (operand set N, independent accumulators) spread between the probability chain of tile jt (accumulator set C ->
-        // operand set C); the score chain of tile jt+1 back to back at the end
-        auto s2_iter = [&](int jt, auto par_tag, auto tail_tag, auto clamp_tag, auto hi_tag) __attribute__((always_inline)) {
-            constexpr int C = decltype(par_tag)::value, N = 1 - C;
+        ring.prologue();
+        // tile jt: K / V^T fragments and seeds from the ring, the score chain, the probability chain, the P.V MFMAs — one
+        // dependent chain per wave; the other waves of the SIMD fill its gaps
+        // (lo bytes only, no clamp: the operand byte is code - 128 = code ^ 0x80 for codes < 256, i.e. the low byte of code + 128 —
+        //  the 128 rides in the FMA's constant (even, like MAGIC: ties still go to the even code) and the v_xor disappears)
+        const v2f ubm128 = {ubias + MAGIC + 128.f, ubias + MAGIC + 128.f};
+        auto tile = [&](int jt, auto tail_tag, auto clamp_tag, auto hi_tag, auto st_tag) __attribute__((always_inline)) {
             constexpr bool tail = decltype(tail_tag)::value, CLAMP = decltype(clamp_tag)::value, HI = decltype(hi_tag)::value;
-            constexpr int NPV = DT * (HI ? 2 : 1);
-            step_sync(jt, true, C == 0);
-            read_v(jt, vfr[C]);
-            read_k(jt + 1, kf);
-            read_t(jt + 1, ti);
+            constexpr int ST = decltype(st_tag)::value;
+            constexpr bool BIAS128 = !tail && !CLAMP && !HI;
+            v4i kf[DT], vf[DT];
+            v16i acc;
+            ring.template step_sync<ST>(jt);
+            ring.template read_k<ST>(jt, kf);
+            ring.template read_t<ST>(jt, acc);
+            ring.template read_v<ST>(jt, vf);
+            __builtin_amdgcn_sched_barrier(0);                 // every fragment read of the tile is in flight before the score chain starts
+            attn_qk<DT, KT>(kf, qf, acc);
             unsigned ub[16];
+            v4i plo, phi;
 #pragma unroll
-            for (int m = 0; m < NPV; ++m) {
-                const int t = HI ? m >> 1 : m;
-                if (HI && (m & 1)) oh[P16 ? t : 0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(phi[N], vfr[N][t], oh[P16 ? t : 0], 0, 0, 0);
-                else ol[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(plo[N], vfr[N][t], ol[t], 0, 0, 0);
-#pragma unroll
-                for (int sidx = (8 * m) / NPV; sidx < (8 * (m + 1)) / NPV; ++sidx) {
-                    const int r = 2 * sidx;
-                    const v2f F = {__int_as_float(acc[C][r]), __int_as_float(acc[C][r + 1])};
-                    const v2f x = __builtin_elementwise_fma(F, cs2v, ncv);
-                    const v2f e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-                    v2f t2;
-                    if (CLAMP) {
-                        t2 = __builtin_elementwise_fma(e, invv, ubv);
-                        t2.x = fminf(t2.x, urange);
-                        t2.y = fminf(t2.y, urange);
-                        t2 += magic;
-                    } else {
-                        t2 = __builtin_elementwise_fma(e, invv, ubm);
-                    }
-                    ub[r] = __float_as_uint(t2.x);
-                    ub[r + 1] = __float_as_uint(t2.y);
-                    if (tail) {
-                        if (!key_ok(jt, r)) ub[r] = 0x8080u;
-                        if (!key_ok(jt, r + 1)) ub[r + 1] = 0x8080u;
-                    }
-                    if (sidx & 1) {
-                        const int g = sidx >> 1;
-                        const unsigned a01 = __builtin_amdgcn_perm(ub[4 * g + 1], ub[4 * g], 0x05010400u);
-                        const unsigned a23 = __builtin_amdgcn_perm(ub[4 * g + 3], ub[4 * g + 2], 0x05010400u);
-                        plo[C][g] = (int)(__builtin_amdgcn_perm(a23, a01, 0x05040100u) ^ 0x80808080u);
-                        if (HI) phi[C][g] = (int)(__builtin_amdgcn_perm(a23, a01, 0x07060302u) ^ 0x80808080u);
-                    }
+            for (int sidx = 0; sidx < 8; ++sidx) {
+                const int r = 2 * sidx;
+                const v2f F = {__int_as_float(acc[r]), __int_as_float(acc[r + 1])};
+                const v2f x = __builtin_elementwise_fma(F, cs2v, ncv);
+                const v2f e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                v2f t2;
+                if (CLAMP) {
+                    t2 = __builtin_elementwise_fma(e, invv, ubv);
+                    t2.x = fminf(t2.x, urange);
+                    t2.y = fminf(t2.y, urange);
+                    t2 += magic;
+                } else {
+                    t2 = __builtin_elementwise_fma(e, invv, BIAS128 ? ubm128 : ubm);     // one rounding: half-even on the exact e*inv
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                ub[r] = __float_as_uint(t2.x);
+                ub[r + 1] = __float_as_uint(t2.y);
+                if (tail) {
+                    if (!key_ok(jt, r)) ub[r] = 0x8080u;
+                    if (!key_ok(jt, r + 1)) ub[r + 1] = 0x8080u;
+                }
+                if (sidx & 1) {
+                    const int g = sidx >> 1;
+                    const unsigned a01 = __builtin_amdgcn_perm(ub[4 * g + 1], ub[4 * g], 0x05010400u);
+                    const unsigned a23 = __builtin_amdgcn_perm(ub[4 * g + 3], ub[4 * g + 2], 0x05010400u);
+                    const unsigned lo = __builtin_amdgcn_perm(a23, a01, 0x05040100u);
+                    plo[g] = BIAS128 ? (int)lo : (int)(lo ^ 0x80808080u);
+                    if (HI) phi[g] = (int)(__builtin_amdgcn_perm(a23, a01, 0x07060302u) ^ 0x80808080u);
+                }
             }
-            qk(kf, ti, acc[N]);
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                ol[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(plo, vf[t], ol[t], 0, 0, 0);
+                if (HI) oh[HIK ? t : 0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(phi, vf[t], oh[HIK ? t : 0], 0, 0, 0);
+            }
         };
         auto run = [&](auto clamp_tag, auto hi_tag) __attribute__((always_inline)) {
             int jt = 0;
-            for (; jt + 2 <= nfull; jt += 2) {
-                s2_iter(jt, std::integral_constant<int, 0>{}, std::false_type{}, clamp_tag, hi_tag);
-                s2_iter(jt + 1, std::integral_constant<int, 1>{}, std::false_type{}, clamp_tag, hi_tag);
+            for (; jt + 4 <= nfull; jt += 4) {                 // four tiles = one turn of the ring: stage offsets are immediates
+                tile(jt, std::false_type{}, clamp_tag, hi_tag, std::integral_constant<int, 0>{});
+                tile(jt + 1, std::false_type{}, clamp_tag, hi_tag, std::integral_constant<int, 1>{});
+                tile(jt + 2, std::false_type{}, clamp_tag, hi_tag, std::integral_constant<int, 2>{});
+                tile(jt + 3, std::false_type{}, clamp_tag, hi_tag, std::integral_constant<int, 3>{});
             }
-            int last = 1;
-            if (jt < nfull) {
-                s2_iter(jt, std::integral_constant<int, 0>{}, std::false_type{}, clamp_tag, hi_tag);
-                ++jt;
-                last = 0;
-                if (jt < ntile) { s2_iter(jt, std::integral_constant<int, 1>{}, std::true_type{}, std::true_type{}, hi_tag); last = 1; }
-            } else if (jt < ntile) {
-                s2_iter(jt, std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{}, hi_tag);
-                last = 0;
-            }
-            constexpr bool HI = decltype(hi_tag)::value;
-#pragma unroll
-            for (int t = 0; t < DT; ++t) {
-                if (last == 0) {
-                    ol[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(plo[0], vfr[0][t], ol[t], 0, 0, 0);
-                    if (HI) oh[P16 ? t : 0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(phi[0], vfr[0][t], oh[P16 ? t : 0], 0, 0, 0);
-                } else {
-                    ol[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(plo[1], vfr[1][t], ol[t], 0, 0, 0);
-                    if (HI) oh[P16 ? t : 0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(phi[1], vfr[1][t], oh[P16 ? t : 0], 0, 0, 0);
-                }
-            }
+            for (; jt < nfull; ++jt) tile(jt, std::false_type{}, clamp_tag, hi_tag, std::integral_constant<int, -1>{});
+            if (nfull < ntile) tile(nfull, std::true_type{}, std::true_type{}, hi_tag, std::integral_constant<int, -1>{});
         };
-        if (need_clamp) run(std::true_type{}, std::integral_constant<bool, P16>{});
-        else if (hi_live) run(std::false_type{}, std::true_type{});
-        else run(std::false_type{}, std::false_type{});
+        if constexpr (FULL) {
+            if (need_clamp) run(std::true_type{}, std::integral_constant<bool, P16>{});
+            else if (hi_live) run(std::false_type{}, std::true_type{});
+            else run(std::false_type{}, std::false_type{});
+        } else {
+            run(std::false_type{}, std::false_type{});
+        }
         attn_wait_vmcnt<0>();                                  // the ring's run-ahead copies: nothing may land in LDS after the block retires
     }
     if (!live) return;
@@ -1046,13 +1090,13 @@ __global__ __launch_bounds__(256, 2) void attn_lds_kernel(const AttnK p) {
         for (int t = 0; t < DT; ++t)
             if (t == t1) {
                 sl = ol[t][r];
-                if (P16) sh = oh[P16 ? t : 0][r];
+                if (HIK) sh = oh[HIK ? t : 0][r];
             }
         sl = __shfl(sl, frow1 + 32 * half);
-        if (P16) sh = __shfl(sh, frow1 + 32 * half);
+        if (HIK) sh = __shfl(sh, frow1 + 32 * half);
         us[r] = sl + 128 * p.S + (hi_live ? 256 * (sh + 128 * p.S) : 0) + p.S * p.iwmin;
     }
-    attn_write_rows<DT, P16>(p, ol, oh, us, hi_live, bh, q0, frow, half, dw, zpw, oscale, zv);
+    attn_write_rows<DT, HIK>(p, ol, oh, us, hi_live, bh, q0, frow, half, dw, zpw, oscale, zv);
 }
 
 // any row length (a multiple of 16 bytes): one thread per K row
@@ -1070,14 +1114,22 @@ __global__ __launch_bounds__(256) void attn_keyterm_rows_kernel(const int8_t* __
     kterm[r] = QD_MAGICI + nzq * s;
 }
 
-// kt: 0 = symmetric q (no per-key term), 1 = constant-operand MFMAs, 2 = key-term table (AttnK::kterm)
+// The LDS-staged path: statistics, then the two P.V launches (every block runs in exactly one of them).  kt: 0 = symmetric q
+// (no per-key term), 2 = key-term table (AttnK::kterm).  ws: [BH][Tpad] AttnStat + one int per block.
 template <int DT>
-int launch_lds(const AttnK& k, bool p16, int kt, int se, hipStream_t st) {
+int launch_lds(const AttnK& k, bool p16, int kt, void* ws, hipStream_t st) {
     dim3 grid((unsigned)(k.gx * k.BH));
-#define QD_LDS_CASE(P, K) if (p16 == P && kt == K) { if (se == 2) hipLaunchKernelGGL((attn_lds_kernel<DT, P, K, 2>), grid, dim3(256), 0, st, k); \
-                                                     else hipLaunchKernelGGL((attn_lds_kernel<DT, P, K, 1>), grid, dim3(256), 0, st, k); }
-    QD_LDS_CASE(true, 0) QD_LDS_CASE(true, 1) QD_LDS_CASE(true, 2) QD_LDS_CASE(false, 0) QD_LDS_CASE(false, 1) QD_LDS_CASE(false, 2)
-#undef QD_LDS_CASE
+    AttnStat* stat = reinterpret_cast<AttnStat*>(ws);
+    int* flag = reinterpret_cast<int*>(stat + (long)k.BH * k.Tpad);
+    if (kt == 2) hipLaunchKernelGGL((attn_stats_kernel<DT, 2>), grid, dim3(256), 0, st, k, stat, flag, p16 ? 1 : 0);
+    else hipLaunchKernelGGL((attn_stats_kernel<DT, 0>), grid, dim3(256), 0, st, k, stat, flag, p16 ? 1 : 0);
+#define QD_PV_CASE(P, K)                                                                                          \
+    if (p16 == P && kt == K) {                                                                                    \
+        hipLaunchKernelGGL((attn_pv_kernel<DT, P, K, false>), grid, dim3(256), 0, st, k, (const AttnStat*)stat, (const int*)flag); \
+        hipLaunchKernelGGL((attn_pv_kernel<DT, P, K, true>), grid, dim3(256), 0, st, k, (const AttnStat*)stat, (const int*)flag);  \
+    }
+    QD_PV_CASE(true, 0) QD_PV_CASE(true, 2) QD_PV_CASE(false, 0) QD_PV_CASE(false, 2)
+#undef QD_PV_CASE
     return 0;
 }
 
@@ -1121,11 +1173,11 @@ int launch_dt(const AttnK& k, bool p16, bool asym, hipStream_t st) {
 
 // Run-time knobs of the attention launcher: read from the environment ONCE (first call), changed afterwards only through
 // qd_attn_config (tests and A/B runs flip the kernel choice inside one process).
-struct AttnKnobs { int lean, pipe, xcd, ktab, sync; };
+struct AttnKnobs { int lean, pipe, xcd, ktab; };
 static AttnKnobs& attn_knobs() {
     static AttnKnobs k = [] {
         auto env = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
-        return AttnKnobs{env("QD_ATTN_LEAN", 1), env("QD_ATTN_PIPE", 2), env("QD_ATTN_XCD", 1), env("QD_ATTN_KTAB", 1), env("QD_ATTN_SYNC", 1)};
+        return AttnKnobs{env("QD_ATTN_LEAN", 1), env("QD_ATTN_PIPE", 2), env("QD_ATTN_XCD", 1), env("QD_ATTN_KTAB", 1)};
     }();
     return k;
 }
@@ -1147,8 +1199,20 @@ extern "C" void qd_attn_config(int pipe_mode, int xcd, int ktab, int lean) {
     if (lean >= 0) k.lean = lean;
 }
 
-extern "C" void qd_attn_sync(int tiles_per_rendezvous) {
-    if (tiles_per_rendezvous == 1 || tiles_per_rendezvous == 2) attn_knobs().sync = tiles_per_rendezvous;
+// shapes of the LDS-staged two-kernel path: a lean shape (d < 64, not a multiple of 32) whose key axis is long enough for
+// the ring start-up and the barriers to pay (pipe 2: S >= 512; pipe 3: any) and fits the constant row of ones
+static bool attn_lds_shape(int T, int S, int d, int Spad, int dpad) {
+    (void)T;
+    const AttnKnobs& kn = attn_knobs();
+    if (!attn_lean_shape(d) || dpad > 64 || Spad > QD_ONES_ROW) return false;
+    return kn.pipe == 3 || (kn.pipe == 2 && S >= 512);
+}
+
+extern "C" int64_t qd_attn_ws_bytes(int BH, int T, int S, int d) {
+    if (BH <= 0 || T <= 0 || S <= 0 || d <= 0) return 0;
+    const int Tpad = (T + 31) / 32 * 32, Spad = (S + 31) / 32 * 32, dpad = (d + 31) / 32 * 32;
+    if (!attn_lds_shape(T, S, d, Spad, dpad)) return 0;
+    return (int64_t)BH * Tpad * (int64_t)sizeof(AttnStat) + (int64_t)BH * ((T + 127) / 128) * 4;
 }
 
 // the table pays where the LDS-staged kernel runs (thousands of keys); the register-fed kernel on short key axes (the 77
@@ -1177,7 +1241,8 @@ extern "C" int qd_attn_keyterm(const int8_t* k, int BH, int Spad, int dpad, cons
 extern "C" int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt, const int32_t* qsum, const int32_t* kterm,
                           const int32_t* vsum, int BH, int H, int T, int S, int d, int Tpad, int Spad, int dpad,
                           const float* prm, int wbits, int wmin, int wmax, int q_asym, float* out, int64_t ldo,
-                          int8_t* out8, int64_t ldo8, const float* oq_params, int oq_min, int oq_max, int oq_off, void* stream) {
+                          int8_t* out8, int64_t ldo8, const float* oq_params, int oq_min, int oq_max, int oq_off,
+                          void* ws, int64_t ws_bytes, void* stream) {
     QD_REQUIRE(q && k && vt && vsum && prm && (out || out8), "qd_attn_i8: null pointer");
     QD_REQUIRE(!out8 || (oq_params && ldo8 >= (int64_t)H * d && oq_max - oq_off <= 127 && oq_min - oq_off >= -128),
                "qd_attn_i8: quantised output needs oq_params, ldo8 >= H*d and a grid that fits int8");
@@ -1199,11 +1264,14 @@ extern "C" int qd_attn_i8(const int8_t* q, const int8_t* k, const int8_t* vt, co
     // test), 3 = LDS-staged kernel on every eligible shape
     if (attn_lean_shape(d)) {
         const int kt = !asym ? 0 : (kterm && qd_attn_uses_keyterm(d, S, q_asym)) ? 2 : 1;     // per-key zero-point term: none / constant-operand MFMAs / table
-        const bool lds_fits = dpad <= 64 && Spad <= QD_ONES_ROW && (long)Spad * dpad < (1L << 31);
-        if (lds_fits && (kn.pipe == 3 || (kn.pipe == 2 && S >= 512))) {         // short key axes: ring start-up and barriers lose
-            const int se = kn.sync == 2 ? 2 : 1;           // measured equal (profiles/r05_attn_rendezvous.md): round 3's schedule stays the default
-            if (dpad == 32) launch_lds<1>(a, p16, kt, se, st);
-            else launch_lds<2>(a, p16, kt, se, st);
+        // the LDS-staged two-kernel path (qd_attn_ws_bytes says which shapes): without a table for an asymmetric q (kt == 1: the
+        // constant-operand MFMAs, A/B runs with ktab = 0) the register-fed kernel runs instead
+        if (kt != 1 && attn_lds_shape(T, S, d, Spad, dpad)) {
+            const int64_t need = qd_attn_ws_bytes(BH, T, S, d);
+            QD_REQUIRE(ws && ws_bytes >= need && qd_aligned(ws, 16), "qd_attn_i8: this shape needs %ld bytes of 16-byte aligned workspace (qd_attn_ws_bytes), got %ld",
+                       (long)need, (long)ws_bytes);
+            if (dpad == 32) launch_lds<1>(a, p16, kt, ws, st);
+            else launch_lds<2>(a, p16, kt, ws, st);
         } else if (dpad == 32) launch_lean<1>(a, p16, kt, st);
         else if (dpad == 64) launch_lean<2>(a, p16, kt, st);
         else launch_lean<3>(a, p16, kt, st);

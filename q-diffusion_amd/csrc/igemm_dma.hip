@@ -77,16 +77,6 @@ struct ConvD {
     int    pointwise;         // 1x1 convolution / linear layer without padding or stride: output row m is input pixel m
     int    res_f16;           // O_HROWS: the fp residual is fp16 (else fp32)
     int    ups;               // x is the HALF-resolution map [B][H/2][W/2][ldx]; the convolution runs on its nearest-2x up-sampling
-    // O_LN: LayerNorm of the output rows + up to three activation quantisers (qd_ln_fuse)
-    const float* ln_gamma;
-    const float* ln_beta;
-    float  ln_eps;
-    int    ln_nout;
-    const float* ln_qp[3];
-    float  ln_qmin[3], ln_qmax[3];
-    int    ln_off[3];
-    int8_t* ln_out[3];
-    long   ln_ldo;
 };
 
 // O_PART: split-K partial.  The block contracts K-steps [y*it_per, (y+1)*it_per) only and stores
@@ -97,8 +87,7 @@ struct ConvD {
 // attn_i8.hip (rows [(b,h)][t][dpad] for q and k; transposed + key-permuted [(b,h)][dd][t] plus column
 // sums for v) — the fp32 projection output and the separate qd_quantize_heads pass disappear.
 // O_BF16 (WB = 16 only): bf16 rows (+ bf16 residual) — the floating-point mode of the kernel (first-stage decoder, §N1).
-// O_LN: fp32 / fp16 rows (res_f16 says which) + LayerNorm + quantisers of those rows (a wave owns whole rows: WN == 1, 32*NT == Cout)
-enum { O_F32 = 0, O_F16 = 1, O_I32 = 2, O_GEGLU = 3, O_PART = 4, O_HROWS = 5, O_HTR = 6, O_BF16 = 7, O_LN = 8 };
+enum { O_F32 = 0, O_F16 = 1, O_I32 = 2, O_GEGLU = 3, O_PART = 4, O_HROWS = 5, O_HTR = 6, O_BF16 = 7 };
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -815,133 +804,6 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
         return;
     }
 
-    if constexpr (OUT == O_LN) {
-#pragma clang fp contract(off)
-        // Linear (+ residual) -> rows of the activation stream AND LayerNorm(row) -> the next Linear(s)' int8 rows.  WN == 1
-        // and 32 * NT == Cout: the 32 rows of a wave are complete, so the statistics are wave-local — no LDS exchange, no
-        // block barrier.  Phase 1 / 2 are the linear epilogue's; the row-major values (as STORED: rounded to fp16 when the
-        // stream is fp16) stay in registers, taking the place of the accumulators they were made from: per lane 4 rows
-        // (pass * 8 + lane / 8) x NT tiles x 4 columns.  A row is reduced by its eight lanes: 4 * NT values in (tile, column)
-        // order per lane, then a butterfly over the lanes (xor 1, 2, 4); two passes (mean, then squared deviations), explicit
-        // fma — ln_quant_rows8_kernel (norm_quant.hip) evaluates the same expressions in the same order: identical codes.
-        static_assert(WN == 1 && MT == 1 && !SPLIT && !BF, "LayerNorm epilogue: a wave owns whole rows");
-        const bool h16 = p.res_f16 != 0;
-        const bool has_res = p.residual != nullptr;
-        float*  const of = reinterpret_cast<float*>(p.out);
-        __half* const oh = reinterpret_cast<__half*>(p.out);
-        const float*  const rf = reinterpret_cast<const float*>(p.residual);
-        const __half* const rh = reinterpret_cast<const __half*>(p.residual);
-        constexpr int C = 32 * NT;
-        v4f val[4][NT];
-        int as[16];
-        row_terms(wrow0, as);
-        long mrow[4];
-        bool mok[4];
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const long m = m0 + wrow0 + ps * 8 + rr0;
-            mok[ps] = m < p.M;
-            mrow[ps] = mok[ps] ? m : m0;
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int cl = j * 32 + frow;
-            const float sc = sScale[cl];
-            const int zw_n = sZw[cl];
-            const int zc2 = sZc[cl] - zw_n * kz;
-            const float bias_n = sBias[cl];
-            const int n4 = n0 + j * 32 + c4;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = crow(r) + 4 * fhalf;
-                const int I = acc[0][j][r] - zc2 - __mul24(zw_n, as[r]);
-                tb[rl * 32 + frow] = __float_as_uint(__builtin_fmaf((float)I, sc, bias_n));     // the linear epilogue's value, bit for bit
-            }
-            v4f rs[4];
-            if (has_res) {
-#pragma unroll
-                for (int ps = 0; ps < 4; ++ps) {
-                    if (h16) rs[ps] = qd_ld4h(rh + mrow[ps] * p.ldr + n4);
-                    else rs[ps] = *reinterpret_cast<const v4f*>(rf + mrow[ps] * p.ldr + n4);
-                }
-            }
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                v4f v = *reinterpret_cast<const v4f*>(tb + (ps * 8 + rr0) * 32 + c4);
-                if (has_res) v += rs[ps];
-                if (h16) {
-                    const uint2 u = {qd_pack2h(v[0], v[1]), qd_pack2h(v[2], v[3])};
-                    if (mok[ps]) *reinterpret_cast<uint2*>(oh + mrow[ps] * p.ldo + n4) = u;
-                    const float2 a = qd_h2_to_f((int)u.x), b = qd_h2_to_f((int)u.y);
-                    v = v4f{a.x, a.y, b.x, b.y};        // LayerNorm sees what the stream holds
-                } else if (mok[ps]) {
-                    *reinterpret_cast<v4f*>(of + mrow[ps] * p.ldo + n4) = v;
-                }
-                val[ps][j] = v;
-            }
-        }
-        float mean[4], rstd[4];
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            float sacc = 0.f;
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sacc += val[ps][j][e];
-            sacc += __shfl_xor(sacc, 1);
-            sacc += __shfl_xor(sacc, 2);
-            sacc += __shfl_xor(sacc, 4);
-            mean[ps] = sacc / (float)C;
-            float qacc = 0.f;
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float dlt = val[ps][j][e] - mean[ps];
-                    qacc = __builtin_fmaf(dlt, dlt, qacc);
-                }
-            qacc += __shfl_xor(qacc, 1);
-            qacc += __shfl_xor(qacc, 2);
-            qacc += __shfl_xor(qacc, 4);
-            rstd[ps] = 1.0f / sqrtf(qacc / (float)C + p.ln_eps);
-        }
-        const int nout = p.ln_nout;
-        const QP qa = qd_load_qp(p.ln_qp[0]);
-        const QP qb = nout > 1 ? qd_load_qp(p.ln_qp[1]) : QP{1.f, 0.f, 1.f, false};
-        const QP qc = nout > 2 ? qd_load_qp(p.ln_qp[2]) : QP{1.f, 0.f, 1.f, false};
-        const QB ba = qd_bytes_setup(qa, p.ln_qmin[0], p.ln_qmax[0], p.ln_off[0]), bb = qd_bytes_setup(qb, p.ln_qmin[1], p.ln_qmax[1], p.ln_off[1]),
-                 bc = qd_bytes_setup(qc, p.ln_qmin[2], p.ln_qmax[2], p.ln_off[2]);
-        auto lnbody = [&](auto ft) __attribute__((always_inline)) {
-#pragma clang fp contract(off)
-            constexpr bool FAST = decltype(ft)::value;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n4 = n0 + j * 32 + c4;
-                const v4f g4 = *reinterpret_cast<const v4f*>(p.ln_gamma + n4), b4 = *reinterpret_cast<const v4f*>(p.ln_beta + n4);
-#pragma unroll
-                for (int ps = 0; ps < 4; ++ps) {
-                    unsigned u0 = 0, u1 = 0, u2 = 0;
-                    float y[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float tt = (val[ps][j][e] - mean[ps]) * rstd[ps];
-                        y[e] = __builtin_fmaf(tt, g4[e], b4[e]);
-                    }
-                    u0 = qd_pack4_t<FAST>(y[0], y[1], y[2], y[3], qa, ba);
-                    if (nout > 1) u1 = qd_pack4_t<FAST>(y[0], y[1], y[2], y[3], qb, bb);
-                    if (nout > 2) u2 = qd_pack4_t<FAST>(y[0], y[1], y[2], y[3], qc, bc);
-                    if (mok[ps]) {
-                        *reinterpret_cast<unsigned*>(p.ln_out[0] + mrow[ps] * p.ln_ldo + n4) = u0;
-                        if (nout > 1) *reinterpret_cast<unsigned*>(p.ln_out[1] + mrow[ps] * p.ln_ldo + n4) = u1;
-                        if (nout > 2) *reinterpret_cast<unsigned*>(p.ln_out[2] + mrow[ps] * p.ln_ldo + n4) = u2;
-                    }
-                }
-            }
-        };
-        QD_FAST_DISPATCH(qa.fast && (nout < 2 || qb.fast) && (nout < 3 || qc.fast), lnbody);
-        return;
-    }
-
     // ---- linear epilogues: fp32 / fp16 rows, raw int32 (test hook), split-K partials ----------------------------------------
     constexpr bool INT_OUT = OUT == O_PART || OUT == O_I32;
     constexpr bool H16_OUT = OUT == O_F16, B16_OUT = OUT == O_BF16;
@@ -984,7 +846,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
                     tb[rl * 32 + frow] = __float_as_uint((float)acc[i][j][r] + bias_n);
                 } else {
                     const int I = acc[i][j][r] - zc2 - __mul24(zw_n, as[r]);
-                    // one fma(I, scale, bias) — written out: the O_F16 pair form, the O_LN epilogue and the split-K finalise
+                    // one fma(I, scale, bias) — written out: the O_F16 pair form and the split-K finalise
                     // must produce this value bit for bit and may not depend on where the optimiser contracts
                     float v;
                     if (SPLIT) v = __builtin_fmaf((float)I, sc, facc[SPLIT ? i : 0][SPLIT ? j : 0][r]) + bias_n;
@@ -1425,7 +1287,6 @@ int dispatch(ConvD& k, bool split, int out, hipStream_t st, int nsplit = 1) {
         // (int8 weights: the 128 x 128 tile only — the CIFAR attention block's q / k / v, 256 channels)
         if constexpr ((WB == 4 && WM == 4) || (WB == 8 && MT == 1 && NT == 4)) { QD_CASE(false, O_HROWS) QD_CASE(false, O_HTR) }
         if constexpr (NT == 4 && WB == 4 && WM == 4) { QD_CASE(false, O_GEGLU) }
-        if constexpr (MT == 1 && NT == 10 && WB == 4 && WM == 4) { QD_CASE(false, O_LN) }
     }
 #undef QD_CASE
     qd_set_error("qd_conv2d_%s: unsupported variant split=%d out=%d tile %dx%d", WB >= 16 ? "bf16" : "i8", (int)split, out, BM, BN);
@@ -1552,29 +1413,6 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
     }
     QD_REQUIRE(!(iout && split), "qd_conv2d_i8_acc: single segment only");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (d->ln) {
-        const qd_ln_fuse& L = *d->ln;
-        QD_REQUIRE(!iout && !split && !w8 && d->epilogue == QD_EPI_LINEAR && !d->gn_part && !d->rowbias,
-                   "qd_conv2d_i8: the LayerNorm epilogue takes one int4 segment, the linear epilogue, no row bias, no statistics");
-        QD_REQUIRE(d->Cout == 320, "qd_conv2d_i8: the LayerNorm epilogue is built for Cout == 320 (got %d)", d->Cout);
-        QD_REQUIRE(L.gamma && L.beta && L.nout >= 1 && L.nout <= 3 && L.ldo >= d->Cout && L.ldo % 4 == 0,
-                   "qd_conv2d_i8: qd_ln_fuse needs gamma, beta, 1..3 outputs and 4-byte aligned output rows");
-        QD_REQUIRE(qd_aligned(L.gamma, 16) && qd_aligned(L.beta, 16), "qd_conv2d_i8: LayerNorm gamma / beta must be 16-byte aligned");
-        QD_REQUIRE(d->ldo % 4 == 0 && qd_aligned(d->out, 16) && (!d->residual || (d->ldr % 4 == 0 && qd_aligned(d->residual, d->out_dtype == QD_F16 ? 8 : 16))),
-                   "qd_conv2d_i8: the LayerNorm epilogue needs 4-element aligned output / residual rows");
-        k.ln_gamma = L.gamma; k.ln_beta = L.beta; k.ln_eps = L.eps; k.ln_nout = L.nout; k.ln_ldo = (long)L.ldo;
-        for (int i = 0; i < L.nout; ++i) {
-            QD_REQUIRE(L.qparams[i] && L.out[i] && qd_aligned(L.out[i], 4), "qd_conv2d_i8: qd_ln_fuse output %d null / unaligned", i);
-            QD_REQUIRE(L.qmax[i] - L.off[i] <= 127 && L.qmin[i] - L.off[i] >= -128, "qd_conv2d_i8: qd_ln_fuse grid %d does not fit int8", i);
-            k.ln_qp[i] = L.qparams[i]; k.ln_qmin[i] = (float)L.qmin[i]; k.ln_qmax[i] = (float)L.qmax[i]; k.ln_off[i] = L.off[i];
-            k.ln_out[i] = L.out[i];
-        }
-        k.res_f16 = d->out_dtype == QD_F16 ? 1 : 0;
-        int rcl = dispatch<1, 10, 4, 1>(k, false, O_LN, st);
-        if (rcl) return rcl;
-        QD_LAUNCH_CHECK("qd_conv2d_i8 (LayerNorm epilogue)");
-        return 0;
-    }
     const int N = d->Cout;
     const long M = k.M;
     int rc;

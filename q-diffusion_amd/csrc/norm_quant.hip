@@ -445,12 +445,11 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(const T* __restrict__ x, 
     QD_FAST_DISPATCH(qa.fast && (nout < 2 || qb.fast) && (nout < 3 || qc.fast), lnbody);
 }
 
-// C = 32 * J (J <= 10: the 320-channel level of SD, where LayerNorm can also run inside the producing GEMM's epilogue — O_LN
-// of igemm_dma.hip): EIGHT lanes per row, lane c owns columns j*32 + c*4 .. +3 of every 32-column group j — the layout the
-// GEMM epilogue leaves its row-major values in.  A row is reduced exactly as there: 4*J values per lane in (group, column)
-// order, a butterfly over the eight lanes (xor 1, 2, 4), two passes, explicit fma — so the fused and the stand-alone
-// LayerNorm produce the same codes bit for bit (tests/test_hip_kernels.py::test_layernorm_in_the_epilogue).  A wave handles
-// eight rows; per group the eight lanes of a row read 128 (fp32) / 64 (fp16) contiguous bytes.
+// C = 32 * J (J <= 10: the 320-channel level of SD): EIGHT lanes per row, lane c owns columns j*32 + c*4 .. +3 of every
+// 32-column group j.  A row is reduced as 4*J values per lane in (group, column) order, then a butterfly over the eight lanes
+// (xor 1, 2, 4), two passes, explicit fma.  A wave handles eight rows; per group the eight lanes of a row read 128 (fp32) /
+// 64 (fp16) contiguous bytes.  (Round 5 ran the same reduction inside the producing GEMM's epilogue: bit-identical, no
+// faster — the pass is VALU-bound, not bound by its re-read — and deleted in round 6, profiles/r05_ln_fuse_ab.md.)
 template <typename T, int J>
 __global__ __launch_bounds__(256) void ln_quant_rows8_kernel(const T* __restrict__ x, long M, long ldx, float eps,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -857,7 +856,6 @@ extern "C" int qd_layernorm_quant(const void* x, int x_dtype, int64_t M, int C, 
     static const bool f16_lines = !(getenv("QD_F16_LINES") && atoi(getenv("QD_F16_LINES")) == 0);
     static const bool rows8 = !(getenv("QD_LN_ROWS8") && atoi(getenv("QD_LN_ROWS8")) == 0);      // A/B knob: 0 = the generic kernels at C = 320 too
     if (rows8 && C == 320 && vec) {
-        // the reduction order of the GEMM epilogue's LayerNorm (O_LN): what runs fused and what runs here agree bit for bit
         dim3 grid((unsigned)((M + 31) / 32));
         if (x_dtype == QD_F32)
             hipLaunchKernelGGL((ln_quant_rows8_kernel<float, 10>), grid, dim3(256), 0, st, (const float*)x, (long)M, (long)ldx, eps, gamma, beta, nout, qp[0], qp[1], qp[2],

@@ -185,15 +185,8 @@ class SpatialTransformer(nn.Module):
             # row GEMMs on the channels-last stream and the `+ x` rides in proj_out's epilogue.
             rows = qb._nhwc_rows(x)
             xq = qb._gn_silu_to(self.proj_in, rows, b, h * w, c, self.norm, silu=False)
-            blk0 = self.transformer_blocks[0] if len(self.transformer_blocks) else None
-            lnf = None
-            if isinstance(blk0, qb.QuantBasicTransformerBlock):
-                # norm1 of the first block + the q / k / v quantisers of its self-attention in proj_in's own epilogue (320 channels)
-                lnf = qb._ln_fuse(self.proj_in, blk0.norm1, [blk0.attn1.to_q, blk0.attn1.to_k, blk0.attn1.to_v])
-            o = self.proj_in.forward_codes(xq, b, h, w, ln=lnf)
+            o = self.proj_in.forward_codes(xq, b, h, w)
             t = o.view(b, h * w, -1)
-            if getattr(o, "qd_ln", None) is not None:
-                t.qd_ln = o.qd_ln                                # views do not inherit attributes
             last = len(self.transformer_blocks) - 1
             for i, blk in enumerate(self.transformer_blocks):
                 if i == last and self.proj_out.act_quantizer.inited and isinstance(blk, qb.QuantBasicTransformerBlock):

@@ -399,34 +399,14 @@ def upsample_fold_ok(plan, H, W):
     return bool(plan.pack.tiled and plan.kh * plan.kw > 1 and plan.stride == 1 and H % 2 == 0 and W % 2 == 0)
 
 
-# LayerNorm + the next sub-layer's quantisers in the producing GEMM's epilogue (qd_ln_fuse, 320 channels).  OFF by default:
-# built, bit-identical to the unfused path, and measured no faster — 20.36 / 20.29 ms fused vs 20.29 / 20.31 unfused per SD step
-# (fp32 stream), 19.62 vs 19.48 (fp16 stream), profiles/r05_ln_fuse_ab.md: the stand-alone LayerNorm is VALU-bound (statistics,
-# normalisation and up to three quantisers per element), not bound by its re-read of the rows, so moving that work into the
-# GEMM's epilogue moves its time with it.  QDIFF_LN_FUSE=1 switches it on.
-LN_FUSE = os.environ.get("QDIFF_LN_FUSE", "0") == "1"
-
-
-def ln_fusable(plan, ln, consumers):
-    """The Linear `plan` can layer-normalise and quantise its own output rows for `consumers` (ConvPlans of the Linears behind
-    LayerNorm `ln`): qd_ln_fuse — the 320-channel level of SD, where a 128 x 320 tile owns whole rows.  (Capability only:
-    whether the model USES it is engine.LN_FUSE, checked by quant_block._ln_fuse.)"""
-    return bool(plan.pack.tiled and plan.pack.wbits == 4 and len(plan.segs) == 1 and plan.Cout == 320
-                and tuple(ln.normalized_shape) == (320,) and ln.weight is not None and ln.bias is not None
-                and 1 <= len(consumers) <= 3 and all(len(p.segs) == 1 and p.ldx == consumers[0].ldx and p.ldx >= 320 for p in consumers))
-
-
 def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, residual=None, acc_out=None,
-                 out_dtype=None, pad_tl=None, splitk=None, gn_stats=False, slot=None, upsample2x=False, ln=None):
+                 out_dtype=None, pad_tl=None, splitk=None, gn_stats=False, slot=None, upsample2x=False):
     """Run K3/K4 on quantised rows xq [B*H*W][ldx].  Returns out [B*Ho*Wo][Cout] (row-major).
     splitk=False forbids the split-K schedule (tests compare it with the default, which lets the library decide).
     gn_stats=True: when the layer is eligible (tile-ordered int4, fp32 out, Ho*Wo % 128 == 0, not a split-K layer) the
     kernel also writes the first level of GroupNorm statistics of its output; they are attached to the returned tensor
     as `out.qd_gn_part` ([B][Ho*Wo/128][Cout][2]) for groupnorm_silu_quant to pick up.
-    slot: optional CatSlot side — the output (and its statistics) land in that column range of the concatenation buffer.
-    ln: optional (LayerNorm module, [consumer ConvPlans]) with ln_fusable(...) true: the launch also writes LayerNorm(out row)
-    quantised for every consumer; the int8 rows travel with the returned tensor as `out.qd_ln = (module, plans, [rows])` for
-    quant_block._ln_to to pick up instead of launching qd_layernorm_quant."""
+    slot: optional CatSlot side — the output (and its statistics) land in that column range of the concatenation buffer."""
     if Ho is None:
         Ho, Wo = conv_out_hw(H, W, plan)
     M = B * Ho * Wo
@@ -451,14 +431,6 @@ def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, re
                         B=B, H=H, W=W, Ho=Ho, Wo=Wo, Cout=plan.Cout, kh=plan.kh, kw=plan.kw, stride=plan.stride,
                         pad_t=pad, pad_l=pad, wbits=plan.pack.wbits, w_tiled=plan.pack.tiled, segs=plan.segs,
                         splitk=splitk, upsample2x=upsample2x)
-    ln_rows = None
-    if ln is not None and acc_out is None and rowbias is None and out.dtype in (torch.float32, torch.float16) and out.stride(1) == 1:
-        lnm, cons = ln
-        ln_rows = [torch.empty((M, p.ldx), dtype=torch.int8, device=xq.device) for p in cons]
-        call.ln = dict(gamma=lnm.weight, beta=lnm.bias, eps=lnm.eps, qparams=[p.qparams[0] for p in cons], grids=[p.grids[0] for p in cons],
-                       outs=ln_rows, ldo=cons[0].ldx)
-        call.splitk = False
-        gn_stats = False
     part = None
     if (gn_stats and acc_out is None and plan.pack.tiled and out.dtype in (torch.float32, torch.float16) and (Ho * Wo) % 128 == 0
             and out.stride(1) == 1 and (splitk is False or hip.splitk_ws_bytes(call) == 0)):
@@ -470,8 +442,6 @@ def conv_forward(plan, xq, B, H, W, Ho=None, Wo=None, out=None, rowbias=None, re
     hip.conv2d_i8(call, acc_out=acc_out)
     if part is not None:
         out.qd_gn_part = part
-    if ln_rows is not None:
-        out.qd_ln = (ln[0], tuple(ln[1]), ln_rows)
     return out if acc_out is None else acc_out
 
 

@@ -44,15 +44,7 @@ class ConvDesc(ctypes.Structure):
                 ("splitk_ws", ctypes.c_void_p), ("splitk_ws_bytes", ctypes.c_int64),
                 ("hd_H", ctypes.c_int32), ("hd_d", ctypes.c_int32), ("hd_T", ctypes.c_int32), ("hd_Tpad", ctypes.c_int32),
                 ("hd_dpad", ctypes.c_int32), ("oq_prescale", ctypes.c_float), ("hd_sum", ctypes.c_void_p),
-                ("gn_part", ctypes.c_void_p), ("gn_ld", ctypes.c_int64), ("upsample2x", ctypes.c_int32), ("_pad3", ctypes.c_int32),
-                ("ln", ctypes.c_void_p)]
-
-
-class LnFuse(ctypes.Structure):
-    """qd_ln_fuse (ABI v19): LayerNorm + up to three quantisers of the output rows, in the GEMM's epilogue."""
-    _fields_ = [("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("eps", ctypes.c_float), ("nout", ctypes.c_int32),
-                ("qparams", ctypes.c_void_p * 3), ("qmin", ctypes.c_int32 * 3), ("qmax", ctypes.c_int32 * 3), ("off", ctypes.c_int32 * 3),
-                ("_pad", ctypes.c_int32), ("out", ctypes.c_void_p * 3), ("ldo", ctypes.c_int64)]
+                ("gn_part", ctypes.c_void_p), ("gn_ld", ctypes.c_int64), ("upsample2x", ctypes.c_int32), ("_pad3", ctypes.c_int32)]
 
 
 class RawSeg(ctypes.Structure):
@@ -68,11 +60,11 @@ class RawQuant(ctypes.Structure):
 EPI_LINEAR, EPI_GEGLU_I8, EPI_HEADS_I8, EPI_HEADS_T_I8 = 0, 1, 2, 3
 
 
-EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_make_qparams", "qd_quantize_act", "qd_pack_weights", "qd_pack_weights_t4",
+EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_box_probe", "qd_make_qparams", "qd_quantize_act", "qd_pack_weights", "qd_pack_weights_t4",
            "qd_pack_weights_t8",
            "qd_conv2d_i8", "qd_conv2d_i8_splitk_ws_bytes",
            "qd_conv2d_i8_acc", "qd_groupnorm_ws_bytes", "qd_groupnorm_silu_quant", "qd_groupnorm_mod_silu_quant", "qd_layernorm_quant",
-           "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8", "qd_attn_keyterm", "qd_attn_uses_keyterm", "qd_attn_config", "qd_attn_sync", "qd_bmm_qk_i8", "qd_bmm_pv_i8", "qd_temb_mlp",
+           "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8", "qd_attn_keyterm", "qd_attn_uses_keyterm", "qd_attn_config", "qd_attn_ws_bytes", "qd_bmm_qk_i8", "qd_bmm_pv_i8", "qd_temb_mlp",
            "qd_fakequant_blocks", "qd_fakequant_fwd", "qd_fakequant_bwd",
            "qd_conv2d_bf16", "qd_pack_weights_bf16_bytes", "qd_pack_weights_bf16", "qd_groupnorm_silu_bf16",
            "qd_pack_weights_h16", "qd_groupnorm_silu_h16"]
@@ -113,7 +105,7 @@ def load():
     lib.qd_quantize_heads.argtypes = [vp, i32, i32, i32, i32, i32, i64, i64, i64, i64, f32, vp, i32, i32, i32, i32,
                                       vp, vp, i32, i32, vp]
     lib.qd_attn_i8.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp,
-                               i64, vp, i64, vp, i32, i32, i32, vp]
+                               i64, vp, i64, vp, i32, i32, i32, vp, i64, vp]
     lib.qd_attn_keyterm.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     lib.qd_attn_uses_keyterm.argtypes = [i32, i32, i32]
     lib.qd_attn_config.argtypes = [i32, i32, i32, i32]
@@ -132,13 +124,11 @@ def load():
     lib.qd_groupnorm_silu_bf16.argtypes = [vp, i64, i64, i32, i64, i32, f32, vp, vp, i32, vp, i64, vp, vp, i32, i64, vp]
     lib.qd_pack_weights_h16.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     lib.qd_groupnorm_silu_h16.argtypes = [vp, i64, i64, i32, i64, i32, f32, vp, vp, i32, i32, vp, i64, vp, vp, i32, i64, vp]
-    ver = lib.qd_abi_version()
-    # QDIFF_HIP_LIB may name an older build for A/B measurements (v18 = round 4: everything but qd_attn_sync)
-    if ver != 19 and not (ver == 18 and os.environ.get("QDIFF_HIP_LIB")):
+    lib.qd_box_probe.argtypes = [i32, i32, i32, vp, vp, vp]
+    lib.qd_attn_ws_bytes.argtypes = [i32, i32, i32, i32]
+    lib.qd_attn_ws_bytes.restype = ctypes.c_int64
+    if lib.qd_abi_version() != 20:
         raise HipEngineError("libqdiff_hip.so ABI version mismatch")
-    if ver >= 19:
-        lib.qd_attn_sync.argtypes = [i32]
-        lib.qd_attn_sync.restype = None
     _lib = lib
     return lib
 
@@ -240,7 +230,7 @@ class ConvCall:
     """Python-side description of one qd_conv2d_i8 launch (tensors, not pointers)."""
     __slots__ = ("x", "w", "out", "bias", "rowbias", "residual", "ldx", "ldk", "ldo", "ldr", "ld_rowbias",
                  "B", "H", "W", "Ho", "Wo", "Cout", "kh", "kw", "stride", "pad_t", "pad_l", "wbits", "w_tiled", "segs",
-                 "epilogue", "oq_params", "oq_grid", "splitk", "heads", "gn_part", "upsample2x", "ln", "_keep")
+                 "epilogue", "oq_params", "oq_grid", "splitk", "heads", "gn_part", "upsample2x", "_keep")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -308,16 +298,6 @@ def _conv_desc(c):
     if c.gn_part is not None:
         d.gn_ld = part_ld(c.gn_part)
     d.upsample2x = 1 if c.upsample2x else 0
-    if c.ln is not None:
-        # c.ln: dict(gamma, beta, eps, qparams=[float[4] device tensors], grids=[Grid], outs=[int8 rows], ldo)
-        L = LnFuse()
-        L.gamma, L.beta, L.eps, L.nout = _ptr(c.ln["gamma"], "ln gamma"), _ptr(c.ln["beta"], "ln beta"), float(c.ln["eps"]), len(c.ln["outs"])
-        qps = [_qp(q) for q in c.ln["qparams"]]
-        for i, (q, g, o) in enumerate(zip(qps, c.ln["grids"], c.ln["outs"])):
-            L.qparams[i], L.qmin[i], L.qmax[i], L.off[i], L.out[i] = _ptr(q, "ln qparams"), g.qmin, g.qmax, g.off, _ptr(o, "ln out")
-        L.ldo = int(c.ln["ldo"])
-        c._keep = (L, qps)                          # the struct and the completed qparams must outlive the launch call
-        d.ln = ctypes.addressof(L)
     d.nseg = len(c.segs)
     for i, s in enumerate(c.segs):
         g = d.seg[i]
@@ -482,10 +462,23 @@ def attn_keyterm(k, BH, Spad, dpad, prm, kterm=None):
     return kterm
 
 
-def attn_config(pipe_mode=-1, xcd=-1, ktab=-1, lean=-1, sync=-1):
+def attn_config(pipe_mode=-1, xcd=-1, ktab=-1, lean=-1):
     load().qd_attn_config(int(pipe_mode), int(xcd), int(ktab), int(lean))
-    if sync in (1, 2):
-        load().qd_attn_sync(int(sync))
+
+
+_ATTN_WS = {}            # (device, stream) -> scratch of the three-launch attention path (grows; old buffers stay alive for captured graphs)
+
+
+def attn_workspace(device, BH, T, S, d):
+    """Stream-ordered scratch for qd_attn_i8 (per-query statistics + per-block flags of the LDS-staged path), or None when the
+    shape runs on a one-kernel path.  One buffer per (device, stream): calls on a stream are ordered, each consumes what it wrote."""
+    need = int(load().qd_attn_ws_bytes(int(BH), int(T), int(S), int(d)))
+    if need == 0:
+        return None
+    bufs = _ATTN_WS.setdefault((device, _stream()), [])
+    if not bufs or bufs[-1].numel() < need:
+        bufs.append(torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device))
+    return bufs[-1]
 
 
 def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, wmax, q_asym, out, ldo,
@@ -497,10 +490,12 @@ def attn_i8(q, k, vt, vsum, BH, H, T, S, d, Tpad, Spad, dpad, prm, wbits, wmin, 
     g = oq_grid
     if kterm is None and attn_uses_keyterm(d, S, q_asym):
         kterm = attn_keyterm(k, BH, Spad, dpad, prm)
+    ws = attn_workspace(q.device, BH, T, S, d)
     _check(load().qd_attn_i8(_ptr(q), _ptr(k), _ptr(vt), None, _ptr(kterm), _ptr(vsum), BH, H, T, S, d, Tpad, Spad,
                              dpad, _ptr(prm), wbits, wmin, wmax, 1 if q_asym else 0, _ptr(out), ldo,
                              _ptr(out8), out8.stride(0) if out8 is not None else 0, _ptr(_qp(oq_params)),
-                             g.qmin if g else 0, g.qmax if g else 0, g.off if g else 0, _stream()), "qd_attn_i8")
+                             g.qmin if g else 0, g.qmax if g else 0, g.off if g else 0,
+                             _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "qd_attn_i8")
 
 
 def bmm_qk_i8(q8, k8, BH, T, S, d, Tpad, Spad, dpad, prm, out):
@@ -530,6 +525,20 @@ def fakequant_bwd(x, gy, delta, zero_point, qmin, qmax):
     _check(load().qd_fakequant_bwd(_ptr(x, "x"), _ptr(gy, "gy"), x.numel(), _ptr(delta, "delta"), _ptr(zero_point, "zero_point"),
                                    int(qmin), int(qmax), _ptr(gx), _ptr(part), _stream()), "qd_fakequant_bwd")
     return gx, part.sum()
+
+
+def box_probe(device, kind, blocks, iters):
+    """qd_box_probe timed with HIP events: (milliseconds, mean shader-clock ticks of the blocks' first waves)."""
+    ticks = torch.zeros(blocks, dtype=torch.int64, device=device)
+    sink = torch.zeros(1, dtype=torch.int32, device=device)
+    _check(load().qd_box_probe(kind, blocks, 16, _ptr(ticks), _ptr(sink), _stream()), "qd_box_probe")     # warm-up (code load, clocks)
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _check(load().qd_box_probe(kind, blocks, iters, _ptr(ticks), _ptr(sink), _stream()), "qd_box_probe")
+    e1.record()
+    torch.cuda.synchronize(device)
+    return e0.elapsed_time(e1), float(ticks.double().mean())
 
 
 class _TembLayer(ctypes.Structure):

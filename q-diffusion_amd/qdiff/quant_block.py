@@ -143,37 +143,21 @@ def _gn_silu_to(conv, rows, B, S, C, gn, silu=True, raw_plan=None, mod=None):
 
 
 def _ln_to(consumers, rows, M, C, ln):
-    """LayerNorm -> one int8 copy per consumer QuantModule.  When the Linear that produced `rows` already normalised and
-    quantised them in its epilogue for exactly these consumers (engine.conv_forward(ln=...), `rows.qd_ln`), those rows are
-    returned and no kernel runs."""
+    """LayerNorm -> one int8 copy per consumer QuantModule."""
     if not all(m.act_quantizer.inited for m in consumers):
         y = F.layer_norm(rows.float(), (C,), ln.weight, ln.bias, ln.eps)
         for m in consumers:
             m._init_act_quantizers(y)
-    plans = [m.conv_plan() for m in consumers]
-    fused = getattr(rows, "qd_ln", None)
-    if fused is not None and fused[0] is ln and len(fused[1]) == len(plans) and all(a is b for a, b in zip(fused[1], plans)):
-        return list(fused[2])
-    return engine.layernorm_quant(rows, M, C, ln, plans)
+    return engine.layernorm_quant(rows, M, C, ln, [m.conv_plan() for m in consumers])
 
 
-def _ln_fuse(producer, ln, consumers):
-    """(ln, consumer plans) for engine.conv_forward(ln=...) when the Linear `producer` can run LayerNorm `ln` and the
-    consumers' activation quantisers in its own epilogue (qd_ln_fuse: the 320-channel level), else None."""
-    if not (engine.LN_FUSE and isinstance(producer, QuantModule) and not producer.split
-            and all(isinstance(m, QuantModule) and not m.split and m.act_quantizer.inited for m in consumers) and _int_mode(producer, *consumers)):
-        return None
-    plans = [m.conv_plan() for m in consumers]
-    return (ln, plans) if engine.ln_fusable(producer.conv_plan(), ln, plans) else None
-
-
-def _linear_rows(lin, rows, residual=None, gn_stats=False, slot=None, ln=None):
+def _linear_rows(lin, rows, residual=None, gn_stats=False, slot=None):
     """QuantModule linear on float rows [M,K] -> [M,N] (quantise + integer GEMM)."""
     lin._init_act_quantizers(rows)
     plan = lin.conv_plan()
     M, K = rows.shape
     xq = engine.quantize_rows(rows, plan, 1, K, M, (0, rows.stride(1), rows.stride(0)))
-    return engine.conv_forward(plan, xq, 1, 1, M, 1, M, residual=residual, gn_stats=gn_stats, slot=slot, ln=ln)
+    return engine.conv_forward(plan, xq, 1, 1, M, 1, M, residual=residual, gn_stats=gn_stats, slot=slot)
 
 
 # A/B knob for measurements only (tools/r02_ab.sh): "0" evaluates the embedding projections layer by layer
@@ -957,10 +941,9 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
         x = self.attn2(self.norm2(x), context=context) + x
         return self.ff(self.norm3(x)) + x
 
-    def _attn_int(self, att, rows, B, T, C, ln, ctx_rows, S, kv=None, pre_attention=None, next_ln=None):
+    def _attn_int(self, att, rows, B, T, C, ln, ctx_rows, S, kv=None, pre_attention=None):
         """norm -> q/k/v projections -> fused quantised attention -> to_out (+ residual rows).
-        kv: (k8, v8, vsum, kterm) prepared ahead of time for this block's context (ContextKV), else they are computed here.
-        next_ln: (LayerNorm, [consumer QuantModules]) of the NEXT sub-layer: where to_out can run them in its epilogue it does."""
+        kv: (k8, v8, vsum, kterm) prepared ahead of time for this block's context (ContextKV), else they are computed here."""
         h = att.heads
         ap = self._attn_plan(att, float(att.scale), 1.0, rows.device)
         if ctx_rows is None:
@@ -997,28 +980,23 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
         if pre_attention is not None:
             pre_attention()                     # the next launch on this stream is the attention kernel
         out_lin = att.to_out[0]
-        lnf = _ln_fuse(out_lin, next_ln[0], next_ln[1]) if next_ln is not None and out_lin.act_quantizer.inited else None
         if out_lin.act_quantizer.inited and out_lin.conv_plan().ldx == inner and len(out_lin.conv_plan().segs) == 1:
             # the attention epilogue quantises its output for to_out[0]: no fp32 round trip
             o8 = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, h, d, out_plan=out_lin.conv_plan(), kterm=kterm)
-            return out_lin.forward_codes(o8, 1, 1, B * T, residual=rows, ln=lnf)
+            return out_lin.forward_codes(o8, 1, 1, B * T, residual=rows)
         o = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, h, d, kterm=kterm)
-        return _linear_rows(out_lin, o, residual=rows, ln=lnf)
+        return _linear_rows(out_lin, o, residual=rows)
 
     def _forward_int(self, x, context, out_plan=None):
         B, T, C = x.shape
         rows = x.reshape(B * T, C)
         if rows.stride(1) != 1 or rows.stride(0) != C:
             rows = rows.contiguous()
-        elif getattr(x, "qd_ln", None) is not None:
-            rows.qd_ln = x.qd_ln                   # norm1 ran in the epilogue of the Linear that produced x (SpatialTransformer.proj_in)
         grp = self.__dict__.get("_ctx_group")
         fork = (lambda: grp.start(context)) if (grp is not None and context is not None and _CTX_FORK == "attn") else None
-        ln2 = (self.norm2, [self.attn2.to_q] if context is not None else [self.attn2.to_q, self.attn2.to_k, self.attn2.to_v])
-        ln3 = (self.norm3, [self.ff.net[0].proj])
-        rows = self._attn_int(self.attn1, rows, B, T, C, self.norm1, None, T, pre_attention=fork, next_ln=ln2)
+        rows = self._attn_int(self.attn1, rows, B, T, C, self.norm1, None, T, pre_attention=fork)
         if context is None:
-            rows = self._attn_int(self.attn2, rows, B, T, C, self.norm2, None, T, next_ln=ln3)
+            rows = self._attn_int(self.attn2, rows, B, T, C, self.norm2, None, T)
         else:
             S = context.shape[1]
             kv = grp.get(self, context) if grp is not None else None
@@ -1027,7 +1005,7 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
                 ctx = context.reshape(B * S, context.shape[2]).float()
                 if ctx.stride(1) != 1:
                     ctx = ctx.contiguous()
-            rows = self._attn_int(self.attn2, rows, B, T, C, self.norm2, ctx if kv is None else rows, S, kv=kv, next_ln=ln3)
+            rows = self._attn_int(self.attn2, rows, B, T, C, self.norm2, ctx if kv is None else rows, S, kv=kv)
         return self._ff_int(rows, B, T, C, out_plan)
 
     def _ff_int(self, rows, B, T, C, out_plan=None):

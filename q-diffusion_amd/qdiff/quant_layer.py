@@ -605,11 +605,11 @@ class QuantModule(nn.Module):
         return cache[1]
 
     def forward_codes(self, xq, B, H, W, Ho=None, Wo=None, rowbias=None, residual=None, pad_tl=None, gn_stats=False, slot=None,
-                      upsample2x=False, ln=None):
+                      upsample2x=False):
         """Integer path for a producer that already emitted this module's int8 rows (fused blocks).
         slot: engine.CatSlot side that receives the output (a planned skip concatenation), see engine.conv_forward."""
         return engine.conv_forward(self.conv_plan(), xq, B, H, W, Ho, Wo, rowbias=rowbias, residual=residual,
-                                   pad_tl=pad_tl, gn_stats=gn_stats, slot=slot, upsample2x=upsample2x, ln=ln)
+                                   pad_tl=pad_tl, gn_stats=gn_stats, slot=slot, upsample2x=upsample2x)
 
     # -- forward ------------------------------------------------------------------------------
     qd_takes_out_slot = True

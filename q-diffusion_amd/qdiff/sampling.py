@@ -499,6 +499,24 @@ def sharded_noise(shape, seed, world_size, rank, device, stream_id=0):
     return full[lo:hi].to(device)
 
 
+class ShardedStepNoise:
+    """Per-step noise of an eta > 0 sampler, sharded.  The reference draws `noise_like(x.shape, device)` = randn of the WHOLE
+    batch on the device at every step (ddim.py:216, plms.py:216, denoising.py:29); a batch-sharded run reproduces its samples
+    only if every rank draws the full-batch tensor from the same generator state and keeps its slice — the
+    draw is a Philox kernel on the device, so the ranks pay the full batch's random numbers, not a broadcast.  Usable as the
+    `noise_fn` of ddim_sample / generalized_steps."""
+
+    def __init__(self, global_batch, sample_shape, seed, world_size, rank, device):
+        self.shape = (int(global_batch),) + tuple(sample_shape)
+        self.lo, self.hi = shard_bounds(int(global_batch), world_size, rank)
+        self.device = torch.device(device)
+        self.gen = torch.Generator(device=self.device).manual_seed(int(seed))
+
+    def __call__(self, step=None, shape=None):
+        full = torch.randn(self.shape, device=self.device, generator=self.gen)
+        return full[self.lo:self.hi]
+
+
 def _flatten_tensors(obj, out):
     """Replace every tensor of a nested dict / list by a placeholder and collect the tensors in traversal order."""
     if torch.is_tensor(obj):

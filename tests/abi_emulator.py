@@ -199,10 +199,6 @@ def conv2d_i8(c, acc_out=None):
             hd["sum"] += rsum                                    # the kernel accumulates atomically into a zeroed buffer
         return
     c.out[:, :c.Cout] = rows.to(c.out.dtype)
-    if getattr(c, "ln", None) is not None:                       # qd_ln_fuse: LayerNorm of the STORED rows + the consumers' quantisers
-        L = c.ln
-        layernorm_quant(c.out[:, :c.Cout], rows.shape[0], c.Cout, c.out.stride(0), L["eps"], L["gamma"], L["beta"], L["qparams"], L["grids"],
-                        L["outs"], L["ldo"])
     if getattr(c, "gn_part", None) is not None:                  # first level of GroupNorm statistics, 128-row chunks
         ch = c.out[:, :c.Cout].float().reshape(-1, 128, c.Cout)
         c.gn_part.copy_(torch.stack([ch.sum(1), (ch * ch).sum(1)], dim=-1).view(c.gn_part.shape))   # may be a column range (gn_ld)

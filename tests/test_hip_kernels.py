@@ -703,49 +703,6 @@ def test_layernorm_fp16_rows_16_byte_lanes(cuda, M, C):
         assert mx <= 1 and frac <= 1e-3
 
 
-@pytest.mark.parametrize("M,K,nout,res,dt", [(512, 320, 1, True, torch.float32), (4096, 320, 3, False, torch.float32), (200, 1280, 1, True, torch.float32),
-                                             (512, 320, 3, True, torch.float16), (1000, 640, 1, False, torch.float16)])
-def test_layernorm_in_the_epilogue(cuda, M, K, nout, res, dt):
-    """qd_ln_fuse: the 320-wide Linear that layer-normalises and quantises its own output rows (O_LN of igemm_dma.hip) against
-    the same Linear followed by qd_layernorm_quant (ln_quant_rows8_kernel: the same reduction order) — rows and codes bit for
-    bit, fp32 and fp16 stream, with and without residual, one and three quantisers, ragged row counts."""
-    from qdiff import engine, hip
-    g = torch.Generator().manual_seed(91)
-    N = 320
-    x = torch.randn(M, K, generator=g)
-    w = torch.randn(N, K, generator=g) * 0.05
-    q = _weight_quantizer(w, 4, True, g)
-    dx, zx = R.uaq_init_scale(x, 8, False, False, "max")
-    plan = engine.build_conv_plan(engine.pack_module_weights(w.to(cuda), [q], 0), [_aq(dx, zx)], 1, 1, 1, 0, torch.randn(N, generator=g).to(cuda))
-    xq = engine.quantize_rows(x.to(cuda), plan, 1, K, M, (0, 1, K))
-    residual = (torch.randn(M, N, generator=g) * 2).to(cuda).to(dt) if res else None
-    ln = torch.nn.LayerNorm(N).to(cuda)
-    with torch.no_grad():
-        ln.weight.copy_(torch.randn(N, generator=g))
-        ln.bias.copy_(torch.randn(N, generator=g))
-    cons = []
-    for i in range(nout):
-        wc = torch.randn(64, N, generator=g) * 0.05
-        cons.append(engine.build_conv_plan(engine.pack_module_weights(wc.to(cuda), [_weight_quantizer(wc, 4, True, g)], 0),
-                                           [_aq(torch.tensor(0.02 + 0.01 * i), 120 + 5 * i)], 1, 1, 1, 0, None))
-    assert engine.ln_fusable(plan, ln, cons)
-    plain = engine.conv_forward(plan, xq, 1, 1, M, residual=residual, out_dtype=dt, splitk=False)
-    want = engine.layernorm_quant(plain, M, N, ln, cons)
-    fused = engine.conv_forward(plan, xq, 1, 1, M, residual=residual, out_dtype=dt, ln=(ln, cons))
-    torch.cuda.synchronize()
-    assert fused.dtype == dt and torch.equal(fused, plain)
-    mod, plans, rows = fused.qd_ln
-    assert mod is ln and len(rows) == nout
-    for a, b in zip(rows, want):
-        assert torch.equal(a, b) and a.float().abs().max() > 0
-    # and against torch on the stored rows: the bound of test_layernorm_quant_three_consumers
-    y = torch.nn.functional.layer_norm(plain.float(), (N,), ln.weight, ln.bias, ln.eps).cpu()
-    for a, p_ in zip(rows, cons):
-        qp = p_.qparams[0].cpu()
-        mx, frac = _code_mismatch(a.cpu()[:, :N], R.uaq_codes(y, qp[0], int(qp[1]), 8, False) - 128)
-        assert mx <= 1 and frac <= 1e-3
-
-
 def test_linear_to_rows_with_fp16_residual(cuda):
     """QD_EPI_HEADS_I8 ("Linear + residual -> the next Linear's int8 rows") with the residual stored as halves: the same
     bytes as with the residual widened to fp32 first."""
@@ -827,19 +784,19 @@ def test_attention_lds_equals_lean(cuda, case):
     from qdiff import hip
     outs = {}
     try:
-        # pipe 0: attn_lean_kernel, 3: attn_lds_kernel on every eligible shape; ktab 1: per-key zero-point term from the
-        # qd_attn_keyterm table (accumulator seeds), 0: from constant-operand MFMAs — the accumulators hold the same integers
-        # sync (round 5): tiles per block-wide rendezvous of the LDS-staged kernel — 1 = one barrier per tile (4-stage ring),
-        # 2 = one per two tiles (8-stage ring, two tiles prefetched per meeting): the same arithmetic in the same order
-        for mode, sync in ((0, 2), (3, 1), (3, 2)):
+        # pipe 0: attn_lean_kernel (register-fed, one kernel), 3: the LDS-staged path on every eligible shape — three launches
+        # since round 6: statistics, lo-only P.V, hi + lo P.V (every block runs in exactly one of the two); ktab 1: per-key
+        # zero-point term from the qd_attn_keyterm table (accumulator seeds), 0: from constant-operand MFMAs (the register-fed
+        # kernel in both modes) — the accumulators hold the same integers
+        for mode in (0, 3):
             for ktab in (1, 0):
-                hip.attn_config(pipe_mode=mode, ktab=ktab, lean=3 if d >= 64 else 1, sync=sync)
+                hip.attn_config(pipe_mode=mode, ktab=ktab, lean=3 if d >= 64 else 1)
                 o = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d)
                 torch.cuda.synchronize()
-                outs[(mode, sync, ktab)] = o.clone()
+                outs[(mode, ktab)] = o.clone()
     finally:
-        hip.attn_config(pipe_mode=2, ktab=1, lean=1, sync=1)
-    ref = outs[(0, 2, 1)]
+        hip.attn_config(pipe_mode=2, ktab=1, lean=1)
+    ref = outs[(0, 1)]
     assert torch.isfinite(ref).all() and ref.abs().max() > 0
     for key, o in outs.items():
         assert torch.equal(ref, o), (key, (ref - o).abs().max().item())

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     from qdiff import hip
     assert sorted(hip.EXPORTS) == declared
     lib.qd_abi_version.restype = ctypes.c_int
-    assert lib.qd_abi_version() == 19
+    assert lib.qd_abi_version() == 20
     assert lib.qd_device_ok() in (0, 1)                  # no compute calls without a GPU
 
 
@@ -42,8 +42,7 @@ def test_conv_desc_layout_matches_header():
     """ctypes mirror of qd_conv_desc / qd_conv_seg has the C layout (sizes from the header's field list)."""
     from qdiff import hip
     assert ctypes.sizeof(hip.ConvSeg) == 4 * 4 + 6 * 8
-    assert ctypes.sizeof(hip.ConvDesc) == 6 * 8 + 5 * 8 + 16 * 4 + 2 * ctypes.sizeof(hip.ConvSeg) + 8 + 4 * 4 + 16 + 5 * 4 + 4 + 8 + 8 + 8 + 8 + 8
-    assert ctypes.sizeof(hip.LnFuse) == 2 * 8 + 4 + 4 + 3 * 8 + 9 * 4 + 4 + 3 * 8 + 8
+    assert ctypes.sizeof(hip.ConvDesc) == 6 * 8 + 5 * 8 + 16 * 4 + 2 * ctypes.sizeof(hip.ConvSeg) + 8 + 4 * 4 + 16 + 5 * 4 + 4 + 8 + 8 + 8 + 8
     assert ctypes.sizeof(hip.RawSeg) == 6 * 4 + 8 and ctypes.sizeof(hip.RawQuant) == 8 + 8 + 4 + 4 + 2 * ctypes.sizeof(hip.RawSeg)
 
 
@@ -61,10 +60,7 @@ def test_conv_desc_offsets_match_the_compiled_header(tmp_path):
         lines.append(f'printf("seg.{name} %zu\\n", offsetof(qd_conv_seg, {name}));')
     for name, _ in hip.ConvDesc._fields_:
         lines.append(f'printf("desc.{name} %zu\\n", offsetof(qd_conv_desc, {name}));')
-    lines += ['printf("qd_raw_seg %zu\\n", sizeof(qd_raw_seg));', 'printf("qd_raw_quant %zu\\n", sizeof(qd_raw_quant));',
-              'printf("qd_ln_fuse %zu\\n", sizeof(qd_ln_fuse));']
-    for name, _ in hip.LnFuse._fields_:
-        lines.append(f'printf("ln.{name} %zu\\n", offsetof(qd_ln_fuse, {name}));')
+    lines += ['printf("qd_raw_seg %zu\\n", sizeof(qd_raw_seg));', 'printf("qd_raw_quant %zu\\n", sizeof(qd_raw_quant));']
     for name, _ in hip.RawSeg._fields_:
         lines.append(f'printf("rseg.{name} %zu\\n", offsetof(qd_raw_seg, {name}));')
     for name, _ in hip.RawQuant._fields_:
@@ -86,9 +82,6 @@ def test_conv_desc_offsets_match_the_compiled_header(tmp_path):
         assert int(got[f"rseg.{name}"]) == getattr(hip.RawSeg, name).offset, name
     for name, _ in hip.RawQuant._fields_:
         assert int(got[f"raw.{name}"]) == getattr(hip.RawQuant, name).offset, name
-    assert int(got["qd_ln_fuse"]) == ctypes.sizeof(hip.LnFuse)
-    for name, _ in hip.LnFuse._fields_:
-        assert int(got[f"ln.{name}"]) == getattr(hip.LnFuse, name).offset, name
 
 
 def test_ctypes_signatures_match_the_header_prototypes():
@@ -599,43 +592,6 @@ def test_prepared_context_skips_the_chain_and_changes_nothing(emu, monkeypatch):
         got = sampling.plms_sample(qnn, x, table, cond=c, uncond=uc, scale=3.0)
         assert torch.equal(got, ref)
         assert calls["heads"] == 5 * prepared + 2 * nblk, calls
-
-
-def test_layernorm_in_the_producing_epilogue_changes_nothing(emu, monkeypatch):
-    """qd_ln_fuse (round 5): where a Linear's tile owns whole rows, LayerNorm and the next sub-layer's activation quantiser(s) run
-    in its epilogue — norm1 + to_q / to_k / to_v behind SpatialTransformer.proj_in, norm2 + to_q behind attn1.to_out, norm3 + the
-    GEGLU projection behind attn2.to_out (attention.py:229-231).  Host logic on the emulator (any width is "fusable" here; the
-    HIP kernel is built for 320 channels): every LayerNorm of every transformer block is served by its producer, no
-    qd_layernorm_quant launch is left, and the output is the unfused one bit for bit."""
-    from qdiff import engine, hip
-    fx = load_fixture("model_sd_tiny.pt")
-    qnn = _resume_cpu(fx)
-    x, t, c = fixture_inputs(fx, "test")
-    calls = {"ln": 0, "fused": 0}
-    real_ln, real_conv = hip.layernorm_quant, hip.conv2d_i8
-
-    def counting_ln(*a, **k):
-        calls["ln"] += 1
-        return real_ln(*a, **k)
-
-    def counting_conv(cc, acc_out=None):
-        calls["fused"] += cc.ln is not None
-        return real_conv(cc, acc_out)
-    monkeypatch.setattr(hip, "layernorm_quant", counting_ln)
-    monkeypatch.setattr(hip, "conv2d_i8", counting_conv)
-    monkeypatch.setattr(engine, "LN_FUSE", False)
-    with torch.no_grad():
-        want = qnn(x, t, c)
-    n_ln = calls["ln"]
-    assert n_ln > 0 and calls["fused"] == 0
-    monkeypatch.setattr(engine, "LN_FUSE", True)
-    monkeypatch.setattr(engine, "ln_fusable", lambda plan, ln, cons: bool(len(plan.segs) == 1 and tuple(ln.normalized_shape) == (plan.Cout,)
-                                                                          and all(len(p.segs) == 1 and p.ldx == cons[0].ldx for p in cons)))
-    calls.update(ln=0, fused=0)
-    with torch.no_grad():
-        got = qnn(x, t, c)
-    assert torch.equal(got, want)
-    assert calls["ln"] == 0 and calls["fused"] == n_ln, calls
 
 
 def test_ldm_attention_block_qkv_as_three_operand_projections(emu, monkeypatch):
