@@ -183,6 +183,16 @@ typedef struct {
 
 int qd_conv2d_i8(const qd_conv_desc* d, void* stream);
 
+/* Grouped launch (ABI v20): n = 1..3 descriptors of ONE problem shape with head-layout epilogues (QD_EPI_HEADS_I8 / _T_I8) — the
+ * q / k / v projections of an attention block, which the reference evaluates as three Linears on the rows of one LayerNorm
+ * (qdiff/quant_block.py:193-199, ldm attention.py:174-182; the DDIM AttnBlock's q / k / v convolutions diffusion.py:142-144; the
+ * three row subsets of the LDM AttentionBlock's qkv conv1d, openaimodel.py:311-326) — as ONE launch whose grid's second
+ * dimension selects the descriptor: three 256-block launches (one wave per SIMD each) become one that fills the chip, two
+ * prologue ramps and two dependent-launch boundaries disappear.  Members that do not qualify (different shapes, another
+ * epilogue, a tile shape the group kernel is not built for) run as the n single launches of qd_conv2d_i8: the bytes written are
+ * the same either way. */
+int qd_conv2d_i8_group(const qd_conv_desc* const* descs, int n, void* stream);
+
 /* Scratch bytes qd_conv2d_i8 would use for a split-K contraction of this descriptor (shape fields only are
  * read); 0 when the layer is launched unsplit. */
 int64_t qd_conv2d_i8_splitk_ws_bytes(const qd_conv_desc* d);

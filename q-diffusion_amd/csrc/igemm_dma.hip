@@ -136,8 +136,22 @@ __device__ __forceinline__ constexpr int crow(int r) { return (r & 3) + 8 * (r >
 #ifndef QD_MT1_OCC
 #define QD_MT1_OCC 2      // waves per SIMD the 128-row tiles are compiled for (3 fits without spills; A/B knob of build.py)
 #endif
+// LDS bytes of one block: the 3-stage ring (re-used by the epilogue as per-wave transposition tiles + GroupNorm partials) + row
+// tables + per-channel constants
+template <int MT, int NT, int WM, int WN, int OUT, int WB>
+__host__ __device__ constexpr int igemm_smem_bytes() {
+    constexpr bool BF = WB >= 16;
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, NTB = NT * WN;
+    constexpr int TB = BF ? 2048 : 256 * WB;
+    constexpr int STAGE = BM * 64 + NTB * TB;
+    constexpr int TBW = ((OUT == O_F16 || OUT == O_HROWS) && !BF) ? 8192 : 4096;
+    constexpr int EPI_BYTES = 4 * TBW + 4 * (32 * NT) * 8;
+    constexpr int RING = 3 * STAGE > EPI_BYTES ? 3 * STAGE : EPI_BYTES;
+    return RING + 2 * BM * 4 + 4 * BN * 4;
+}
+
 template <int MT, int NT, int WM, int WN, bool SPLIT, int OUT, int WB>
-__global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <= 5 ? QD_MT1_OCC : 2)) void igemm_kernel(const ConvD p) {
+__device__ __forceinline__ void igemm_body(const ConvD& p, unsigned char* smem) {
     static_assert(WB == 4 || WB == 8 || WB == 16 || WB == 17, "weight bits (16 = bf16 mode, 17 = fp16 mode)");
     constexpr bool BF = WB >= 16;                 // the floating-point mode (either operand type: same bytes, same loop)
     constexpr bool FH = WB == 17;                 // ... on IEEE halves (v_mfma_f32_32x32x16_f16) instead of bf16
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
     constexpr int TBW = ((OUT == O_F16 || OUT == O_HROWS) && !BF) ? 8192 : 4096;
     constexpr int EPI_BYTES = 4 * TBW + 4 * WCOLS * 8;
     constexpr int RING = 3 * STAGE > EPI_BYTES ? 3 * STAGE : EPI_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[RING + 2 * BM * 4 + 4 * BN * 4];
+    static_assert(RING + 2 * BM * 4 + 4 * BN * 4 == igemm_smem_bytes<MT, NT, WM, WN, OUT, WB>(), "igemm_smem_bytes out of step with the body");
     int* sRowB = reinterpret_cast<int*>(smem + RING);
     int* sAsum = sRowB + BM;
     // per-output-channel epilogue constants of the LAST segment, fetched at kernel start so that their
@@ -1133,6 +1147,30 @@ __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <
     }
 }
 
+template <int MT, int NT, int WM, int WN, bool SPLIT, int OUT, int WB>
+__global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <= 5 ? QD_MT1_OCC : 2)) void igemm_kernel(const ConvD p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[igemm_smem_bytes<MT, NT, WM, WN, OUT, WB>()];
+    igemm_body<MT, NT, WM, WN, SPLIT, OUT, WB>(p, smem);
+}
+
+// Grouped launch of the q / k / v projections of one attention block (reference qdiff/quant_block.py:193-199: three Linears on
+// the rows of one LayerNorm): the SAME problem shape three times — member blockIdx.y runs its own descriptor (its own rows,
+// weights, quantiser, operand buffer), q and k with the head-row epilogue, v with the transposed one.  One launch fills the
+// chip where each of the three left it with one block per CU (256 blocks on 256 CUs: a single wave per SIMD), and two of the
+// three prologue ramps and dependent-launch boundaries disappear.  Same code per member as the single launch: same bytes.
+struct ConvG {
+    ConvD d[3];
+    int   out[3];             // O_HROWS / O_HTR per member
+};
+template <int MT, int NT, int WM, int WN, int WB>
+__global__ __launch_bounds__(256, (MT * NT > 10) ? 1 : (MT == 1 && NT <= 5 ? QD_MT1_OCC : 2)) void igemm_heads_group_kernel(const ConvG g) {
+    constexpr int SA = igemm_smem_bytes<MT, NT, WM, WN, O_HROWS, WB>(), SB = igemm_smem_bytes<MT, NT, WM, WN, O_HTR, WB>();
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SA > SB ? SA : SB];
+    const int z = blockIdx.y;
+    if (g.out[z] == O_HTR) igemm_body<MT, NT, WM, WN, false, O_HTR, WB>(g.d[z], smem);
+    else igemm_body<MT, NT, WM, WN, false, O_HROWS, WB>(g.d[z], smem);
+}
+
 // ---------------------------------------------------------------------------------------------
 // tile-ordered nibble packer: thread = one 8-byte unit (row n, 16 consecutive K)
 // ---------------------------------------------------------------------------------------------
@@ -1265,11 +1303,21 @@ template __global__ void igemm_kernel<QD_PROBE_INSTANCE>(const ConvD);
 }  // namespace
 #else
 // tile shapes (MT, NT, WM, WN): block = (32*MT*WM) x (32*NT*WN)
+// qd_conv2d_i8_group runs every member through run() — all its checks, its tile choice — with this set: dispatch() then
+// records the finished kernel descriptor and the tile it would have launched instead of launching.
+struct GroupCapture { ConvD k; int out, tile; bool split; };
+thread_local GroupCapture* g_capture = nullptr;
+constexpr int tile_code(int MT, int NT, int WM, int WN, int WB) { return (((MT * 16 + NT) * 8 + WM) * 8 + WN) * 32 + WB; }
+
 template <int MT, int NT, int WM, int WN, int WB = 4>
 int dispatch(ConvD& k, bool split, int out, hipStream_t st, int nsplit = 1) {
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     k.nblk_m = (k.M + BM - 1) / BM;
     k.nblk_n = (k.Cout + BN - 1) / BN;
+    if (g_capture) {
+        *g_capture = GroupCapture{k, out, nsplit == 1 ? tile_code(MT, NT, WM, WN, WB) : -1, split};
+        return 0;
+    }
     dim3 grid(k.nblk_m * k.nblk_n, nsplit), block(256);
 #define QD_CASE(SP, O)                                                                              \
     if (split == SP && out == O) {                                                                  \
@@ -1459,6 +1507,9 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
     // give every CU a block
     auto want_mt2 = [&](int bn) {
         if (split || !mt2_ok || out == O_I32) return false;
+        // members of a grouped launch take 128-row tiles: three times the blocks fill the chip anyway, and the smaller tile's
+        // epilogue tail is shorter (heads_i8_out 1.82 -> 1.74 ms per SD evaluation, profiles/r06_group_ab.md)
+        if (g_capture) return false;
         if (force_mt) return force_mt == 2;
         return Ktot >= mt2_mink && blocks(256, bn) >= 256;
     };
@@ -1618,6 +1669,54 @@ extern "C" int64_t qd_conv2d_i8_splitk_ws_bytes(const qd_conv_desc* d) {
     return S < 2 ? 0 : (int64_t)S * d->B * d->Ho * d->Wo * d->Cout * 4;
 }
 
+template <int MT, int NT, int WM, int WN, int WB>
+void launch_group(const ConvG& g, int n, hipStream_t st) {
+    dim3 grid(g.d[0].nblk_m * g.d[0].nblk_n, n), block(256);
+    hipLaunchKernelGGL((igemm_heads_group_kernel<MT, NT, WM, WN, WB>), grid, block, 0, st, g);
+}
+
+// Up to three projections of ONE shape with head-layout epilogues as one launch (see igemm_heads_group_kernel); whatever does
+// not qualify — different shapes / tiles, another epilogue, a tile the group kernel is not built for, QD_QKV_GROUP=0 — runs as
+// the n single launches it always was: same bytes either way.
+int run_group(const qd_conv_desc* const* descs, int n, void* stream) {
+    QD_REQUIRE(descs && n >= 1 && n <= 3, "qd_conv2d_i8_group: 1..3 descriptors");
+    static const bool enabled = !(getenv("QD_QKV_GROUP") && atoi(getenv("QD_QKV_GROUP")) == 0);      // A/B knob
+    GroupCapture cap[3];
+    bool ok = enabled && n >= 2;
+    for (int i = 0; i < n && ok; ++i) {
+        QD_REQUIRE(descs[i] != nullptr, "qd_conv2d_i8_group: null descriptor");
+        g_capture = &cap[i];
+        const int rc = run(descs[i], nullptr, stream);
+        g_capture = nullptr;
+        if (rc) return rc;
+        const ConvD &a = cap[i].k, &b = cap[0].k;
+        ok = cap[i].tile >= 0 && !cap[i].split && (cap[i].out == O_HROWS || cap[i].out == O_HTR) && cap[i].tile == cap[0].tile &&
+             a.M == b.M && a.Cout == b.Cout && a.nblk_m == b.nblk_m && a.nblk_n == b.nblk_n;
+    }
+    if (ok) {
+        ConvG g{};
+        for (int i = 0; i < n; ++i) { g.d[i] = cap[i].k; g.out[i] = cap[i].out; }
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        switch (cap[0].tile) {
+            case tile_code(1, 5, 4, 1, 4): launch_group<1, 5, 4, 1, 4>(g, n, st); break;
+            case tile_code(1, 7, 4, 1, 4): launch_group<1, 7, 4, 1, 4>(g, n, st); break;
+            case tile_code(1, 4, 4, 1, 4): launch_group<1, 4, 4, 1, 4>(g, n, st); break;
+            case tile_code(1, 4, 4, 1, 8): launch_group<1, 4, 4, 1, 8>(g, n, st); break;
+            default: ok = false; break;
+        }
+        if (ok) {
+            QD_LAUNCH_CHECK("qd_conv2d_i8_group");
+            return 0;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        const int rc = run(descs[i], nullptr, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int qd_conv2d_i8_group(const qd_conv_desc* const* descs, int n, void* stream) { return run_group(descs, n, stream); }
 extern "C" int qd_conv2d_i8(const qd_conv_desc* d, void* stream) { return run(d, nullptr, stream); }
 extern "C" int qd_conv2d_i8_acc(const qd_conv_desc* d, int32_t* iout, void* stream) {
     if (!iout) { qd_set_error("qd_conv2d_i8_acc: null iout"); return 1; }

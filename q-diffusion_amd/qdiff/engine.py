@@ -700,17 +700,26 @@ def heads_fusable(plan, T, H):
 def project_heads(plan, xq, B, T, H, ap, which, out8, vsum=None):
     """q (which=0) / k (1) / v (2) projection of B*T token rows `xq`, quantised with the attention block's
     own act quantiser inside the GEMM epilogue and stored in the operand layout of the attention kernel."""
+    hip.conv2d_i8(_heads_call(plan, xq, B, T, H, ap, which, out8, vsum))
+
+
+def project_heads_group(members, B, T, H, ap, vsum=None):
+    """The q / k / v projections of one attention block — members: [(plan, xq, which, out8), ...], all heads_fusable, on the
+    same B*T rows — as ONE launch where the library can group them (hip.conv2d_i8_group), else one launch each: same bytes."""
+    hip.conv2d_i8_group([_heads_call(plan, xq, B, T, H, ap, which, out8, vsum) for plan, xq, which, out8 in members])
+
+
+def _heads_call(plan, xq, B, T, H, ap, which, out8, vsum):
     d = plan.Cout // H
     if which == 2:
         _vsum_prepare(vsum)
-    call = hip.ConvCall(x=xq, w=plan.pack.wq, out=out8, bias=plan.bias, ldx=plan.ldx, ldk=plan.pack.ldk, ldo=0,
+    return hip.ConvCall(x=xq, w=plan.pack.wq, out=out8, bias=plan.bias, ldx=plan.ldx, ldk=plan.pack.ldk, ldo=0,
                         B=B, H=1, W=T, Ho=1, Wo=T, Cout=plan.Cout, kh=1, kw=1, stride=1, pad_t=0, pad_l=0,
                         wbits=plan.pack.wbits, w_tiled=True, segs=plan.segs,
                         epilogue=hip.EPI_HEADS_T_I8 if which == 2 else hip.EPI_HEADS_I8,
                         oq_params=ap.qparams[which], oq_grid=ap.grids[which],
                         heads=dict(H=H, d=d, T=T, Tpad=pad32(T), dpad=pad32(d), sum=vsum,
                                    prescale=ap.prescale if which < 2 else 1.0))
-    hip.conv2d_i8(call)
 
 
 def rows_i8_fusable(plan, next_plan, T):

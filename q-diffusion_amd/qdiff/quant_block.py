@@ -852,8 +852,7 @@ class QuantAttentionBlock(BaseQuantBlock, _AttnQuant):
         ap = self._attn_plan(holder, 1.0, scale, x.device)
         q8, k8, v8, vsum = engine.head_buffers(x.device, B * nh, T, T, d)
         vsum = engine.vsum_slice(id(self), x.device, tuple(vsum.shape))
-        for which, (plan, buf) in enumerate(zip(plans, (q8, k8, v8))):
-            engine.project_heads(plan, xq, B, T, nh, ap, which, buf, vsum)
+        engine.project_heads_group([(plan, xq, which, buf) for which, (plan, buf) in enumerate(zip(plans, (q8, k8, v8)))], B, T, nh, ap, vsum)
         po = self.proj_out
         if po.act_quantizer.inited and po.split == 0 and po.conv_plan().ldx == C and len(po.conv_plan().segs) == 1:
             o8 = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, T, nh, d, out_plan=po.conv_plan())
@@ -973,10 +972,16 @@ class QuantBasicTransformerBlock(BaseQuantBlock, _AttnQuant):
             y = mod.forward_codes(codes, 1, 1, B * n_tok) if codes is not None else _linear_rows(mod, ctx_rows)
             engine.heads_from_float(ap, which, y, B, n_tok, h, d, (n_tok * inner, inner, d, 1), buf, vsum)
 
-        operand(att.to_q, xq, 0, T, q8)
-        if kv is None:
-            operand(att.to_k, xk, 1, S, k8)
-            operand(att.to_v, xv, 2, S, v8)
+        if (kv is None and ctx_rows is None
+                and all(engine.heads_fusable(m.conv_plan(), T, h) for m in (att.to_q, att.to_k, att.to_v))):
+            # self-attention: the three projections read rows of one LayerNorm and have one shape -> one grouped launch
+            engine.project_heads_group([(att.to_q.conv_plan(), xq, 0, q8), (att.to_k.conv_plan(), xk, 1, k8),
+                                        (att.to_v.conv_plan(), xv, 2, v8)], B, T, h, ap, vsum)
+        else:
+            operand(att.to_q, xq, 0, T, q8)
+            if kv is None:
+                operand(att.to_k, xk, 1, S, k8)
+                operand(att.to_v, xv, 2, S, v8)
         if pre_attention is not None:
             pre_attention()                     # the next launch on this stream is the attention kernel
         out_lin = att.to_out[0]
@@ -1152,9 +1157,9 @@ class QuantAttnBlock(BaseQuantBlock, _AttnQuant):
             if all(engine.heads_fusable(p, T, 1) and p.Cout == C for p in plans):
                 q8, k8, v8, vsum = engine.head_buffers(x.device, B, T, T, C)
                 vsum = engine.vsum_slice(id(self), x.device, tuple(vsum.shape))
-                for which, (plan, buf) in enumerate(zip(plans, (q8, k8, v8))):
-                    xq = engine.quantize_rows(y, plan, 1, C, B * T, (0, y.stride(1), y.stride(0)))
-                    engine.project_heads(plan, xq, B, T, 1, ap, which, buf, vsum)
+                members = [(plan, engine.quantize_rows(y, plan, 1, C, B * T, (0, y.stride(1), y.stride(0))), which, buf)
+                           for which, (plan, buf) in enumerate(zip(plans, (q8, k8, v8)))]
+                engine.project_heads_group(members, B, T, 1, ap, vsum)
                 if po.act_quantizer.inited and po.split == 0 and po.conv_plan().ldx == C and len(po.conv_plan().segs) == 1:
                     o8 = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, T, 1, C, out_plan=po.conv_plan())
                     out = po.forward_codes(o8, B, H, W, residual=rows, gn_stats=True, slot=out_slot)

@@ -204,6 +204,14 @@ def conv2d_i8(c, acc_out=None):
         c.gn_part.copy_(torch.stack([ch.sum(1), (ch * ch).sum(1)], dim=-1).view(c.gn_part.shape))   # may be a column range (gn_ld)
 
 
+def conv2d_i8_group(calls):
+    """qd_conv2d_i8_group: the members one after the other (what the grouped launch is defined to equal) — through
+    hip.conv2d_i8, so that a test's launch counter on that entry sees every member."""
+    from qdiff import hip
+    for c in calls:
+        hip.conv2d_i8(c)
+
+
 def groupnorm_ws_bytes(B, C, S):
     return 64
 
@@ -422,7 +430,7 @@ def groupnorm_silu_bf16(x, B, S, C, groups, eps, gamma, beta, silu, out, ws, par
 def install(monkeypatch):
     """Replace qdiff.hip's device entry points by the emulation (CPU tensors only)."""
     from qdiff import hip
-    for name in ("make_qparams", "quantize_act", "pack_weights", "pack_weights_t4", "pack_weights_t8", "conv2d_i8", "groupnorm_ws_bytes", "groupnorm_silu_quant",
+    for name in ("make_qparams", "quantize_act", "pack_weights", "pack_weights_t4", "pack_weights_t8", "conv2d_i8", "conv2d_i8_group", "groupnorm_ws_bytes", "groupnorm_silu_quant",
                  "layernorm_quant", "geglu_quant", "quantize_heads", "attn_i8", "attn_keyterm", "attn_uses_keyterm", "splitk_ws_bytes", "bmm_qk_i8", "bmm_pv_i8", "temb_mlp",
                  "pack_weights_bf16", "conv2d_bf16", "groupnorm_silu_bf16"):
         monkeypatch.setattr(hip, name, globals()[name])

@@ -236,7 +236,13 @@ def test_ldm_attention_qkv_operand_projections_on_gpu(cuda, name, monkeypatch, t
     def counting_qh(*a, **k):
         calls["float"] += 1
         return real_qh(*a, **k)
+    real_group = hip.conv2d_i8_group
+
+    def counting_group(ccs):                               # q / k / v as ONE grouped launch: three projections
+        calls["heads"] += sum(cc.epilogue in (hip.EPI_HEADS_I8, hip.EPI_HEADS_T_I8) and (cc.heads["H"] > 1 or cc.wbits == 8) for cc in ccs)
+        return real_group(ccs)
     monkeypatch.setattr(hip, "conv2d_i8", counting_conv)
+    monkeypatch.setattr(hip, "conv2d_i8_group", counting_group)
     monkeypatch.setattr(hip, "quantize_heads", counting_qh)
     qnn.enable_hip_graphs(False)
     monkeypatch.setattr(quant_block, "QKV_HEADS", False)

@@ -873,6 +873,30 @@ def _heads_epilogue_case(cuda, T, N, K, H, wbits):
         assert torch.equal(got, want), (which, (got != want).float().mean().item())
         if which == 2:
             assert torch.equal(gs, ws)
+    # round 6: the three projections as ONE grouped launch (qd_conv2d_i8_group; three different weight matrices and input rows,
+    # one shape) write exactly the bytes of three single launches — whichever tile the library picks, and also where it declines
+    # to group (tile not built for groups) and falls back to single launches
+    members, singles = [], []
+    vs_g = torch.full((B * H, dpad), 5, dtype=torch.int32, device=cuda)
+    vs_s = torch.full((B * H, dpad), 9, dtype=torch.int32, device=cuda)
+    for which in (0, 1, 2):
+        wi = torch.randn(N, K, generator=g) * 0.05
+        xi = torch.randn(B * T, K, generator=g)
+        pk = engine.pack_module_weights(wi.to(cuda), [_weight_quantizer(wi, wbits, True, g)], 0)
+        di, zi = R.uaq_init_scale(xi, 8, False, False, "max")
+        pl = engine.build_conv_plan(pk, [_aq(di, zi)], 1, 1, 1, 0, (torch.randn(N, generator=g) * 0.1).to(cuda))
+        xqi = engine.quantize_rows(xi.to(cuda), pl, 1, K, B * T, (0, 1, K))
+        shape = (B * H, dpad, Tpad) if which == 2 else (B * H, Tpad, dpad)
+        bg, bs = torch.zeros(shape, dtype=torch.int8, device=cuda), torch.zeros(shape, dtype=torch.int8, device=cuda)
+        members.append((pl, xqi, which, bg))
+        singles.append((pl, xqi, which, bs))
+    engine.project_heads_group(members, B, T, H, ap, vs_g)
+    for pl, xqi, which, bs in singles:
+        engine.project_heads(pl, xqi, B, T, H, ap, which, bs, vs_s)
+    torch.cuda.synchronize()
+    for (_, _, which, bg), (_, _, _, bs) in zip(members, singles):
+        assert torch.equal(bg, bs) and bg.float().abs().max() > 0, which
+    assert torch.equal(vs_g, vs_s)
 
 
 def test_attention_quantised_output_matches_quantise_rows(cuda):
