@@ -765,110 +765,26 @@ static int groupnorm_impl(const void* x, int x_dtype, int64_t B, int64_t S, int 
         hipLaunchKernelGGL(gn_partial_h8_kernel, dim3(nchunk, (unsigned)B), dim3(256), 0, st, (const __half*)x, (long)S, C, (long)ldx, part, nchunk);
     else
         hipLaunchKernelGGL(gn_partial_kernel<__half>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, (const __half*)x, (long)S, C, (long)ldx, part, nchunk, vec);
-    RawQ rq{};
-    if (raw && raw->out) {
-        QD_REQUIRE(raw->nseg == 1 || raw->nseg == 2, "qd_groupnorm_silu_quant: raw output takes 1 or 2 segments");
-        QD_REQUIRE(raw->ldo % 16 == 0 && qd_aligned(raw->out, 16), "qd_groupnorm_silu_quant: raw output rows must be 16-byte aligned");
-        rq.out = raw->out; rq.ldo = (long)raw->ldo; rq.nseg = raw->nseg;
-        for (int i = 0; i < raw->nseg; ++i) {
-            const auto& g = raw->seg[i];
-            QD_REQUIRE(g.qparams && g.c0 >= 0 && g.clen > 0 && g.c0 % 16 == 0 && g.clen % 16 == 0 && g.oc0 % 16 == 0 && g.c0 + g.clen <= C &&
-                       g.oc0 + g.clen <= raw->ldo, "qd_groupnorm_silu_quant: raw segment %d: c0 / clen / oc0 must be multiples of 16 inside the rows", i);
-            QD_REQUIRE(g.qmax - g.off <= 127 && g.qmin - g.off >= -128, "qd_groupnorm_silu_quant: raw segment %d grid does not fit int8", i);
-            QD_REQUIRE(i == 0 || g.c0 >= raw->seg[0].c0 + raw->seg[0].clen, "qd_groupnorm_silu_quant: raw segments must be ordered and disjoint");
-            rq.c0[i] = g.c0; rq.clen[i] = g.clen; rq.oc0[i] = g.oc0; rq.off[i] = g.off;
-            rq.qmin[i] = (float)g.qmin; rq.qmax[i] = (float)g.qmax; rq.qp[i] = g.qparams;
-        }
-    }
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, (unsigned)B), dim3(64), 0, st, part_in ? part_in : part, nchunk, ldp, (long)S, C, groups, eps, gamma, beta, ab);
-    const long rows = B * S, total = rows * (C / 8);
-    hipLaunchKernelGGL(gn_apply_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, rows, (long)S, C, (long)ldx, ab, apply_silu,
-                       reinterpret_cast<unsigned short*>(out), (long)ldo, out_dtype == QD_F16 ? 1 : 0);
-    QD_LAUNCH_CHECK("qd_groupnorm_silu_bf16");
-    return 0;
-}
-
-extern "C" int64_t qd_groupnorm_ws_bytes(int64_t B, int64_t C, int64_t S) {
-    int64_t nchunk = (S + gn_rows(S) - 1) / gn_rows(S);
-    return (B * nchunk * C * 2 + B * C * 2) * (int64_t)sizeof(float);
-}
-
-// finalise folded into the apply pass (default) or as its own launch (QD_GN_FUSE=0 / qd_groupnorm_config(0): A/B runs, the
-// equality test)
-static int& gn_fuse_knob() {
-    static int v = (getenv("QD_GN_FUSE") && atoi(getenv("QD_GN_FUSE")) == 0) ? 0 : 1;
-    return v;
-}
-extern "C" void qd_groupnorm_config(int fuse_finalize) {
-    if (fuse_finalize >= 0) gn_fuse_knob() = fuse_finalize ? 1 : 0;
-}
-
-static int groupnorm_impl(const void* x, int x_dtype, int64_t B, int64_t S, int C, int64_t ldx, int groups,
-                          float eps, const float* gamma, const float* beta, int apply_silu,
-                          const float* qparams, int qmin, int qmax, int off, int8_t* out, int64_t ldo,
-                          float* yout, int64_t ldy, void* ws, const float* part_in, int nchunk_in, int64_t part_ld, const qd_raw_quant* raw,
-                          const float* mod, int64_t mod_ld, void* stream) {
-    QD_REQUIRE(x && ws && (out || yout), "qd_groupnorm_silu_quant: null pointer");
-    QD_REQUIRE(!out || qparams, "qd_groupnorm_silu_quant: quantised output needs qparams");
-    QD_REQUIRE(x_dtype == QD_F32 || x_dtype == QD_F16, "qd_groupnorm_silu_quant: dtype must be f32/f16");
-    QD_REQUIRE(B > 0 && S > 0 && C > 0 && groups > 0 && C % groups == 0 && C % 16 == 0, "qd_groupnorm_silu_quant: C=%d must be a multiple of 16 and of groups=%d", C, groups);
-    QD_REQUIRE(ldx >= C && (!out || (ldo >= C && ldo % 16 == 0 && qd_aligned(out, 16))), "qd_groupnorm_silu_quant: bad leading dimensions");
-    QD_REQUIRE(B < 65536, "qd_groupnorm_silu_quant: batch too large");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int nchunk_own = (int)((S + gn_rows(S) - 1) / gn_rows(S));
-    const int vec = qd_aligned(x, x_dtype == QD_F32 ? 16 : 8) && ldx % 4 == 0;
-    // fp16 rows that take 16-byte (8-half) lanes; QD_F16_LINES=0 keeps the 4-halves-per-lane kernels (A/B knob)
-    static const bool f16_lines = !(getenv("QD_F16_LINES") && atoi(getenv("QD_F16_LINES")) == 0);
-    const bool vec8 = f16_lines && x_dtype == QD_F16 && qd_aligned(x, 16) && ldx % 8 == 0;      // C % 16 == 0 is required above
-    float* part = reinterpret_cast<float*>(ws);
-    float* ab = part + (size_t)B * nchunk_own * C * 2;
-    QD_REQUIRE(!part_in || (nchunk_in > 0 && (part_ld == 0 || part_ld >= C)), "qd_groupnorm_silu_quant: part_in needs nchunk_in > 0 and part_ld >= C");
-    const long ldp = part_in && part_ld ? (long)part_ld : (long)C;
-    const int nchunk = part_in ? nchunk_in : nchunk_own;
-    if (part_in) {
-        // first statistics level came with the tensor (written by the producing GEMM's epilogue)
-    } else if (x_dtype == QD_F32)
-        hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, (const float*)x, (long)S, C, (long)ldx, part, nchunk, vec);
-    else if (vec8)
-        hipLaunchKernelGGL(gn_partial_h8_kernel, dim3(nchunk, (unsigned)B), dim3(256), 0, st, (const __half*)x, (long)S, C, (long)ldx, part, nchunk);
-    else
-        hipLaunchKernelGGL(gn_partial_kernel<__half>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, (const __half*)x, (long)S, C, (long)ldx, part, nchunk, vec);
-    RawQ rq{};
-    if (raw && raw->out) {
-        QD_REQUIRE(raw->nseg == 1 || raw->nseg == 2, "qd_groupnorm_silu_quant: raw output takes 1 or 2 segments");
-        QD_REQUIRE(raw->ldo % 16 == 0 && qd_aligned(raw->out, 16), "qd_groupnorm_silu_quant: raw output rows must be 16-byte aligned");
-        rq.out = raw->out; rq.ldo = (long)raw->ldo; rq.nseg = raw->nseg;
-        for (int i = 0; i < raw->nseg; ++i) {
-            const auto& g = raw->seg[i];
-            QD_REQUIRE(g.qparams && g.c0 >= 0 && g.clen > 0 && g.c0 % 16 == 0 && g.clen % 16 == 0 && g.oc0 % 16 == 0 && g.c0 + g.clen <= C &&
-                       g.oc0 + g.clen <= raw->ldo, "qd_groupnorm_silu_quant: raw segment %d: c0 / clen / oc0 must be multiples of 16 inside the rows", i);
-            QD_REQUIRE(g.qmax - g.off <= 127 && g.qmin - g.off >= -128, "qd_groupnorm_silu_quant: raw segment %d grid does not fit int8", i);
-            QD_REQUIRE(i == 0 || g.c0 >= raw->seg[0].c0 + raw->seg[0].clen, "qd_groupnorm_silu_quant: raw segments must be ordered and disjoint");
-            rq.c0[i] = g.c0; rq.clen[i] = g.clen; rq.oc0[i] = g.oc0; rq.off[i] = g.off;
-            rq.qmin[i] = (float)g.qmin; rq.qmax[i] = (float)g.qmax; rq.qp[i] = g.qparams;
-        }
-    }
-    // fp32 rows -> int8 rows without a float copy and without a modulation: finalise + apply in ONE launch (gn_apply_fused_kernel)
-    if (gn_fuse_knob() && x_dtype == QD_F32 && vec && out && !yout && !mod && C / groups >= 4) {
-        const float* pp = part_in ? part_in : part;
-        // rows per block: enough that the window's partials (nchunk x ~1.3 CW pairs) are a fraction of the rows it streams
-        const int R = S >= 2048 ? 512 : (S >= 512 ? 256 : (S >= 128 ? 64 : 32));
-        const unsigned gy = (unsigned)((S + R - 1) / R);
-        if (C % 64 == 0) {
-            hipLaunchKernelGGL((gn_apply_fused_kernel<64, 2>), dim3((unsigned)(C / 64), gy, (unsigned)B), dim3(256), 0, st, (const float*)x, (long)S, C, (long)ldx, R,
-                               pp, nchunk, ldp, groups, eps, gamma, beta, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, rq);
-        } else {
-            hipLaunchKernelGGL((gn_apply_fused_kernel<32, 2>), dim3((unsigned)((C + 31) / 32), gy, (unsigned)B), dim3(256), 0, st, (const float*)x, (long)S, C, (long)ldx, R,
-                               pp, nchunk, ldp, groups, eps, gamma, beta, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, rq);
-        }
-        QD_LAUNCH_CHECK("qd_groupnorm_silu_quant");
-        return 0;
-    }
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, (unsigned)B), dim3(64), 0, st, part_in ? part_in : part, nchunk, ldp, (long)S, C, groups, eps, gamma, beta, ab);
     if (mod) {
         QD_REQUIRE(mod_ld >= 2 * (int64_t)C, "qd_groupnorm_mod_silu_quant: modulation rows hold scale | shift: mod_ld >= 2 C");
         const long tot = (long)B * C;
         hipLaunchKernelGGL(gn_modulate_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ab, mod, (long)mod_ld, C, tot);
+    }
+    RawQ rq{};
+    if (raw && raw->out) {
+        QD_REQUIRE(raw->nseg == 1 || raw->nseg == 2, "qd_groupnorm_silu_quant: raw output takes 1 or 2 segments");
+        QD_REQUIRE(raw->ldo % 16 == 0 && qd_aligned(raw->out, 16), "qd_groupnorm_silu_quant: raw output rows must be 16-byte aligned");
+        rq.out = raw->out; rq.ldo = (long)raw->ldo; rq.nseg = raw->nseg;
+        for (int i = 0; i < raw->nseg; ++i) {
+            const auto& g = raw->seg[i];
+            QD_REQUIRE(g.qparams && g.c0 >= 0 && g.clen > 0 && g.c0 % 16 == 0 && g.clen % 16 == 0 && g.oc0 % 16 == 0 && g.c0 + g.clen <= C &&
+                       g.oc0 + g.clen <= raw->ldo, "qd_groupnorm_silu_quant: raw segment %d: c0 / clen / oc0 must be multiples of 16 inside the rows", i);
+            QD_REQUIRE(g.qmax - g.off <= 127 && g.qmin - g.off >= -128, "qd_groupnorm_silu_quant: raw segment %d grid does not fit int8", i);
+            QD_REQUIRE(i == 0 || g.c0 >= raw->seg[0].c0 + raw->seg[0].clen, "qd_groupnorm_silu_quant: raw segments must be ordered and disjoint");
+            rq.c0[i] = g.c0; rq.clen[i] = g.clen; rq.oc0[i] = g.oc0; rq.off[i] = g.off;
+            rq.qmin[i] = (float)g.qmin; rq.qmax[i] = (float)g.qmax; rq.qp[i] = g.qparams;
+        }
     }
     long rows = B * S;
     long total = rows * (C / 4);
