@@ -183,6 +183,12 @@ typedef struct {
 
 int qd_conv2d_i8(const qd_conv_desc* d, void* stream);
 
+/* qd_conv_config (ABI v20): kgroups 1 (default; initial value QD_KGROUPS) = a launch with at most one output tile per CU and at least
+ * eight K-steps runs 512-thread blocks whose two groups of four waves contract alternate K-steps and add their int32
+ * accumulators in LDS before the (unchanged) epilogue — two waves per SIMD where the four-wave block leaves one; 0 = always the
+ * four-wave block; -1 = leave unchanged.  The integers, and therefore the bytes written, are the same either way. */
+void qd_conv_config(int kgroups);
+
 /* Grouped launch (ABI v20): n = 1..3 descriptors of ONE problem shape with head-layout epilogues (QD_EPI_HEADS_I8 / _T_I8) — the
  * q / k / v projections of an attention block, which the reference evaluates as three Linears on the rows of one LayerNorm
  * (qdiff/quant_block.py:193-199, ldm attention.py:174-182; the DDIM AttnBlock's q / k / v convolutions diffusion.py:142-144; the

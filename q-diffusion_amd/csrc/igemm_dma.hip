@@ -138,20 +138,28 @@ __device__ __forceinline__ constexpr int crow(int r) { return (r & 3) + 8 * (r >
 #endif
 // LDS bytes of one block: the 3-stage ring (re-used by the epilogue as per-wave transposition tiles + GroupNorm partials) + row
 // tables + per-channel constants
-template <int MT, int NT, int WM, int WN, int OUT, int WB>
+template <int MT, int NT, int WM, int WN, int OUT, int WB, int KS = 1>
 __host__ __device__ constexpr int igemm_smem_bytes() {
     constexpr bool BF = WB >= 16;
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, NTB = NT * WN;
     constexpr int TB = BF ? 2048 : 256 * WB;
     constexpr int STAGE = BM * 64 + NTB * TB;
     constexpr int TBW = ((OUT == O_F16 || OUT == O_HROWS) && !BF) ? 8192 : 4096;
-    constexpr int EPI_BYTES = 4 * TBW + 4 * (32 * NT) * 8;
-    constexpr int RING = 3 * STAGE > EPI_BYTES ? 3 * STAGE : EPI_BYTES;
-    return RING + 2 * BM * 4 + 4 * BN * 4;
+    constexpr int EPI_BYTES = 4 * KS * TBW + 4 * (32 * NT) * 8;
+    constexpr int RING = 3 * KS * STAGE > EPI_BYTES ? 3 * KS * STAGE : EPI_BYTES;
+    return RING + (2 + (KS > 1 ? 1 : 0)) * BM * 4 + 4 * BN * 4;
 }
 
-template <int MT, int NT, int WM, int WN, bool SPLIT, int OUT, int WB>
+// KS = 2 (round 6): TWO K-groups of four waves in one 512-thread block.  A launch whose tiles number at most one per CU (the
+// 16 x 16 and 32 x 32 levels of SD at batch 16: 256 blocks) runs ONE wave per SIMD, and a single wave cannot keep its SIMD
+// busy: the same layers at twice the batch — two independent blocks per CU — take 1.40 .. 1.44 x the time, not 2 x
+// (profiles/r06_igemm_blocks_per_cu.txt).  Splitting K across two BLOCKS pays that back in int32 partial traffic (rounds 2 - 5);
+// here the K range is split inside the block: group g contracts the K-steps s = g (mod 2) out of its own ring stages with its
+// own four loader waves — each SIMD hosts one wave of either group — and the two accumulator sets meet in LDS (exact int32
+// adds: the same integers, the same epilogue, the same bytes as the four-wave kernel).  The groups share the block's barrier.
+template <int MT, int NT, int WM, int WN, bool SPLIT, int OUT, int WB, int KS = 1>
 __device__ __forceinline__ void igemm_body(const ConvD& p, unsigned char* smem) {
+    static_assert(KS == 1 || (KS == 2 && !SPLIT && (OUT == O_F32 || OUT == O_F16) && WB <= 8), "two K-groups: one segment, linear fp32 / fp16 rows");
     static_assert(WB == 4 || WB == 8 || WB == 16 || WB == 17, "weight bits (16 = bf16 mode, 17 = fp16 mode)");
     constexpr bool BF = WB >= 16;                 // the floating-point mode (either operand type: same bytes, same loop)
     constexpr bool FH = WB == 17;                 // ... on IEEE halves (v_mfma_f32_32x32x16_f16) instead of bf16
@@ -170,20 +178,24 @@ __device__ __forceinline__ void igemm_body(const ConvD& p, unsigned char* smem) 
     // The epilogue re-uses the (dead) ring as per-wave transposition tiles + the GroupNorm partials behind them: 4 KB per wave,
     // 8 KB for the fp16 stream (two MFMA tiles = 64 columns = one 128-byte line of halves per row, see the epilogue)
     constexpr int TBW = ((OUT == O_F16 || OUT == O_HROWS) && !BF) ? 8192 : 4096;
-    constexpr int EPI_BYTES = 4 * TBW + 4 * WCOLS * 8;
-    constexpr int RING = 3 * STAGE > EPI_BYTES ? 3 * STAGE : EPI_BYTES;
-    static_assert(RING + 2 * BM * 4 + 4 * BN * 4 == igemm_smem_bytes<MT, NT, WM, WN, OUT, WB>(), "igemm_smem_bytes out of step with the body");
+    constexpr int EPI_BYTES = 4 * KS * TBW + 4 * WCOLS * 8;
+    constexpr int RS = KS * STAGE;                // ring stride: a K-group's stages are KS apart
+    constexpr int RING = 3 * RS > EPI_BYTES ? 3 * RS : EPI_BYTES;
+    static_assert(RING + (2 + (KS > 1 ? 1 : 0)) * BM * 4 + 4 * BN * 4 == igemm_smem_bytes<MT, NT, WM, WN, OUT, WB, KS>(), "igemm_smem_bytes out of step with the body");
     int* sRowB = reinterpret_cast<int*>(smem + RING);
     int* sAsum = sRowB + BM;
+    int* sAsum1 = sAsum + BM;                     // KS == 2: the second K-group's activation row sums
     // per-output-channel epilogue constants of the LAST segment, fetched at kernel start so that their
     // global-load latency overlaps the prologue DMA instead of serialising in front of the stores
-    float* sScale = reinterpret_cast<float*>(sAsum + BM);
+    float* sScale = reinterpret_cast<float*>(sAsum + (KS > 1 ? 2 : 1) * BM);
     int*   sZc    = reinterpret_cast<int*>(sScale + BN);
     int*   sZw    = sZc + BN;
     float* sBias  = reinterpret_cast<float*>(sZw + BN);
 
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kg = KS > 1 ? wave_all >> 2 : 0;    // K-group of this wave
+    const int wave = wave_all & 3;                // wave inside its group: everything below is per group
     const int wm = wave / WN, wn = wave % WN;
     const int frow = lane & 31, fhalf = lane >> 5;
 
@@ -347,6 +359,14 @@ __device__ __forceinline__ void igemm_body(const ConvD& p, unsigned char* smem) 
             if (ls < p.nseg) set_tap();
         }
     };
+    // KS == 2: the K-step between two of this group's steps belongs to the other group — move the loader over it
+    auto skip_step = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a_cur[i] += a_inc[i];
+#pragma unroll
+        for (int r = 0; r < NBW; ++r) b_cur[r] += b_inc[r];
+        advance();
+    };
 
     // ---- accumulators ------------------------------------------------------------------------------------
     typename std::conditional<BF, v16f, v16i>::type acc[MT][NT];
@@ -414,12 +434,16 @@ __device__ __forceinline__ void igemm_body(const ConvD& p, unsigned char* smem) 
     }
 
     // ---- prologue: two stages in flight ------------------------------------------------------------------------
+    const unsigned gofs = kg * STAGE;                  // this K-group's first ring stage
+    if (KS > 1 && kg == 1) skip_step();                // group 1 starts at K-step 1
 #pragma unroll
-    for (int d = 0; d < PER; ++d) issue_one(0, d);
+    for (int d = 0; d < PER; ++d) issue_one(gofs, d);
     advance();
+    if (KS > 1) skip_step();
 #pragma unroll
-    for (int d = 0; d < PER; ++d) issue_one(STAGE, d);
+    for (int d = 0; d < PER; ++d) issue_one(gofs + RS, d);
     advance();
+    if (KS > 1) skip_step();
 #pragma unroll
     for (int u = 0; u < NPR; ++u) {                    // visible to every wave after the main loop's barriers
         const int cl = (int)threadIdx.x + 256 * u;
@@ -529,21 +553,67 @@ __device__ __forceinline__ void igemm_body(const ConvD& p, unsigned char* smem) 
 #pragma unroll
         for (int d = S; d < PER; ++d) issue_one(nxt, d);
         advance();
+        if (KS > 1) skip_step();
     };
 
     {
-        unsigned cur = 0, nxt = 2 * STAGE;
+        unsigned cur = gofs, nxt = gofs + 2 * RS;
 #ifdef QD_ABL_NOKLOOP          // measurement-only build (wrong results): prologue + epilogue, one K-step
         for (int it = 0; it < 1; ++it) {
 #else
-        for (int it = 0; it < total; ++it) {
+        // KS == 2: ceil(total / 2) rounds; with an odd step count the second group's last round contracts a stage of zeros (its
+        // loader ran out one step earlier: the copies past the end read the zero block), which adds nothing
+        for (int it = 0; it < (total + KS - 1) / KS; ++it) {
 #endif
             step(cur, nxt);
             if (SPLIT && p.nseg == 2 && it == nst0 - 1) flush_segment0();
             nxt = cur;
-            cur = cur == 2 * STAGE ? 0 : cur + STAGE;
+            cur = cur == gofs + 2 * RS ? gofs : cur + RS;
         }
         wait_vmcnt<0>();                               // the last two steps' dummy prefetches: the ring is reused below
+    }
+    // KS == 2: after the K loop the two groups split the EPILOGUE by column tiles — group 0 owns tiles j < J0, group 1 the rest —
+    // and hand each other the partial accumulators of the tiles they do not own (two waves per SIMD in the epilogue as well)
+    constexpr int J0 = KS > 1 ? (NT == 7 ? 4 : 2) : NT;          // even: a tile pair of the fp16 epilogue never straddles the groups
+    auto owner = [](int j) constexpr { return (KS > 1 && j >= J0) ? 1 : 0; };
+    if constexpr (KS > 1) {
+        // ---- the two K-groups meet: row sums, then the accumulators in batches through the (dead) ring — exact int32 adds ----
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int v = asum[i] + __shfl_xor(asum[i], 32);
+            if (fhalf == 0) (kg == 1 ? sAsum1 : sAsum)[wrow0 + i * 32 + frow] = v;   // waves sharing rows (WN > 1) write identical values
+        }
+        constexpr int TPB = (RING / 16384) < (MT * NT) ? (RING / 16384) : (MT * NT);     // 32 x 32 tiles of all four waves per batch
+        static_assert(TPB >= 1, "the ring holds at least one tile of every wave");
+        v4i* xch = reinterpret_cast<v4i*>(smem);       // [tile in batch][wave][quarter][lane] 16 bytes
+#pragma unroll
+        for (int t0 = 0; t0 < MT * NT; t0 += TPB) {
+            __syncthreads();                           // the ring is dead (first batch) / the previous batch has been taken
+#pragma unroll
+            for (int t = t0; t < t0 + TPB && t < MT * NT; ++t) {
+                if (kg != owner(t % NT)) {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd)
+                        xch[(((t - t0) * 4 + wave) * 4 + qd) * 64 + lane] =
+                            v4i{acc[t / NT][t % NT][4 * qd], acc[t / NT][t % NT][4 * qd + 1], acc[t / NT][t % NT][4 * qd + 2], acc[t / NT][t % NT][4 * qd + 3]};
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = t0; t < t0 + TPB && t < MT * NT; ++t) {
+                if (kg == owner(t % NT)) {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const v4i o = xch[(((t - t0) * 4 + wave) * 4 + qd) * 64 + lane];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[t / NT][t % NT][4 * qd + e] += o[e];
+                    }
+                }
+            }
+        }
+        // total row sums for both groups (the partials were published before the first barrier above)
+        for (int r = threadIdx.x; r < BM; r += 256 * KS) sAsum[r] += sAsum1[r];
+        __syncthreads();                               // sAsum complete; the exchange area is the epilogue's transposition space from here on
     }
 
     // ---- epilogue ----------------------------------------------------------------------------------------------
@@ -558,15 +628,17 @@ __device__ __forceinline__ void igemm_body(const ConvD& p, unsigned char* smem) 
         return;
     }
 #endif
-    publish_asum();
-    __syncthreads();                                   // sAsum / sRowB visible to every wave; the ring is dead from here on
+    if constexpr (KS == 1) {
+        publish_asum();
+        __syncthreads();                               // sAsum / sRowB visible to every wave; the ring is dead from here on
+    }
     const SegD& sg = p.seg[p.nseg - 1];
     const int kz = sg.zfill ? sg.zfill[1] : 0;
     // Per-wave transposition tile (the ring is dead): 32 rows x 32 dwords.  Phase 1 writes one MFMA tile in the C layout
     // (lane = column, 16 rows per lane: conflict-free ds_write_b32), phase 2 reads it back row-major, 16 B per lane:
     // lane -> (row = pass*8 + lane/8, 4 columns from (lane%8)*4); zw * Asum uses the 24-bit multiplier (both factors
     // fit: |zw| <= 128, |Asum - kz| <= 2 * 128 * K < 2^23, checked on the host).
-    unsigned* tb = reinterpret_cast<unsigned*>(smem + wave * TBW);
+    unsigned* tb = reinterpret_cast<unsigned*>(smem + (kg * 4 + wave) * TBW);
     const int rr0 = lane >> 3, c4 = (lane & 7) * 4;
     const int wcol0 = n0 + wn * WCOLS;                 // first global column of this wave
 
@@ -832,7 +904,7 @@ __device__ __forceinline__ void igemm_body(const ConvD& p, unsigned char* smem) 
     // pass over HBM): per-column partials of the lane's rows -> butterfly over the 8 lanes that share the columns ->
     // fixed-order LDS reduction over the waves of each 128-row chunk -> one {sum, sumsq} pair per (chunk, channel).
     const bool gn = (OUT == O_F32 || OUT == O_F16 || OUT == O_BF16) && p.gnpart != nullptr;   // statistics of the fp32 values (before a 16-bit store)
-    float* sGn = reinterpret_cast<float*>(smem + 4 * TBW);        // [4 waves][WCOLS][2], behind the transposition tiles
+    float* sGn = reinterpret_cast<float*>(smem + 4 * KS * TBW);   // [4 waves][WCOLS][2], behind the transposition tiles (K-groups own disjoint columns)
     auto single = [&](const int j) __attribute__((always_inline)) {
         const int cl = wn * WCOLS + j * 32 + frow;
         const float sc = sScale[cl];
@@ -1115,15 +1187,19 @@ __device__ __forceinline__ void igemm_body(const ConvD& p, unsigned char* smem) 
         // aligned line) was measured SLOWER: 19.33 vs 18.98 ms per SD step (profiles/r05_streams_ab.md) — a second copy of
         // the epilogue with other accumulator indices, 62 -> 109 spilled registers on the MT = 2 tiles.
 #pragma unroll
-        for (int q = 0; q < NT / 2; ++q) pair(2 * q);
-        if constexpr (NT % 2 == 1) single(NT - 1);
+        for (int q = 0; q < NT / 2; ++q)
+            if (owner(2 * q) == kg) pair(2 * q);
+        if constexpr (NT % 2 == 1) {
+            if (owner(NT - 1) == kg) single(NT - 1);
+        }
     } else {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) single(j);
+        for (int j = 0; j < NT; ++j)
+            if (owner(j) == kg) single(j);
     }
     if (gn) {
         __syncthreads();
-        for (int c = threadIdx.x; c < BN; c += 256)
+        for (int c = threadIdx.x; c < BN; c += 256 * KS)
         if (n0 + c < p.Cout) {
             constexpr int WPC = MT >= 4 ? 1 : 4 / MT;         // waves (along M) per 128-row chunk
             const int wnc = c / WCOLS, cw = c - wnc * WCOLS;
@@ -1151,6 +1227,12 @@ template <int MT, int NT, int WM, int WN, bool SPLIT, int OUT, int WB>
 __global__ __launch_bounds__(256, (SPLIT || MT * NT > 10) ? 1 : (MT == 1 && NT <= 5 ? QD_MT1_OCC : 2)) void igemm_kernel(const ConvD p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[igemm_smem_bytes<MT, NT, WM, WN, OUT, WB>()];
     igemm_body<MT, NT, WM, WN, SPLIT, OUT, WB>(p, smem);
+}
+
+template <int MT, int NT, int WM, int WN, int OUT, int WB>
+__global__ __launch_bounds__(512, 1) void igemm_k2_kernel(const ConvD p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[igemm_smem_bytes<MT, NT, WM, WN, OUT, WB, 2>()];
+    igemm_body<MT, NT, WM, WN, false, OUT, WB, 2>(p, smem);
 }
 
 // Grouped launch of the q / k / v projections of one attention block (reference qdiff/quant_block.py:193-199: three Linears on
@@ -1303,6 +1385,19 @@ template __global__ void igemm_kernel<QD_PROBE_INSTANCE>(const ConvD);
 }  // namespace
 #else
 // tile shapes (MT, NT, WM, WN): block = (32*MT*WM) x (32*NT*WN)
+// two K-groups per block where a launch has at most one tile per CU (default) or never (QD_KGROUPS=0 / qd_conv_config(0): A/B
+// runs and the equality test)
+static int& kgroups_knob() {
+    static int v = (getenv("QD_KGROUPS") && atoi(getenv("QD_KGROUPS")) == 0) ? 0 : 1;
+    return v;
+}
+
+// K loops of fewer than eight 64-byte steps stay on the four-wave block (nothing to split).  Measured with the epilogue divided
+// between the groups (profiles/r06_c7_kgroups_igemm_ab.txt, one box, us per launch at batch 16): 3 x 3 1280 -> 1280 at 16 x 16
+// 104.8 -> 86.1, 2560 -> 1280 188.9 -> 152.7, 3 x 3 640 -> 640 at 32 x 32 83.4 -> 74.5, 1 x 1 5120 -> 1280 47.9 -> 40.3,
+// 1 x 1 1280 -> 1280 22.9 -> 19.8, 1 x 1 640 -> 640 at 32 x 32 (ten steps) 26.0 -> 24.7; SD step 19.84 -> 19.35 ms.
+constexpr int kgroups_min_steps() { return 8; }
+
 // qd_conv2d_i8_group runs every member through run() — all its checks, its tile choice — with this set: dispatch() then
 // records the finished kernel descriptor and the tile it would have launched instead of launching.
 struct GroupCapture { ConvD k; int out, tile; bool split; };
@@ -1317,6 +1412,17 @@ int dispatch(ConvD& k, bool split, int out, hipStream_t st, int nsplit = 1) {
     if (g_capture) {
         *g_capture = GroupCapture{k, out, nsplit == 1 ? tile_code(MT, NT, WM, WN, WB) : -1, split};
         return 0;
+    }
+    // At most one tile per CU and a K loop worth splitting: two K-groups in a 512-thread block (igemm_body, KS = 2)
+    if constexpr (WB <= 8 && (WM == 4 || (MT == 2 && NT == 5)) && (NT == 4 || NT == 5 || NT == 7) && (WB == 4 || NT == 4)) {
+        const int ksteps = k.taps * k.seg[0].nsteps_tap;
+        if (kgroups_knob() && !split && nsplit == 1 && k.nseg == 1 && (long)k.nblk_m * k.nblk_n <= 256 && ksteps >= kgroups_min_steps() &&
+            (out == O_F32 || (out == O_F16 && NT == 5 && MT == 1))) {          // (fp16 rows on the 256-row tiles spill: four-wave block)
+            dim3 grid2(k.nblk_m * k.nblk_n), block2(512);
+            if (out == O_F32) hipLaunchKernelGGL((igemm_k2_kernel<MT, NT, WM, WN, O_F32, WB>), grid2, block2, 0, st, k);
+            else if constexpr (NT == 5 && MT == 1) hipLaunchKernelGGL((igemm_k2_kernel<MT, NT, WM, WN, O_F16, WB>), grid2, block2, 0, st, k);
+            return 0;
+        }
     }
     dim3 grid(k.nblk_m * k.nblk_n, nsplit), block(256);
 #define QD_CASE(SP, O)                                                                              \
@@ -1716,6 +1822,9 @@ int run_group(const qd_conv_desc* const* descs, int n, void* stream) {
     return 0;
 }
 
+extern "C" void qd_conv_config(int kgroups) {
+    if (kgroups >= 0) kgroups_knob() = kgroups ? 1 : 0;
+}
 extern "C" int qd_conv2d_i8_group(const qd_conv_desc* const* descs, int n, void* stream) { return run_group(descs, n, stream); }
 extern "C" int qd_conv2d_i8(const qd_conv_desc* d, void* stream) { return run(d, nullptr, stream); }
 extern "C" int qd_conv2d_i8_acc(const qd_conv_desc* d, int32_t* iout, void* stream) {

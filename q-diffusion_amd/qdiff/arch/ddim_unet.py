@@ -296,6 +296,15 @@ class Model(nn.Module):
                 h = run(stage.upsample, h, slot=dec_slot())
         self.__dict__["_cat_plan"] = seen
 
+        # output head (reference ddim/models/diffusion.py:346-348: norm_out -> swish -> conv_out): on the integer path the
+        # normalisation emits conv_out's int8 rows in one pass (statistics from the last block's epilogue), as UNetModel._out does
+        conv = self.conv_out
+        if (isinstance(conv, QuantModule) and qb._int_mode(conv) and conv.split == 0 and conv.kind == 'conv2d'
+                and conv.act_quantizer.inited and h.dim() == 4 and h.shape[1] % 16 == 0):
+            B, C, H, W = h.shape
+            rows = qb._nhwc_rows(h)
+            xq = qb._gn_silu_to(conv, rows, B, H * W, C, self.norm_out)
+            return qb._rows_to_nchw(conv.forward_codes(xq, B, H, W), B, H, W)
         if h.dtype != torch.float32:
             h = h.float()                                   # fp16 activation stream: the torch output head runs on fp32
         return self.conv_out(nonlinearity(self.norm_out(h)))

@@ -62,7 +62,7 @@ EPI_LINEAR, EPI_GEGLU_I8, EPI_HEADS_I8, EPI_HEADS_T_I8 = 0, 1, 2, 3
 
 EXPORTS = ["qd_abi_version", "qd_last_error", "qd_device_ok", "qd_box_probe", "qd_make_qparams", "qd_quantize_act", "qd_pack_weights", "qd_pack_weights_t4",
            "qd_pack_weights_t8",
-           "qd_conv2d_i8", "qd_conv2d_i8_group", "qd_conv2d_i8_splitk_ws_bytes",
+           "qd_conv2d_i8", "qd_conv_config", "qd_conv2d_i8_group", "qd_conv2d_i8_splitk_ws_bytes",
            "qd_conv2d_i8_acc", "qd_groupnorm_ws_bytes", "qd_groupnorm_silu_quant", "qd_groupnorm_mod_silu_quant", "qd_layernorm_quant",
            "qd_geglu_quant", "qd_quantize_heads", "qd_attn_i8", "qd_attn_keyterm", "qd_attn_uses_keyterm", "qd_attn_config", "qd_attn_ws_bytes", "qd_bmm_qk_i8", "qd_bmm_pv_i8", "qd_temb_mlp",
            "qd_fakequant_blocks", "qd_fakequant_fwd", "qd_fakequant_bwd",
@@ -91,6 +91,8 @@ def load():
     lib.qd_pack_weights_t4.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]
     lib.qd_pack_weights_t8.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]
     lib.qd_conv2d_i8.argtypes = [ctypes.POINTER(ConvDesc), vp]
+    lib.qd_conv_config.argtypes = [i32]
+    lib.qd_conv_config.restype = None
     lib.qd_conv2d_i8_group.argtypes = [ctypes.POINTER(ctypes.POINTER(ConvDesc)), i32, vp]
     lib.qd_conv2d_i8_acc.argtypes = [ctypes.POINTER(ConvDesc), vp, vp]
     lib.qd_conv2d_i8_splitk_ws_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
@@ -268,6 +270,10 @@ def conv2d_i8(c, acc_out=None):
         _check(load().qd_conv2d_i8(ctypes.byref(d), _stream()), "qd_conv2d_i8")
     else:
         _check(load().qd_conv2d_i8_acc(ctypes.byref(d), _ptr(acc_out), _stream()), "qd_conv2d_i8_acc")
+
+
+def conv_config(kgroups=-1):
+    load().qd_conv_config(int(kgroups))
 
 
 def conv2d_i8_group(calls):

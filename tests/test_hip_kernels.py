@@ -816,6 +816,45 @@ def test_attention_keyterm_table(cuda):
         assert torch.equal(got.cpu(), want)
 
 
+@pytest.mark.parametrize("B,Cin,H,Cout,k,wbits,dt", [
+    (2, 1280, 16, 1280, 3, 4, torch.float32),      # SD 16 x 16 level: 128 x 160 tiles, 180 K-steps
+    (4, 640, 32, 640, 3, 4, torch.float32),        # SD 32 x 32 level: the 128 x 320 tile of 2 x 2 waves, 90 K-steps
+    (1, 320, 64, 320, 3, 4, torch.float32),        # 256-row tiles, 45 K-steps (odd: the second group's last round is a zero stage)
+    (2, 1280, 16, 1280, 1, 4, torch.float32),      # 1 x 1, 20 K-steps
+    (2, 1920, 16, 1280, 3, 4, torch.float32), (3, 200, 16, 320, 3, 4, torch.float32),       # K tail (200 = 3 x 64 + 8), odd step counts
+    (2, 448, 32, 448, 3, 4, torch.float32), (2, 672, 16, 896, 1, 4, torch.float32),         # LDM-4: 224-wide tiles
+    (8, 256, 16, 256, 3, 8, torch.float32), (4, 128, 32, 128, 3, 8, torch.float32), (2, 192, 16, 64, 3, 4, torch.float32),  # CIFAR int8 / 128- and 64-wide
+    (2, 1280, 16, 1280, 3, 4, torch.float16), (4, 640, 32, 640, 3, 4, torch.float16)])
+def test_conv_two_k_groups_equal_the_four_wave_block(cuda, B, Cin, H, Cout, k, wbits, dt):
+    """Round 6: launches with at most one tile per CU run 512-thread blocks whose two groups of four waves contract alternate
+    K-steps and add their int32 accumulators in LDS (igemm_body, KS = 2).  Integer adds commute: the output — rows, with
+    row bias, residual and GroupNorm statistics of the epilogue — equals the four-wave kernel's bit for bit (qd_conv_config
+    switches the variant; shapes the variant is not built for fall back and compare trivially equal)."""
+    from qdiff import engine, hip
+    g = torch.Generator().manual_seed(61)
+    x = F.silu(torch.randn(B, Cin, H, H, generator=g))
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
+    q = _weight_quantizer(w, wbits, True, g)
+    d, z = R.uaq_init_scale(x, 8, False, False, "max")
+    plan = engine.build_conv_plan(engine.pack_module_weights(w.to(cuda), [q], 0), [_aq(d, z)], k, k, 1, k // 2, torch.randn(Cout, generator=g).to(cuda))
+    rows = x.permute(0, 2, 3, 1).reshape(B * H * H, Cin).contiguous().to(cuda)
+    xq = engine.quantize_rows(rows, plan, 1, Cin, B * H * H, (0, 1, Cin))
+    residual = (torch.randn(B * H * H, Cout, generator=g)).to(cuda).to(dt)
+    rowbias = torch.randn(B, Cout, generator=g).to(cuda)
+    outs = {}
+    try:
+        for kg in (1, 0):
+            hip.conv_config(kgroups=kg)
+            o = engine.conv_forward(plan, xq, B, H, H, rowbias=rowbias, residual=residual, out_dtype=dt, splitk=False, gn_stats=(H * H) % 128 == 0)
+            torch.cuda.synchronize()
+            outs[kg] = (o.clone(), getattr(o, "qd_gn_part", None))
+    finally:
+        hip.conv_config(kgroups=1)
+    assert torch.equal(outs[1][0], outs[0][0]) and torch.isfinite(outs[1][0].float()).all() and outs[1][0].float().abs().max() > 0
+    if outs[0][1] is not None:
+        assert torch.equal(outs[1][1], outs[0][1])
+
+
 @pytest.mark.parametrize("T,N,K,H", [(128, 320, 320, 8), (256, 640, 640, 8), (512, 320, 1280, 8), (128, 288, 320, 8), (256, 1280, 320, 8),
                                      (128, 256, 640, 8),
                                      # the LDM AttentionBlock's role projections (QuantModule.head_plans): LDM-4 beds, 32 channels

@@ -1,0 +1,40 @@
+#!/bin/bash
+# Round 6, GPU call 7: two K-groups, epilogue split between the groups, K loops of >= 40 steps only — kernel tests, micro A/B, SD /
+# CIFAR / LDM A/B.
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r06_c7
+mkdir -p $O
+timeout 1500 python -m pytest tests/test_hip_kernels.py -m gpu -x -q -k "conv or gemm or groupnorm or heads or linear" > $O/pytest_kernels.log 2>&1; echo "pytest rc=$?" >> $O/pytest_kernels.log
+tail -4 $O/pytest_kernels.log
+SH="16,1280,16,1280,3,1;16,640,32,640,3,1;16,1280,16,1280,1,1;16,2560,16,1280,3,1;16,640,32,640,1,1;16,1920,16,1280,3,1;16,1280,32,640,3,1;16,5120,16,1280,1,1"
+for rep in 1 2; do
+  echo "== four-wave blocks rep=$rep" >> $O/igemm_ab.txt; QD_KGROUPS=0 IGEMM_SHAPES="$SH" timeout 300 python tools/bench_igemm.py 4 20 2>/dev/null | grep custom >> $O/igemm_ab.txt
+  echo "== two K-groups (>= 40 steps) rep=$rep" >> $O/igemm_ab.txt; IGEMM_SHAPES="$SH" timeout 300 python tools/bench_igemm.py 4 20 2>/dev/null | grep custom >> $O/igemm_ab.txt
+  echo "== two K-groups (>= 8 steps) rep=$rep" >> $O/igemm_ab.txt; QD_KGROUPS_MINSTEPS=8 IGEMM_SHAPES="$SH" timeout 300 python tools/bench_igemm.py 4 20 2>/dev/null | grep custom >> $O/igemm_ab.txt
+done
+cat $O/igemm_ab.txt
+X="--no-cpu-baseline --no-denominators --no-extras --steps 20 --warmup 5"
+one() { name=$1; shift; echo "== $name" >> $O/ab.log; ( "$@" ) >> $O/ab.log 2>> $O/ab.err; }
+for rep in 1 2; do
+  one "sd four-wave rep=$rep" env QD_KGROUPS=0 timeout 600 python bench.py $X
+  one "sd k-groups rep=$rep" timeout 600 python bench.py $X
+  one "sd k-groups min 16 rep=$rep" env QD_KGROUPS_MINSTEPS=16 timeout 600 python bench.py $X
+  one "cifar four-wave rep=$rep" env QD_KGROUPS=0 timeout 600 python bench.py --model cifar --images-per-gpu 64 $X
+  one "cifar k-groups rep=$rep" timeout 600 python bench.py --model cifar --images-per-gpu 64 $X
+  one "ldm four-wave rep=$rep" env QD_KGROUPS=0 timeout 600 python bench.py --model ldm --images-per-gpu 64 --extra-batch 10 $X
+  one "ldm k-groups rep=$rep" timeout 600 python bench.py --model ldm --images-per-gpu 64 --extra-batch 10 $X
+done
+python - <<'PY' > $O/ab_summary.txt
+import json
+name=None
+for ln in open("gpurun_out/r06_c7/ab.log"):
+    if ln.startswith("=="): name=ln.strip(); continue
+    if ln.startswith("{"):
+        d=json.loads(ln); r=d.get("roofline",{})
+        print(name, "ms_per_step", d.get("ms_per_step"), "value", d.get("value"), "igemm_ms", r.get("igemm_ms_per_eval"), "frac", r.get("frac"),
+              "classes", {k: v.get("ms") for k, v in (r.get("by_launch_class") or {}).items()},
+              "extra", (d.get("config") or {}).get("extra_batch",{}).get("ms_per_step"), "box", (d.get("box") or {}).get("mfma_ubench_tops"))
+PY
+cat $O/ab_summary.txt
+tail -3 $O/ab.err
