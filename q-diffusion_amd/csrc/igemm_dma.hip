@@ -159,7 +159,8 @@ __host__ __device__ constexpr int igemm_smem_bytes() {
 // adds: the same integers, the same epilogue, the same bytes as the four-wave kernel).  The groups share the block's barrier.
 template <int MT, int NT, int WM, int WN, bool SPLIT, int OUT, int WB, int KS = 1>
 __device__ __forceinline__ void igemm_body(const ConvD& p, unsigned char* smem) {
-    static_assert(KS == 1 || (KS == 2 && !SPLIT && (OUT == O_F32 || OUT == O_F16) && WB <= 8), "two K-groups: one segment, linear fp32 / fp16 rows");
+    static_assert(KS == 1 || (KS == 2 && !SPLIT && WB <= 8 && (OUT == O_F32 || OUT == O_F16 || OUT == O_PART || OUT == O_HROWS || OUT == O_HTR)),
+                  "two K-groups: one segment; linear rows, split-K partials or the head-layout epilogues");
     static_assert(WB == 4 || WB == 8 || WB == 16 || WB == 17, "weight bits (16 = bf16 mode, 17 = fp16 mode)");
     constexpr bool BF = WB >= 16;                 // the floating-point mode (either operand type: same bytes, same loop)
     constexpr bool FH = WB == 17;                 // ... on IEEE halves (v_mfma_f32_32x32x16_f16) instead of bf16
@@ -821,11 +822,15 @@ __device__ __forceinline__ void igemm_body(const ConvD& p, unsigned char* smem) 
         };
         if (p.vec == 2) {
 #pragma unroll
-            for (int q2 = 0; q2 < NT / 2; ++q2) tile2(2 * q2);
-            if constexpr (NT % 2 == 1) tile1(NT - 1);
+            for (int q2 = 0; q2 < NT / 2; ++q2)
+                if (owner(2 * q2) == kg) tile2(2 * q2);
+            if constexpr (NT % 2 == 1) {
+                if (owner(NT - 1) == kg) tile1(NT - 1);
+            }
         } else {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) tile1(j);
+            for (int j = 0; j < NT; ++j)
+                if (owner(j) == kg) tile1(j);
         }
         };
         QD_FAST_DISPATCH(oqp.fast, epi);
@@ -840,6 +845,7 @@ __device__ __forceinline__ void igemm_body(const ConvD& p, unsigned char* smem) 
         constexpr bool FAST = decltype(ft)::value;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
+            if (owner(j) != kg) continue;              // KS == 2: the other K-group's column tile
             const int cl = wn * WCOLS + j * 32 + frow;
             const bool nok = n0 + cl < p.Cout;
             const int nn = nok ? n0 + cl : 0;
@@ -1413,15 +1419,19 @@ int dispatch(ConvD& k, bool split, int out, hipStream_t st, int nsplit = 1) {
         *g_capture = GroupCapture{k, out, nsplit == 1 ? tile_code(MT, NT, WM, WN, WB) : -1, split};
         return 0;
     }
-    // At most one tile per CU and a K loop worth splitting: two K-groups in a 512-thread block (igemm_body, KS = 2)
+    // At most one tile per CU and a K loop worth splitting: two K-groups in a 512-thread block (igemm_body, KS = 2) — linear rows
+    // on every tile shape, split-K partials and the head-layout epilogues on the shapes the three UNets launch them with
     if constexpr (WB <= 8 && (WM == 4 || (MT == 2 && NT == 5)) && (NT == 4 || NT == 5 || NT == 7) && (WB == 4 || NT == 4)) {
-        const int ksteps = k.taps * k.seg[0].nsteps_tap;
-        if (kgroups_knob() && !split && nsplit == 1 && k.nseg == 1 && (long)k.nblk_m * k.nblk_n <= 256 && ksteps >= kgroups_min_steps() &&
-            (out == O_F32 || (out == O_F16 && NT == 5 && MT == 1))) {          // (fp16 rows on the 256-row tiles spill: four-wave block)
-            dim3 grid2(k.nblk_m * k.nblk_n), block2(512);
-            if (out == O_F32) hipLaunchKernelGGL((igemm_k2_kernel<MT, NT, WM, WN, O_F32, WB>), grid2, block2, 0, st, k);
-            else if constexpr (NT == 5 && MT == 1) hipLaunchKernelGGL((igemm_k2_kernel<MT, NT, WM, WN, O_F16, WB>), grid2, block2, 0, st, k);
-            return 0;
+        const long nb = (long)k.nblk_m * k.nblk_n * nsplit;
+        const int ksteps = out == O_PART ? k.it_per : k.taps * k.seg[0].nsteps_tap;
+        if (kgroups_knob() && !split && k.nseg == 1 && nb <= 256 && ksteps >= kgroups_min_steps()) {
+            dim3 grid2(k.nblk_m * k.nblk_n, nsplit), block2(512);
+#define QD_K2(O) { hipLaunchKernelGGL((igemm_k2_kernel<MT, NT, WM, WN, O, WB>), grid2, block2, 0, st, k); return 0; }
+            if (out == O_F32) QD_K2(O_F32)
+            if constexpr (NT == 5 && MT == 1) { if (out == O_F16) QD_K2(O_F16) }        // (fp16 rows on the 256-row tiles spill: four-wave block)
+            if constexpr (MT == 1 && WM == 4 && ((WB == 4 && (NT == 5 || NT == 7)) || (WB == 8 && NT == 4))) { if (out == O_PART) QD_K2(O_PART) }
+            if constexpr (WB == 4 && NT == 5 && WM == 4) { if (out == O_HROWS) QD_K2(O_HROWS) if (out == O_HTR) QD_K2(O_HTR) }
+#undef QD_K2
         }
     }
     dim3 grid(k.nblk_m * k.nblk_n, nsplit), block(256);

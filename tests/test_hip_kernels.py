@@ -820,7 +820,8 @@ def test_attention_keyterm_table(cuda):
     (2, 1280, 16, 1280, 3, 4, torch.float32),      # SD 16 x 16 level: 128 x 160 tiles, 180 K-steps
     (4, 640, 32, 640, 3, 4, torch.float32),        # SD 32 x 32 level: the 128 x 320 tile of 2 x 2 waves, 90 K-steps
     (1, 320, 64, 320, 3, 4, torch.float32),        # 256-row tiles, 45 K-steps (odd: the second group's last round is a zero stage)
-    (2, 1280, 16, 1280, 1, 4, torch.float32),      # 1 x 1, 20 K-steps
+    (2, 1280, 16, 1280, 1, 4, torch.float32),      # 1 x 1, 20 K-steps (+ head-layout epilogues: 8 heads of 160)
+    (2, 640, 16, 320, 1, 4, torch.float32), (16, 1280, 8, 1280, 3, 4, torch.float32),       # heads of 40 on 10 steps; 8 x 8 level: split-K partials
     (2, 1920, 16, 1280, 3, 4, torch.float32), (3, 200, 16, 320, 3, 4, torch.float32),       # K tail (200 = 3 x 64 + 8), odd step counts
     (2, 448, 32, 448, 3, 4, torch.float32), (2, 672, 16, 896, 1, 4, torch.float32),         # LDM-4: 224-wide tiles
     (8, 256, 16, 256, 3, 8, torch.float32), (4, 128, 32, 128, 3, 8, torch.float32), (2, 192, 16, 64, 3, 4, torch.float32),  # CIFAR int8 / 128- and 64-wide
@@ -853,6 +854,31 @@ def test_conv_two_k_groups_equal_the_four_wave_block(cuda, B, Cin, H, Cout, k, w
     assert torch.equal(outs[1][0], outs[0][0]) and torch.isfinite(outs[1][0].float()).all() and outs[1][0].float().abs().max() > 0
     if outs[0][1] is not None:
         assert torch.equal(outs[1][1], outs[0][1])
+    # the same for the split-K schedule (partials of every K slice from two K-groups) and, on 1 x 1 layers with whole heads, for
+    # the head-layout epilogues (q / k rows, transposed v + column sums)
+    res = {}
+    try:
+        for kg in (1, 0):
+            hip.conv_config(kgroups=kg)
+            o = engine.conv_forward(plan, xq, B, H, H, residual=residual, out_dtype=dt)            # the library decides about split-K
+            got = [o.clone()]
+            T = H * H
+            if k == 1 and T % 128 == 0 and Cout % 8 == 0 and (Cout // 8) % 4 == 0 and wbits == 4 and dt == torch.float32:
+                d8 = Cout // 8
+                mkq = lambda dl, zp: NS(delta=torch.tensor(dl), zero_point=torch.tensor(float(zp)), n_bits=8, sym=False)
+                ap = engine.build_attn_plan(mkq(0.05, 128), mkq(0.05, 120), mkq(0.04, 131), NS(delta=torch.tensor(1.0 / 65535), zero_point=torch.tensor(0.0), n_bits=16, sym=False),
+                                            1.0, 0.7, cuda)
+                for which in (0, 2):
+                    shape = (B * 8, engine.pad32(d8), engine.pad32(T)) if which == 2 else (B * 8, engine.pad32(T), engine.pad32(d8))
+                    buf = torch.zeros(shape, dtype=torch.int8, device=cuda)
+                    vs = torch.zeros((B * 8, engine.pad32(d8)), dtype=torch.int32, device=cuda)
+                    engine.project_heads(plan, xq, B, T, 8, ap, which, buf, vs)
+                    got += [buf, vs]
+            torch.cuda.synchronize()
+            res[kg] = got
+    finally:
+        hip.conv_config(kgroups=1)
+    assert len(res[1]) == len(res[0]) and all(torch.equal(a, b) for a, b in zip(res[1], res[0]))
 
 
 @pytest.mark.parametrize("T,N,K,H", [(128, 320, 320, 8), (256, 640, 640, 8), (512, 320, 1280, 8), (128, 288, 320, 8), (256, 1280, 320, 8),
