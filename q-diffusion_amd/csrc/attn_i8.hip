@@ -831,16 +831,13 @@ __device__ __forceinline__ void attn_qk(const v4i (&kf)[DT], const v4i (&qf)[DT]
 #ifndef QD_ATTN_PVFULL_OCC
 #define QD_ATTN_PVFULL_OCC 3                                  // ... the hi + lo P.V kernel (<= 168 VGPRs)
 #endif
-#ifndef QD_ATTN_LDS_PAD
-#define QD_ATTN_LDS_PAD 0                                     // measurement-only: extra LDS bytes per block (caps the blocks per CU)
-#endif
 
 template <int DT, int KT>
 __global__ __launch_bounds__(256, QD_ATTN_STATS_OCC) void attn_stats_kernel(const AttnK p, AttnStat* __restrict__ stat, int* __restrict__ blkflag, int p16) {
     // a*b+c written as such stays unfused: the lean and the LDS-staged bodies must produce the same normaliser bit for bit
 #pragma clang fp contract(off)
     using Ring = AttnRing<DT, KT, false>;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[Ring::NST * Ring::STAGE + QD_ATTN_LDS_PAD];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Ring::NST * Ring::STAGE];
     __shared__ int s_flag[2];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -960,7 +957,7 @@ __global__ __launch_bounds__(256, FULL ? QD_ATTN_PVFULL_OCC : QD_ATTN_PV_OCC) vo
 #pragma clang fp contract(off)
     using Ring = AttnRing<DT, KT, true>;
     constexpr bool HIK = FULL && P16;                         // this kernel owns hi accumulators
-    __shared__ __attribute__((aligned(16))) unsigned char smem[Ring::NST * Ring::STAGE + QD_ATTN_LDS_PAD];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Ring::NST * Ring::STAGE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int frow = lane & 31, half = lane >> 5;

@@ -48,7 +48,9 @@ def main(path, evals, out_path, kind="sd"):
             n[klass(nm)] += 1
         res[c] = {k: per[k] / evals for k in per}
         res[c + "_dispatches_per_eval"] = {k: n[k] / evals for k in n}
-        calls = sum(1 for _, nm, _ in seg if "igemm_kernel" in nm) / evals
+        # contraction launches: igemm_kernel / igemm_k2_kernel / igemm_heads_group_kernel (a grouped q / k / v launch counts once,
+        # as bench.py's per-launch events count it); the split-K finalise passes belong to their partial launches
+        calls = sum(1 for _, nm, _ in seg if "igemm_" in nm and "_kernel" in nm) / evals
     out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace --output-format csv -- "
                       f"python tools/eval_breakdown.py run {kind} 8 {evals}   (steady-state evaluations between spin markers only)",
            "evaluations": evals, "classes": {}}
