@@ -1507,8 +1507,7 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
     k.B = d->B; k.H = d->H; k.W = d->W; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout;
     k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad_t = d->pad_t; k.pad_l = d->pad_l;
     k.M = d->B * d->Ho * d->Wo; k.taps = d->kh * d->kw; k.nseg = d->nseg;
-    static const bool pw_ok = !(getenv("QD_POINTWISE") && atoi(getenv("QD_POINTWISE")) == 0);          // A/B knob
-    k.pointwise = pw_ok && k.taps == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->H == d->Ho && d->W == d->Wo;
+    k.pointwise = k.taps == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->H == d->Ho && d->W == d->Wo;
     k.ups = d->upsample2x ? 1 : 0;
     k.ntiles = (d->Cout + 31) / 32;
     for (int s = 0; s < d->nseg; ++s) {
@@ -1534,9 +1533,8 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
                                          (!d->residual || (d->ldr % 4 == 0 && qd_aligned(d->residual, 4 * esz))) &&
                                          (!d->rowbias || (d->ld_rowbias % 4 == 0 && qd_aligned(d->rowbias, 16)))));
     // fp16 rows whose every access may also be a 16-byte (8-half) vector: the full-line epilogue (two MFMA tiles per
-    // transposition, see the kernel); QD_F16_LINES=0 keeps the 4-halves-per-lane form (A/B knob)
-    static const bool f16_lines = !(getenv("QD_F16_LINES") && atoi(getenv("QD_F16_LINES")) == 0);
-    if (k.vec && f16_lines && !iout && d->out_dtype == QD_F16 && d->Cout % 8 == 0 && d->ldo % 8 == 0 && qd_aligned(d->out, 16) &&
+    // transposition, see the kernel)
+    if (k.vec && !iout && d->out_dtype == QD_F16 && d->Cout % 8 == 0 && d->ldo % 8 == 0 && qd_aligned(d->out, 16) &&
         (!d->residual || (d->ldr % 8 == 0 && qd_aligned(d->residual, 16))))
         k.vec = 2;
     if (heads) {
@@ -1551,8 +1549,7 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
                    "qd_conv2d_i8: heads epilogue takes no rowbias; a residual (fp32 or fp16 as out_dtype says, 4-element aligned rows) only with QD_EPI_HEADS_I8");
         k.res_f16 = d->out_dtype == QD_F16 ? 1 : 0;
         // head rows written 8 codes per lane (two tiles per transposition): head dim, padded head dim and the residual rows 8-aligned
-        static const bool heads8 = !(getenv("QD_HEADS8") && atoi(getenv("QD_HEADS8")) == 0);          // A/B knob
-        k.vec = (heads8 && d->epilogue == QD_EPI_HEADS_I8 && d->hd_d % 8 == 0 && d->hd_dpad % 8 == 0 && d->Cout % 8 == 0 && qd_aligned(d->out, 8) &&
+        k.vec = (d->epilogue == QD_EPI_HEADS_I8 && d->hd_d % 8 == 0 && d->hd_dpad % 8 == 0 && d->Cout % 8 == 0 && qd_aligned(d->out, 8) &&
                  (!d->residual || (d->ldr % 8 == 0 && qd_aligned(d->residual, 16)))) ? 2 : 1;
         k.oq = d->oq_params; k.oqmin = (float)d->oq_min; k.oqmax = (float)d->oq_max; k.oqoff = d->oq_off;
         k.hdH = d->hd_H; k.hdd = d->hd_d; k.hdT = d->hd_T; k.hdTpad = d->hd_Tpad; k.hddpad = d->hd_dpad;
@@ -1610,11 +1607,6 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
         QD_LAUNCH_CHECK("qd_conv2d_i8 (split-K)");
         return 0;
     }
-    static const int force_mt = getenv("QD_TILE_MT") ? atoi(getenv("QD_TILE_MT")) : 0;       // tuning knob: 1 / 2, 0 = heuristic
-    static const int force_gmt = getenv("QD_GEGLU_MT") ? atoi(getenv("QD_GEGLU_MT")) : 0;
-    static const int mt2_mink = getenv("QD_MT2_MINK") ? atoi(getenv("QD_MT2_MINK")) : 0;
-    // 128 x 320 tiles: 0 = off, 1 = only where the 256 x 160 tile gives < 2 blocks per CU, 2 = wherever they fit (default)
-    static const int wide_tile = getenv("QD_WIDE_TILE") ? atoi(getenv("QD_WIDE_TILE")) : 2;
     static const int wide_mink = getenv("QD_WIDE_MINK") ? atoi(getenv("QD_WIDE_MINK")) : 1280;
     static const int wide_minblk = getenv("QD_WIDE_MINBLK") ? atoi(getenv("QD_WIDE_MINBLK")) : 200;
     const long Ktot = (long)k.taps * d->seg[0].clen;
@@ -1626,8 +1618,7 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
         // members of a grouped launch take 128-row tiles: three times the blocks fill the chip anyway, and the smaller tile's
         // epilogue tail is shorter (heads_i8_out 1.82 -> 1.74 ms per SD evaluation, profiles/r06_group_ab.md)
         if (g_capture) return false;
-        if (force_mt) return force_mt == 2;
-        return Ktot >= mt2_mink && blocks(256, bn) >= 256;
+        return blocks(256, bn) >= 256;
     };
     if (w8) {                                      // int8 weights (CIFAR W8A8): 128-wide N tiles
         if (N > 64) {
@@ -1637,10 +1628,8 @@ int run(const qd_conv_desc* d, int32_t* iout, void* stream) {
             rc = dispatch<1, 2, 4, 1, 8>(k, split, out, st);
         }
     } else if (geglu) {
-        if (force_gmt == 2) rc = dispatch<2, 4, 4, 1>(k, split, out, st);
-        else rc = dispatch<1, 4, 4, 1>(k, split, out, st);
-    } else if (wide_tile && N % 320 == 0 && (out == O_F32 || out == O_F16) && !split && Ktot >= wide_mink && blocks(128, 320) >= wide_minblk &&
-               (wide_tile >= 2 || blocks(256, 160) < 2 * 256)) {
+        rc = dispatch<1, 4, 4, 1>(k, split, out, st);          // (256-row GEGLU tiles: measured slower, profiles/r05_c4_ab_summary.txt)
+    } else if (N % 320 == 0 && (out == O_F32 || out == O_F16) && !split && Ktot >= wide_mink && blocks(128, 320) >= wide_minblk) {
         // 2 x 2 waves of 64 x 160: a 128 x 320 block moves 18 KB per K-step into LDS for 40960 MACs per K element where the
         // 256 x 160 block of 4 x 1 waves moves 21 KB — the long-K convolutions are bound by exactly that L2 -> LDS traffic
         // (profiles/r02_igemm_kstep_ablation.md).  Measured (profiles/r02b_igemm_tiles.md): -5 .. -13 % on the 32 x 32 level
@@ -1705,8 +1694,7 @@ int run_bf16(const qd_conv_desc* d, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int N = d->Cout, out = d->out_dtype == QD_BF16 ? O_BF16 : d->out_dtype == QD_F16 ? O_F16 : O_F32;
     const long M = k.M;
-    static const int force_mt = getenv("QD_BF16_MT") ? atoi(getenv("QD_BF16_MT")) : 0;       // tuning knob: 1 / 2, 0 = heuristic
-    const bool mt2 = force_mt ? force_mt == 2 : ((M + 255) / 256) * ((N + 127) / 128) >= 256;
+    const bool mt2 = ((M + 255) / 256) * ((N + 127) / 128) >= 256;
     int rc;
     if (fh) {
         if (N > 64) rc = mt2 ? dispatch<2, 4, 4, 1, 17>(k, false, out, st) : dispatch<1, 4, 4, 1, 17>(k, false, out, st);
@@ -1792,13 +1780,12 @@ void launch_group(const ConvG& g, int n, hipStream_t st) {
 }
 
 // Up to three projections of ONE shape with head-layout epilogues as one launch (see igemm_heads_group_kernel); whatever does
-// not qualify — different shapes / tiles, another epilogue, a tile the group kernel is not built for, QD_QKV_GROUP=0 — runs as
+// not qualify — different shapes / tiles, another epilogue, a tile the group kernel is not built for — runs as
 // the n single launches it always was: same bytes either way.
 int run_group(const qd_conv_desc* const* descs, int n, void* stream) {
     QD_REQUIRE(descs && n >= 1 && n <= 3, "qd_conv2d_i8_group: 1..3 descriptors");
-    static const bool enabled = !(getenv("QD_QKV_GROUP") && atoi(getenv("QD_QKV_GROUP")) == 0);      // A/B knob
     GroupCapture cap[3];
-    bool ok = enabled && n >= 2;
+    bool ok = n >= 2;
     for (int i = 0; i < n && ok; ++i) {
         QD_REQUIRE(descs[i] != nullptr, "qd_conv2d_i8_group: null descriptor");
         g_capture = &cap[i];

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
-// The apply pass with U rows per thread (default U = 2 since round 3: -0.15 ms per SD evaluation, profiles/r03_first_call_ab.md; QD_GN_ROWS=0|2|4) — the U 16-byte loads of a thread
+// The apply pass with U rows per thread (default U = 2 since round 3: -0.15 ms per SD evaluation, profiles/r03_first_call_ab.md) — the U 16-byte loads of a thread
 // are issued back to back before any of them is used (more bytes in flight per wave: the one-row kernel streams at
 // 3.8 TB/s of the ~5.5 the HBM sustains), the per-(sample, channel) affine is fetched once per U rows.  fp32 input, 16-byte
 // aligned rows, no float output; U consecutive rows always belong to one sample (S % U == 0).  Same arithmetic per element.
@@ -749,9 +749,8 @@ static int groupnorm_impl(const void* x, int x_dtype, int64_t B, int64_t S, int 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nchunk_own = (int)((S + gn_rows(S) - 1) / gn_rows(S));
     const int vec = qd_aligned(x, x_dtype == QD_F32 ? 16 : 8) && ldx % 4 == 0;
-    // fp16 rows that take 16-byte (8-half) lanes; QD_F16_LINES=0 keeps the 4-halves-per-lane kernels (A/B knob)
-    static const bool f16_lines = !(getenv("QD_F16_LINES") && atoi(getenv("QD_F16_LINES")) == 0);
-    const bool vec8 = f16_lines && x_dtype == QD_F16 && qd_aligned(x, 16) && ldx % 8 == 0;      // C % 16 == 0 is required above
+    // fp16 rows that take 16-byte (8-half) lanes
+    const bool vec8 = x_dtype == QD_F16 && qd_aligned(x, 16) && ldx % 8 == 0;      // C % 16 == 0 is required above
     float* part = reinterpret_cast<float*>(ws);
     float* ab = part + (size_t)B * nchunk_own * C * 2;
     QD_REQUIRE(!part_in || (nchunk_in > 0 && (part_ld == 0 || part_ld >= C)), "qd_groupnorm_silu_quant: part_in needs nchunk_in > 0 and part_ld >= C");
@@ -788,14 +787,10 @@ static int groupnorm_impl(const void* x, int x_dtype, int64_t B, int64_t S, int 
     }
     long rows = B * S;
     long total = rows * (C / 4);
-    static const int gn_rows_knob = getenv("QD_GN_ROWS") ? atoi(getenv("QD_GN_ROWS")) : 2;       // rows per thread: 2 (default), 4, or 0 = the one-row kernel (A/B knob)
-    if ((gn_rows_knob == 2 || gn_rows_knob == 4) && x_dtype == QD_F32 && vec && out && !yout && S % gn_rows_knob == 0) {
-        const long tot = (rows / gn_rows_knob) * (C / 4);
+    if (x_dtype == QD_F32 && vec && out && !yout && S % 2 == 0) {       // two rows per thread (four measured no better, round 3)
+        const long tot = (rows / 2) * (C / 4);
         dim3 g2((unsigned)((tot + 255) / 256));
-        if (gn_rows_knob == 2)
-            hipLaunchKernelGGL(gn_apply_rows_kernel<2>, g2, dim3(256), 0, st, (const float*)x, rows, (long)S, C, (long)ldx, ab, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, rq);
-        else
-            hipLaunchKernelGGL(gn_apply_rows_kernel<4>, g2, dim3(256), 0, st, (const float*)x, rows, (long)S, C, (long)ldx, ab, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, rq);
+        hipLaunchKernelGGL(gn_apply_rows_kernel<2>, g2, dim3(256), 0, st, (const float*)x, rows, (long)S, C, (long)ldx, ab, apply_silu, qparams, (float)qmin, (float)qmax, off, out, (long)ldo, rq);
         QD_LAUNCH_CHECK("qd_groupnorm_silu_quant");
         return 0;
     }
@@ -858,9 +853,7 @@ extern "C" int qd_layernorm_quant(const void* x, int x_dtype, int64_t M, int C, 
     const int vec = qd_aligned(x, x_dtype == QD_F32 ? 16 : 8) && ldx % 4 == 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nvl = (C / 4 + 63) / 64;
-    static const bool f16_lines = !(getenv("QD_F16_LINES") && atoi(getenv("QD_F16_LINES")) == 0);
-    static const bool rows8 = !(getenv("QD_LN_ROWS8") && atoi(getenv("QD_LN_ROWS8")) == 0);      // A/B knob: 0 = the generic kernels at C = 320 too
-    if (rows8 && C == 320 && vec) {
+    if (C == 320 && vec) {
         dim3 grid((unsigned)((M + 31) / 32));
         if (x_dtype == QD_F32)
             hipLaunchKernelGGL((ln_quant_rows8_kernel<float, 10>), grid, dim3(256), 0, st, (const float*)x, (long)M, (long)ldx, eps, gamma, beta, nout, qp[0], qp[1], qp[2],
@@ -868,7 +861,7 @@ extern "C" int qd_layernorm_quant(const void* x, int x_dtype, int64_t M, int C, 
         else
             hipLaunchKernelGGL((ln_quant_rows8_kernel<__half, 10>), grid, dim3(256), 0, st, (const __half*)x, (long)M, (long)ldx, eps, gamma, beta, nout, qp[0], qp[1], qp[2],
                                mn, mx, of, o[0], o[1], o[2], (long)ldo);
-    } else if (f16_lines && x_dtype == QD_F16 && qd_aligned(x, 16) && ldx % 8 == 0 && C % 8 == 0 && C <= 64 * 8 * 3) {
+    } else if (x_dtype == QD_F16 && qd_aligned(x, 16) && ldx % 8 == 0 && C % 8 == 0 && C <= 64 * 8 * 3) {
         const int nv8 = (C / 8 + 63) / 64;
         if (nv8 == 1) launch_ln_h8<1>(st, x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, (long)ldo);
         else if (nv8 == 2) launch_ln_h8<2>(st, x, (long)M, C, (long)ldx, eps, gamma, beta, nout, qp, mn, mx, of, o, (long)ldo);
