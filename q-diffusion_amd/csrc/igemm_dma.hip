@@ -485,7 +485,11 @@ __device__ __forceinline__ void igemm_body(const ConvD& p, unsigned char* smem) 
     typedef typename std::conditional<WB == 4, uint2, v4i>::type braw_t;
     auto step = [&](unsigned cur, unsigned nxt) __attribute__((always_inline)) {
         wait_vmcnt<PER>();
-        __builtin_amdgcn_s_barrier();                  // stage `cur` landed for every wave; the stage before it is fully consumed
+        // stage `cur` landed for every wave; the stage before it is fully consumed.  (KS == 2: both K-groups meet here.  Letting each
+        // group meet on its own LDS counter — ds_add + a bounded s_sleep poll instead of s_barrier, so that the two waves of a SIMD run
+        // out of phase like two independent blocks — was built, bit-identical, and SLOWER: 84.6 -> 94.7 us on the 3 x 3 1280 -> 1280
+        // layer, 18.01 -> 18.31 ms per SD step, profiles/r06_c9_k2_group_counters_*.txt; deleted.)
+        __builtin_amdgcn_s_barrier();
         const unsigned char* cS = smem + cur;
         constexpr int S = 2 * NT;                      // (k-half, n-tile) MFMA groups of this step
         auto bread = [&](int s) __attribute__((always_inline)) {
