@@ -113,6 +113,33 @@ def test_shard_bounds_cover_batch():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_sharded_step_noise_reproduces_the_single_process_draws():
+    """eta > 0 (LDM-4 LSUN-beds, README.md:47-49 `-e 1.0`): the reference draws `noise_like(x.shape)` = randn of the WHOLE batch at
+    every step (ddim.py:216).  ShardedStepNoise on R ranks: every rank draws the full batch from an identically seeded generator
+    and keeps its slice — concatenated over the ranks, every step's noise equals the single-process draw bit for bit, and a DDIM
+    run with it as `noise_fn` equals the unsharded run on each rank's samples."""
+    from qdiff import sampling
+    gb, shape, steps = 10, (3, 8, 8), 4
+    g = torch.Generator().manual_seed(4321)
+    want = [torch.randn((gb,) + shape, generator=g) for _ in range(steps)]
+    for world in (1, 2, 3, 8):
+        ranks = [sampling.ShardedStepNoise(gb, shape, 4321, world, r, "cpu") for r in range(world)]
+        for s in range(steps):
+            got = torch.cat([n() for n in ranks])
+            assert torch.equal(got, want[s]), (world, s)
+    # through the sampler: a stand-in eps model that mixes nothing across samples
+    table = sampling.StepTable(sampling.ldm_betas(0.0015, 0.0195), 5, eta=1.0)
+    unet = lambda x, t, c=None: torch.tanh(x) * 0.3 + 0.01 * t.view(-1, 1, 1, 1).float() / 1000
+    x_T = sampling.sharded_noise((gb,) + shape, 0, 1, 0, torch.device("cpu"))
+    full = sampling.ddim_sample(unet, x_T, table, noise_fn=sampling.ShardedStepNoise(gb, shape, 99, 1, 0, "cpu"))
+    for world in (2, 3):
+        parts = []
+        for r in range(world):
+            lo, hi = sampling.shard_bounds(gb, world, r)
+            parts.append(sampling.ddim_sample(unet, x_T[lo:hi], table, noise_fn=sampling.ShardedStepNoise(gb, shape, 99, world, r, "cpu")))
+        assert torch.equal(torch.cat(parts), full), world
+
+
 def _worker8(rank, world, port, gb, out_dir):
     """One of the 8 ranks of `bench.py --gpus 8`'s shard arithmetic (no model): the full-batch noise drawn on every rank and
     sliced, a rank-dependent "sampler", the all_gather of the results."""
