@@ -28,11 +28,20 @@ struct TembLayer {
     int Cout, out_off;
 };
 
+// Round 6: grid = (blocks, row groups).  The (layer, 64-channel) blocks of the 22 embedding projections number 40 .. 80 — a
+// quarter of the CUs, one wave per SIMD each, every block quantising ALL rows for itself (SiLU + the exact division: the bulk
+// of its time).  blockIdx.y now selects a slice of `rpb` rows: the same work per row, spread over the idle CUs (rows are
+// independent: same bytes).
 template <int WB, int RB>   // RB = rows per pass (accumulators per thread)
-__global__ __launch_bounds__(256) void temb_kernel(const float* __restrict__ x, long ldx, int B, int K, int silu,
+__global__ __launch_bounds__(256) void temb_kernel(const float* __restrict__ x, long ldx, int Btot, int rpb, int K, int silu,
                                                    const TembLayer* __restrict__ layers, const int2* __restrict__ blocks,
                                                    float qmin, float qmax, int off, float* __restrict__ out, long ldo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int b_first = blockIdx.y * rpb;
+    const int B = min(rpb, Btot - b_first);
+    if (B <= 0) return;
+    x += (long)b_first * ldx;
+    out += (long)b_first * ldo;
     int8_t* codes = reinterpret_cast<int8_t*>(sm);                       // [B][K]
     int* sAsum = reinterpret_cast<int*>(sm + (size_t)B * K);              // [B]
     int* sRed = sAsum + ((B + 3) & ~3);                                   // [4 parts][RB][64]
@@ -140,15 +149,21 @@ extern "C" int qd_temb_mlp(const float* x, int64_t ldx, int B, int K, int apply_
     QD_REQUIRE(wbits == 4 || wbits == 8, "qd_temb_mlp: wbits must be 4 or 8");
     QD_REQUIRE(ldx % 4 == 0 && qd_aligned(x, 16), "qd_temb_mlp: x rows must be 16-byte aligned");
     constexpr int RB = 16;
-    const size_t lds = (size_t)B * K + (size_t)((B + 3) & ~3) * 4 + 4 * RB * 64 * 4;
-    QD_REQUIRE(lds <= 64 * 1024, "qd_temb_mlp: B * K = %ld does not fit LDS (call it on at most %d rows at a time)", (long)B * K, (int)((64 * 1024 - 20000) / K));
+    // row groups: enough that the launch has about two blocks per CU, at least 4 rows each
+    int groups = 512 / n_blocks;
+    if (groups > (B + 3) / 4) groups = (B + 3) / 4;
+    if (groups < 1) groups = 1;
+    const int rpb = (B + groups - 1) / groups;
+    groups = (B + rpb - 1) / rpb;
+    const size_t lds = (size_t)rpb * K + (size_t)((rpb + 3) & ~3) * 4 + 4 * RB * 64 * 4;
+    QD_REQUIRE(lds <= 64 * 1024, "qd_temb_mlp: %d rows x K = %d do not fit LDS (call it on at most %d rows at a time)", rpb, K, (int)((64 * 1024 - 20000) / K));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const auto* L = reinterpret_cast<const TembLayer*>(layers);
     const auto* bl = reinterpret_cast<const int2*>(blocks);
     if (wbits == 4)
-        hipLaunchKernelGGL((temb_kernel<4, RB>), dim3(n_blocks), dim3(256), lds, st, x, (long)ldx, B, K, apply_silu, L, bl, (float)qmin, (float)qmax, off, out, (long)ldo);
+        hipLaunchKernelGGL((temb_kernel<4, RB>), dim3(n_blocks, groups), dim3(256), lds, st, x, (long)ldx, B, rpb, K, apply_silu, L, bl, (float)qmin, (float)qmax, off, out, (long)ldo);
     else
-        hipLaunchKernelGGL((temb_kernel<8, RB>), dim3(n_blocks), dim3(256), lds, st, x, (long)ldx, B, K, apply_silu, L, bl, (float)qmin, (float)qmax, off, out, (long)ldo);
+        hipLaunchKernelGGL((temb_kernel<8, RB>), dim3(n_blocks, groups), dim3(256), lds, st, x, (long)ldx, B, rpb, K, apply_silu, L, bl, (float)qmin, (float)qmax, off, out, (long)ldo);
     QD_LAUNCH_CHECK("qd_temb_mlp");
     return 0;
 }
