@@ -150,7 +150,7 @@ extern "C" int qd_temb_mlp(const float* x, int64_t ldx, int B, int K, int apply_
     QD_REQUIRE(ldx % 4 == 0 && qd_aligned(x, 16), "qd_temb_mlp: x rows must be 16-byte aligned");
     constexpr int RB = 16;
     // row groups: enough that the launch has about two blocks per CU, at least 4 rows each
-    int groups = 512 / n_blocks;
+    int groups = (512 + n_blocks - 1) / n_blocks;
     if (groups > (B + 3) / 4) groups = (B + 3) / 4;
     if (groups < 1) groups = 1;
     const int rpb = (B + groups - 1) / groups;
