@@ -512,6 +512,9 @@ ATTN_CASES = [
     ("sd_qpos_zq-128", 2, 8, 200, 77, 40, 16, False, 40 ** -0.5),
     # SD's 1024-token level on the register-fed lean kernel with three K slabs (d = 80 padded to 96) and the key-term table
     ("sd_self_d80_1024", 1, 8, 1024, 1024, 80, 16, False, 80 ** -0.5),
+    # diffuse rows under a fine probability grid (codes ~300 of 1024 keys, a few rows above the grid: clamped): the per-query
+    # code shift with signed hi bytes and the per-tile hi skip of attn_pv_kernel, held to the oracle directly
+    ("sd_self_flatgrid_1024", 1, 4, 256, 1024, 40, 16, False, 40 ** -0.5),
 ]
 # LSUN-Churches LDM-8 (8 heads on 192 / 384 / 768 channels: head dims 24 / 48 / 96, 8-bit operands — asymmetric as the
 # README runs this model, one symmetric case — 8-bit probabilities, tokens 1024 .. 4): the lean kernel's 8-bit-probability
@@ -540,6 +543,8 @@ def test_attention_fused(cuda, case):
     pre = (d ** -0.25) if name.startswith("ldm") else 1.0
     if "qpos" in name:
         q = q.abs()
+    if "flatgrid" in name:
+        q = q * 0.25
 
     def mk(t, n_bits=8, s=sym, always_zero=False):
         dd, zz = R.uaq_init_scale(t, n_bits, s, False, "max", always_zero)
@@ -553,6 +558,8 @@ def test_attention_fused(cuda, case):
         p = sim.softmax(-1)
     w_sym = sym if name.startswith("cifar") else False
     aq_w = mk(p, smb, w_sym, always_zero=not name.startswith("cifar"))
+    if "flatgrid" in name:
+        aq_w["delta"] = torch.tensor(1.0 / (S * 300.0))
     want_int, _ = R.attention_int(heads(q, T), heads(k, S), heads(v, S), scale, aq_q, aq_k, aq_v, aq_w, pre_scale=pre)
     want_fq = R.attention_fq(heads(q, T), heads(k, S), heads(v, S), scale, aq_q, aq_k, aq_v, aq_w, pre_scale=pre)
     ns = lambda a: NS(delta=a["delta"], zero_point=a["zero_point"], n_bits=a["n_bits"], sym=a["sym"])
@@ -746,6 +753,14 @@ PIPE_CASES = [
     ("octaves_repeat", 1, 2, 256,  512,  40, 16, False, False, "huge"),    # the row maximum rises > 64 octaves after tile 0: repeat pass
     ("d80_three_slabs", 2, 4, 160, 544,  80, 16, False, False, True),      # dpad 96: register-fed kernel in both modes; table vs constant-operand MFMAs
     ("d80_zq-128",     1, 4, 96,  77,   80, 16, False, True,  False),
+    # round 6: rows whose codes reach 256 are shifted per query (signed hi byte, hi MFMAs skipped per tile when every shifted code
+    # of the wave's tile fits the lo byte).  flatmix: head 0 peaked (codes up to 65535: shifted by -32768), the others diffuse at
+    # three widths (all tiles skip / some tiles carry codes below the lo byte's window / too wide for the flat rule), ragged S;
+    # flatgrid: every row diffuse under a probability grid 220 x finer than the data needs (codes ~300 of 4096 keys; the few
+    # rows that exceed the grid take the clamped body with the shift)
+    ("flatmix",        2, 4, 128,  237,  40, 16, False, False, "flatmix"),
+    ("flatgrid_4096",  1, 2, 256,  4096, 40, 16, False, False, "flatgrid"),
+    ("flatgrid_tail",  1, 4, 160,  1000, 40, 16, False, False, "flatgrid"),
 ]
 
 
@@ -764,6 +779,13 @@ def test_attention_lds_equals_lean(cuda, case):
     if peaky == "huge":
         q, k = q * 6.0, k * 6.0
         k[:, :40] *= 0.02                        # small scores in the first key tile, large ones later
+    elif peaky == "flatmix":
+        qh = q.view(B, T, H, d)
+        qh[:, :, 0] *= 4.0
+        for h, f in ((1, 0.05), (2, 0.3), (3, 0.8)):
+            qh[:, :, h] *= f
+    elif peaky == "flatgrid":
+        q = q * 0.25
     elif peaky:
         q, k = q * 3.0, k * 3.0
 
@@ -773,7 +795,10 @@ def test_attention_lds_equals_lean(cuda, case):
     heads = lambda t, L: t.view(B, L, H, d).permute(0, 2, 1, 3).reshape(B * H, L, d)
     scale = d ** -0.5
     p = (torch.einsum("bid,bjd->bij", heads(q, T), heads(k, S)) * scale).softmax(-1)
-    ap = engine.build_attn_plan(mk(q, 8, qsym), mk(k, 8, qsym), mk(v, 8, qsym), mk(p, smb, False, True), scale, 1.0, cuda)
+    aw = mk(p, smb, False, True)
+    if peaky == "flatgrid":
+        aw.delta = torch.tensor(1.0 / (S * 300.0))             # the mean probability 1 / S has code 300
+    ap = engine.build_attn_plan(mk(q, 8, qsym), mk(k, 8, qsym), mk(v, 8, qsym), aw, scale, 1.0, cuda)
     Tp, Sp, dp = engine.pad32(T), engine.pad32(S), engine.pad32(d)
     q8 = torch.zeros((B * H, Tp, dp), dtype=torch.int8, device=cuda)
     k8 = torch.zeros((B * H, Sp, dp), dtype=torch.int8, device=cuda)
