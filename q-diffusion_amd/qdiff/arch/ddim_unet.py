@@ -56,9 +56,8 @@ class Upsample(nn.Module):
     def forward(self, x, out_slot=None):
         if self.with_conv:
             from .. import engine, quant_block as qb
-            from .ldm_unet import UPSAMPLE_FOLD
             conv = self.conv
-            if (UPSAMPLE_FOLD and isinstance(conv, qb.QuantModule) and qb._int_mode(conv) and conv.split == 0
+            if (isinstance(conv, qb.QuantModule) and qb._int_mode(conv) and conv.split == 0
                     and conv.act_quantizer.inited and not conv.act_quantizer.running_stat and x.dim() == 4):
                 # quantisation commutes with nearest-neighbour replication, and the replication itself is folded into the
                 # convolution's im2col gather (qd_conv_desc.upsample2x): quantise the SMALL map, convolve its up-sampling

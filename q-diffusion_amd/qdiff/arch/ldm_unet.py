@@ -6,7 +6,6 @@ feed-forward), written for this engine (2-D only, channels-last activations).
 Unquantised definitions; qdiff.QuantModel rewrites them (quant_model.py / quant_block.py).
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -17,7 +16,6 @@ import torch.nn.functional as F
 # small pieces (reference ldm/modules/diffusionmodules/util.py)
 # ------------------------------------------------------------------------------------------------
 _FREQ_CACHE = {}
-UPSAMPLE_FOLD = os.environ.get("QDIFF_UPSAMPLE_FOLD", "1") != "0"   # A/B knob: nearest-2x folded into the conv gather
 
 
 def timestep_embedding(timesteps, dim, max_period=10000, repeat_only=False):
@@ -255,7 +253,7 @@ class Upsample(nn.Module):
                 rows = qb._nhwc_rows(x)
                 plan = conv.conv_plan()
                 xq = engine.quantize_rows(rows, plan, 1, c, b * h * w, (0, 1, rows.stride(0)))
-                if UPSAMPLE_FOLD and engine.upsample_fold_ok(plan, 2 * h, 2 * w):
+                if engine.upsample_fold_ok(plan, 2 * h, 2 * w):
                     # the replication is folded into the convolution's im2col gather: the kernel reads the small map
                     out = conv.forward_codes(xq, b, 2 * h, 2 * w, gn_stats=True, slot=out_slot, upsample2x=True)
                     return qb._rows_to_nchw(out, b, 2 * h, 2 * w)

@@ -160,8 +160,6 @@ def _linear_rows(lin, rows, residual=None, gn_stats=False, slot=None):
     return engine.conv_forward(plan, xq, 1, 1, M, 1, M, residual=residual, gn_stats=gn_stats, slot=slot)
 
 
-# A/B knob for measurements only (tools/r02_ab.sh): "0" evaluates the embedding projections layer by layer
-_TEMB_FUSION = os.environ.get("QDIFF_TEMB_FUSION", "1") != "0"
 
 
 class EmbGroup:
@@ -195,7 +193,7 @@ class EmbGroup:
 
     def _compute(self, emb):
         lins = [l for _, l in self.members]
-        if not _TEMB_FUSION or not torch.is_tensor(emb) or emb.dim() != 2 or not emb.is_floating_point() or len(lins) < 2:
+        if not torch.is_tensor(emb) or emb.dim() != 2 or not emb.is_floating_point() or len(lins) < 2:
             return
         if not _int_mode(*lins) or any(l.split or l.kind != 'linear' or not l.act_quantizer.inited for l in lins):
             return
@@ -215,7 +213,6 @@ class EmbGroup:
         self._out = out
 
 
-_CTX_BRANCH = os.environ.get("QDIFF_CTX_BRANCH", "1") != "0"     # A/B knob for measurements only
 # where the context branch forks off the main stream: "start" = the model's forward pre-hook (before the stem), "attn" = right
 # before the first self-attention kernel of the first transformer block, "late" = at the first cross-attention (= its join)
 _CTX_FORK = os.environ.get("QDIFF_CTX_FORK", "start")
@@ -226,9 +223,11 @@ _CTX_PIN = os.environ.get("QDIFF_CTX_PIN", "1") != "0"
 # (default: QuantModel.forward prepares a context it has not seen — the unmodified reference samplers never announce theirs)
 _CTX_PINS = max(1, int(os.environ.get("QDIFF_CTX_PINS", "2")))
 _CTX_AUTO = os.environ.get("QDIFF_CTX_AUTO", "1") != "0"
-_FUSE_SKIP_QUANT = os.environ.get("QDIFF_FUSE_SKIP_QUANT", "1") != "0"     # A/B knob: skip-connection rows from the GroupNorm pass
-QKV_HEADS = os.environ.get("QDIFF_QKV_HEADS", "1") != "0"         # A/B knob: the LDM AttentionBlock's qkv as three GEMMs with operand epilogues; q / k / v of the DDIM AttnBlock likewise
-CAT_SLOTS = os.environ.get("QDIFF_CAT_SLOTS", "1") != "0"         # A/B knob: planned skip-concatenation buffers (engine.CatSlot)
+# Switches of the equality tests (tests/test_host_logic.py, tests/test_engine_models.py compare both sides in one process); no
+# environment variable selects them.
+_FUSE_SKIP_QUANT = True     # skip-connection rows from the GroupNorm pass
+QKV_HEADS = True            # the LDM AttentionBlock's qkv as three GEMMs with operand epilogues; q / k / v of the DDIM AttnBlock likewise
+CAT_SLOTS = True            # planned skip-concatenation buffers (engine.CatSlot)
 
 
 class ContextKV:
@@ -436,7 +435,7 @@ class ContextKV:
         return self._out[id(blk)]
 
     def _ready(self, context):
-        if not _CTX_BRANCH or not torch.is_tensor(context) or context.dim() != 3 or len(self.members) < 2:
+        if not torch.is_tensor(context) or context.dim() != 3 or len(self.members) < 2:
             return False
         mods = [m for blk in self.members for m in (blk.attn2.to_k, blk.attn2.to_v)]
         if not _int_mode(*mods) or any(m.split or not m.act_quantizer.inited for m in mods):
@@ -502,7 +501,7 @@ class ContextKV:
 def time_mlp(lin0, lin1, t_emb, act=F.silu):
     """`Linear -> SiLU -> Linear` on the sinusoid table (reference openaimodel.py:758-759 `time_embed`, ddim
     diffusion.py:318-320): two K6 launches on the integer path, the plain composition otherwise."""
-    if (_TEMB_FUSION and _int_mode(lin0, lin1) and lin0.kind == 'linear' and lin1.kind == 'linear' and not (lin0.split or lin1.split)
+    if (_int_mode(lin0, lin1) and lin0.kind == 'linear' and lin1.kind == 'linear' and not (lin0.split or lin1.split)
             and lin0.act_quantizer.inited and lin1.act_quantizer.inited and torch.is_tensor(t_emb) and t_emb.dim() == 2):
         p0, p1 = lin0.conv_plan(), lin1.conv_plan()
         if len(p0.segs) == 1 and len(p1.segs) == 1:
