@@ -693,11 +693,7 @@ __device__ __forceinline__ void igemm_body(const ConvD& p, unsigned char* smem) 
                     const v2f vi = {(float)(acc[i][2 * jp][r] - zcv - __mul24(zwv, as0)), (float)(acc[i][2 * jp][r + 1] - zcv - __mul24(zwv, as1))};
                     const v2f gi = {(float)(acc[i][2 * jp + 1][r] - zcg - __mul24(zwg, as0)), (float)(acc[i][2 * jp + 1][r + 1] - zcg - __mul24(zwg, as1))};
                     const v2f val = qd_fma2(vi, qd_splat2(sv), qd_splat2(bv)), gate = qd_fma2(gi, qd_splat2(sgt), qd_splat2(bg));
-#ifdef QD_ABL_NOERF
-                    const v2f y = val * (qd_splat2(0.5f) * gate * (qd_splat2(1.0f) + gate * qd_splat2(0.70710678118654752440f)));
-#else
                     const v2f y = val * (qd_splat2(0.5f) * gate * (qd_splat2(1.0f) + qd_erff2(gate * qd_splat2(0.70710678118654752440f))));
-#endif
                     int b0, b1;
                     qd_bytes2_t<FAST>(y, oqp, oqb, b0, b1);
                     tb8[rl0 * ROWB + jp * 32 + frow] = (int8_t)b0;
