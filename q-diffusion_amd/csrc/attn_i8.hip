@@ -831,6 +831,9 @@ __device__ __forceinline__ void attn_qk(const v4i (&kf)[DT], const v4i (&qf)[DT]
 #ifndef QD_ATTN_PVFULL_OCC
 #define QD_ATTN_PVFULL_OCC 3                                  // ... the hi + lo P.V kernel (<= 168 VGPRs)
 #endif
+// hi + lo P.V kernel: vector instructions between two of the previous tile's P.V MFMAs (measured on one box, us per 4096-token call:
+// undeferred 961, all six MFMAs of a tile in one cluster 961, 8 / 15 / 22 instructions apart 940 / 935 / 940 — r06_c18)
+constexpr int QD_ATTN_PV_DEFER_VALU = 15;
 
 template <int DT, int KT>
 __global__ __launch_bounds__(256, QD_ATTN_STATS_OCC) void attn_stats_kernel(const AttnK p, AttnStat* __restrict__ stat, int* __restrict__ blkflag, int p16) {
@@ -1006,20 +1009,11 @@ __global__ __launch_bounds__(256, FULL ? QD_ATTN_PVFULL_OCC : QD_ATTN_PV_OCC) vo
         // (lo bytes only, no clamp: the operand byte is code - 128 = code ^ 0x80 for codes < 256, i.e. the low byte of code + 128 —
         //  the 128 rides in the FMA's constant (even, like MAGIC: ties still go to the even code) and the v_xor disappears)
         const v2f ubm128 = {ubias + MAGIC + 128.f, ubias + MAGIC + 128.f};
-        auto tile = [&](int jt, auto tail_tag, auto clamp_tag, auto hi_tag, auto st_tag) __attribute__((always_inline)) {
+        // the probability chain of one 32 x 32 score tile: 16 accumulators of this lane -> four operand words of lo (and hi) bytes
+        auto chain = [&](const v16i& acc, int jt, auto tail_tag, auto clamp_tag, auto hi_tag, v4i& plo, v4i& phi) __attribute__((always_inline)) {
             constexpr bool tail = decltype(tail_tag)::value, CLAMP = decltype(clamp_tag)::value, HI = decltype(hi_tag)::value;
-            constexpr int ST = decltype(st_tag)::value;
             constexpr bool BIAS128 = !tail && !CLAMP && !HI;
-            v4i kf[DT], vf[DT];
-            v16i acc;
-            ring.template step_sync<ST>(jt);
-            ring.template read_k<ST>(jt, kf);
-            ring.template read_t<ST>(jt, acc);
-            ring.template read_v<ST>(jt, vf);
-            __builtin_amdgcn_sched_barrier(0);                 // every fragment read of the tile is in flight before the score chain starts
-            attn_qk<DT, KT>(kf, qf, acc);
             unsigned ub[16];
-            v4i plo, phi;
 #pragma unroll
             for (int sidx = 0; sidx < 8; ++sidx) {
                 const int r = 2 * sidx;
@@ -1050,22 +1044,94 @@ __global__ __launch_bounds__(256, FULL ? QD_ATTN_PVFULL_OCC : QD_ATTN_PV_OCC) vo
                     if (HI) phi[g] = (int)(__builtin_amdgcn_perm(a23, a01, 0x07060302u) ^ 0x80808080u);
                 }
             }
+        };
+        auto tile = [&](int jt, auto tail_tag, auto clamp_tag, auto hi_tag, auto st_tag, bool met = false) __attribute__((always_inline)) {
+            constexpr bool tail = decltype(tail_tag)::value, CLAMP = decltype(clamp_tag)::value, HI = decltype(hi_tag)::value;
+            constexpr int ST = decltype(st_tag)::value;
+            v4i kf[DT], vf[DT];
+            v16i acc;
+            if (!met) ring.template step_sync<ST>(jt);
+            ring.template read_k<ST>(jt, kf);
+            ring.template read_t<ST>(jt, acc);
+            ring.template read_v<ST>(jt, vf);
+            __builtin_amdgcn_sched_barrier(0);                 // every fragment read of the tile is in flight before the score chain starts
+            attn_qk<DT, KT>(kf, qf, acc);
+            v4i plo, phi;
+            chain(acc, jt, tail_tag, clamp_tag, hi_tag, plo, phi);
 #pragma unroll
             for (int t = 0; t < DT; ++t) {
                 ol[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(plo, vf[t], ol[t], 0, 0, 0);
                 if (HI) oh[HIK ? t : 0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(phi, vf[t], oh[HIK ? t : 0], 0, 0, 0);
             }
         };
+        // The P.V MFMAs of tile j are issued inside tile j+1: the first right behind the score MFMAs (the wave waits for the scores
+        // anyway), the others each behind a quarter of tile j+1's probability chain — a wave never queues an MFMA behind its own
+        // four, and the matrix pipe works under the vector work of the same wave (sched_group_barrier pins the pattern).
+        struct PVOps { v4i plo, phi; v4i vf[DT]; };
+        PVOps ops[2];
+        auto pv_all = [&](const PVOps& o, auto hi_tag) __attribute__((always_inline)) {
+            constexpr bool HI = decltype(hi_tag)::value;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) ol[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.plo, o.vf[t], ol[t], 0, 0, 0);
+            if (HI) {
+#pragma unroll
+                for (int t = 0; t < DT; ++t) oh[HIK ? t : 0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.phi, o.vf[t], oh[HIK ? t : 0], 0, 0, 0);
+            }
+        };
+        auto tileP = [&](int jt, auto clamp_tag, auto hi_tag, auto st_tag, PVOps& cur, const PVOps& prev, auto prev_tag) __attribute__((always_inline)) {
+            constexpr bool HI = decltype(hi_tag)::value, HASP = decltype(prev_tag)::value;
+            constexpr int ST = decltype(st_tag)::value;
+            constexpr int NPV = HASP ? DT * (HI ? 2 : 1) : 0;
+            v4i kf[DT];
+            v16i acc;
+            __builtin_amdgcn_sched_barrier(0);                 // the previous tile's chain stays on its side
+            if (!HASP) ring.template step_sync<ST>(jt);        // (the first tile; every later one was met by its predecessor)
+            ring.template read_k<ST>(jt, kf);
+            ring.template read_t<ST>(jt, acc);
+            ring.template read_v<ST>(jt, cur.vf);
+            // the rendezvous for the NEXT tile right behind this tile's fragment reads (where hipcc hoists it to in the undeferred
+            // body): a wave waits for the others' reads, not for their vector work
+            ring.template step_sync<(ST + 1) & 3>(jt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            attn_qk<DT, KT>(kf, qf, acc);
+            if (HASP) pv_all(prev, hi_tag);
+            chain(acc, jt, std::false_type{}, clamp_tag, hi_tag, cur.plo, cur.phi);
+            // the pattern of this region: [score MFMAs + the first deferred one] then a quarter of the chain per further MFMA
+            __builtin_amdgcn_sched_group_barrier(0x008, DT + (NPV > 0 ? 1 : 0), 0);
+#pragma unroll
+            for (int i = 1; i < NPV; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x002, QD_ATTN_PV_DEFER_VALU, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x002, 96, 0);
+            // the operand words are consumed one tile later: without a use HERE the optimiser sinks the whole chain down to that use,
+            // i.e. behind the next rendezvous and its fragment reads, and the MFMAs are alone again
+            asm volatile("" : "+v"(cur.plo));
+            if (HI) asm volatile("" : "+v"(cur.phi));
+        };
         auto run = [&](auto clamp_tag, auto hi_tag) __attribute__((always_inline)) {
             int jt = 0;
-            for (; jt + 4 <= nfull; jt += 4) {                 // four tiles = one turn of the ring: stage offsets are immediates
+            bool met = false;
+            if (FULL && nfull >= 5) {
+                using std::integral_constant;
+                tileP(0, clamp_tag, hi_tag, integral_constant<int, 0>{}, ops[0], ops[1], std::false_type{});
+                for (jt = 1; jt + 4 <= nfull; jt += 4) {       // tiles 1 .. : stage and operand set are compile-time again
+                    tileP(jt, clamp_tag, hi_tag, integral_constant<int, 1>{}, ops[1], ops[0], std::true_type{});
+                    tileP(jt + 1, clamp_tag, hi_tag, integral_constant<int, 2>{}, ops[0], ops[1], std::true_type{});
+                    tileP(jt + 2, clamp_tag, hi_tag, integral_constant<int, 3>{}, ops[1], ops[0], std::true_type{});
+                    tileP(jt + 3, clamp_tag, hi_tag, integral_constant<int, 0>{}, ops[0], ops[1], std::true_type{});
+                }
+                pv_all(ops[0], hi_tag);                        // the last deferred tile; what is left of the key axis runs undeferred
+                met = true;                                    // ... and tile jt has been met
+            }
+            for (; jt + 4 <= nfull && (jt & 3) == 0; jt += 4) {                 // four tiles = one turn of the ring: stage offsets are immediates
                 tile(jt, std::false_type{}, clamp_tag, hi_tag, std::integral_constant<int, 0>{});
                 tile(jt + 1, std::false_type{}, clamp_tag, hi_tag, std::integral_constant<int, 1>{});
                 tile(jt + 2, std::false_type{}, clamp_tag, hi_tag, std::integral_constant<int, 2>{});
                 tile(jt + 3, std::false_type{}, clamp_tag, hi_tag, std::integral_constant<int, 3>{});
             }
-            for (; jt < nfull; ++jt) tile(jt, std::false_type{}, clamp_tag, hi_tag, std::integral_constant<int, -1>{});
-            if (nfull < ntile) tile(nfull, std::true_type{}, std::true_type{}, hi_tag, std::integral_constant<int, -1>{});
+            for (; jt < nfull; ++jt, met = false) tile(jt, std::false_type{}, clamp_tag, hi_tag, std::integral_constant<int, -1>{}, met);
+            if (nfull < ntile) tile(nfull, std::true_type{}, std::true_type{}, hi_tag, std::integral_constant<int, -1>{}, met);
         };
         if constexpr (FULL) {
             if (need_clamp) run(std::true_type{}, std::integral_constant<bool, P16>{});
