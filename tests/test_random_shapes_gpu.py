@@ -1,0 +1,165 @@
+"""Seeded random shapes through the contraction and the attention entry points (GPU).
+
+The parametrised tests of test_hip_kernels.py pin the shapes the three UNets launch; this file walks the space between them:
+every draw is checked against the CPU oracle (exact int32 accumulators; fp32 rows within the stated bound) AND across the
+launch variants the library chooses between (four-wave block vs two K-groups, split-K vs one pass, register-fed vs LDS-staged
+attention), which must agree bit for bit.  Seeds are fixed: a failure names its draw.
+"""
+import random
+from types import SimpleNamespace as NS
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import quant_ref as R
+from test_hip_kernels import _aq, _codes, _weight_quantizer
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv_draws(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        k = rng.choice([1, 1, 3, 3, 3])
+        wbits = rng.choice([4, 4, 8])
+        H = rng.choice([4, 7, 8, 12, 16, 16, 24, 32])
+        B = rng.choice([1, 2, 3, 4, 8])
+        Cin = 8 * rng.randint(1, 96) if rng.random() < 0.6 else rng.choice([128, 192, 224, 256, 320, 448, 640, 960, 1280])
+        Cout = rng.choice([8 * rng.randint(1, 60), 64, 128, 160, 224, 256, 320, 448, 640])
+        if B * H * H * Cin * k * k > 6_000_000:          # keep the oracle's integer convolution in seconds
+            B, H = 1, min(H, 16)
+        stride = 2 if (k == 3 and H % 2 == 0 and rng.random() < 0.2) else 1
+        out.append((i, B, Cin, H, Cout, k, wbits, rng.random() < 0.3, rng.random() < 0.5, rng.random() < 0.5, stride))
+    return out
+
+
+CONV_DRAWS = _conv_draws(150, 20260930)
+
+
+@pytest.mark.parametrize("draw", CONV_DRAWS, ids=[f"conv{d[0]}_B{d[1]}_C{d[2]}_H{d[3]}_N{d[4]}_k{d[5]}_w{d[6]}_s{d[10]}" for d in CONV_DRAWS])
+def test_random_conv_shapes(cuda, draw):
+    from qdiff import engine, hip
+    i, B, Cin, H, Cout, k, wbits, a_sym, with_rowbias, with_residual, stride = draw
+    g = torch.Generator().manual_seed(1000 + i)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    x = x if a_sym else F.silu(x)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
+    bias = torch.randn(Cout, generator=g)
+    q = _weight_quantizer(w, wbits, True, g)
+    d, z = R.uaq_init_scale(x, 8, a_sym, False, "max")
+    aq = _aq(d, z, 8, a_sym)
+    pack = engine.pack_module_weights(w.to(cuda), [q], 0)
+    plan = engine.build_conv_plan(pack, [aq], k, k, stride, k // 2, bias.to(cuda))
+    Ho, _ = engine.conv_out_hw(H, H, plan)
+    M = B * Ho * Ho
+    xq = engine.quantize_rows(x.to(cuda), plan, B, Cin, H * H, (Cin * H * H, H * H, 1))
+    rowbias = torch.randn(B, Cout, generator=g).to(cuda) if with_rowbias else None
+    residual = torch.randn(M, Cout, generator=g).to(cuda) if with_residual else None
+
+    # 1. exact int32 accumulators against the integer oracle
+    acc = torch.zeros((M, Cout), dtype=torch.int32, device=cuda)
+    engine.conv_forward(plan, xq, B, H, H, acc_out=acc)
+    torch.cuda.synchronize()
+    xc = R.uaq_codes(x, aq.delta, aq.zero_point, 8, a_sym)
+    want_acc = R.int_conv_exact(xc, int(z), _codes(w, q), q.zero_point.reshape(-1).long(), "conv2d", dict(stride=stride, padding=k // 2))
+    got_acc = acc.cpu().view(B, Ho, Ho, Cout).permute(0, 3, 1, 2).long()
+    assert torch.equal(got_acc, want_acc), f"accumulators: max |diff| = {(got_acc - want_acc).abs().max().item()}"
+
+    # 2. fp32 rows: every launch variant the library may pick produces the same bytes ...
+    outs = {}
+    try:
+        for kg in (1, 0):
+            for sk in (None, False):
+                hip.conv_config(kgroups=kg)
+                kw = {} if sk is None else dict(splitk=False)
+                o = engine.conv_forward(plan, xq, B, H, H, rowbias=rowbias, residual=residual, **kw)
+                torch.cuda.synchronize()
+                outs[(kg, sk)] = o.clone()
+    finally:
+        hip.conv_config(kgroups=1)
+    ref = outs[(0, False)]
+    assert torch.isfinite(ref).all()
+    for key, o in outs.items():
+        if key[1] is False:
+            assert torch.equal(o, ref), key                                     # K-groups: integer adds commute
+        else:
+            assert (o - ref).abs().max().item() <= 1e-6 * ref.abs().max().item(), key     # split-K finalise: one fp32 expression, other association
+
+    # ... 3. and they are the reference's fake-quantised layer within the fp32 bound of test_conv_fp32_matches_fake_quant
+    want = R.quant_module_forward(x, w, bias, "conv2d", dict(stride=stride, padding=k // 2),
+                                  [dict(delta=q.delta, zero_point=q.zero_point, alpha=q.alpha, n_levels=q.n_levels)],
+                                  [dict(delta=aq.delta, zero_point=z, n_bits=8, sym=a_sym)])
+    if rowbias is not None:
+        want = want + rowbias.cpu()[:, :, None, None]
+    if residual is not None:
+        want = want + residual.cpu().view(B, Ho, Ho, Cout).permute(0, 3, 1, 2)
+    got = ref.cpu().view(B, Ho, Ho, Cout).permute(0, 3, 1, 2)
+    assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item() + 1e-6
+
+
+def _attn_draws(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        d = rng.choice([8, 24, 40, 40, 48, 56, 72, 80])
+        smb = rng.choice([16, 16, 8])
+        T = rng.choice([32, 77, 96, 130, 256, 300, 512])
+        S = rng.choice([19, 32, 77, 160, 237, 512, 640, 1024])
+        out.append((i, rng.choice([1, 2]), rng.choice([1, 2, 4]), T, S, d, smb, rng.choice([0.3, 1.0, 3.0]), rng.random() < 0.25))
+    return out
+
+
+ATTN_DRAWS = _attn_draws(60, 930)
+
+
+@pytest.mark.parametrize("draw", ATTN_DRAWS, ids=[f"attn{d[0]}_T{d[3]}_S{d[4]}_d{d[5]}_p{d[6]}" for d in ATTN_DRAWS])
+def test_random_attention_shapes(cuda, draw):
+    """Register-fed and LDS-staged kernels, table and constant-operand key terms: the same bytes; and those bytes are the integer
+    oracle's within the bound of test_attention_fused."""
+    from qdiff import engine, hip
+    i, B, H, T, S, d, smb, sharp, qpos = draw
+    g = torch.Generator().manual_seed(5000 + i)
+    C = H * d
+    q, k, v = (torch.randn(B, L, C, generator=g) for L in (T, S, S))
+    q = q * sharp
+    if qpos:
+        q = q.abs()
+
+    def mk(t, n_bits=8, always_zero=False):
+        dd, zz = R.uaq_init_scale(t, n_bits, False, False, "max", always_zero)
+        return dict(delta=dd, zero_point=zz, n_bits=n_bits, sym=False)
+    heads = lambda t, L: t.view(B, L, H, d).permute(0, 2, 1, 3).reshape(B * H, L, d)
+    scale = d ** -0.5
+    p = (torch.einsum("bid,bjd->bij", heads(q, T), heads(k, S)) * scale).softmax(-1)
+    aq_q, aq_k, aq_v, aq_w = mk(q), mk(k), mk(v), mk(p, smb, True)
+    ns = lambda a: NS(delta=a["delta"], zero_point=a["zero_point"], n_bits=a["n_bits"], sym=a["sym"])
+    ap = engine.build_attn_plan(ns(aq_q), ns(aq_k), ns(aq_v), ns(aq_w), scale, 1.0, cuda)
+    Tp, Sp, dp = engine.pad32(T), engine.pad32(S), engine.pad32(d)
+    q8 = torch.zeros((B * H, Tp, dp), dtype=torch.int8, device=cuda)
+    k8 = torch.zeros((B * H, Sp, dp), dtype=torch.int8, device=cuda)
+    v8 = torch.zeros((B * H, dp, Sp), dtype=torch.int8, device=cuda)
+    vsum = torch.zeros((B * H, dp), dtype=torch.int32, device=cuda)
+    for which, (t, L, buf) in enumerate(((q, T, q8), (k, S, k8), (v, S, v8))):
+        engine.heads_from_float(ap, which, t.to(cuda), B, L, H, d, (L * C, C, d, 1), buf, vsum)
+    outs = {}
+    try:
+        for mode in (0, 3):
+            for ktab in (1, 0):
+                hip.attn_config(pipe_mode=mode, ktab=ktab, lean=3 if d >= 64 else 1)
+                o = engine.attention_codes(ap, q8, k8, v8, vsum, B, T, S, H, d)
+                torch.cuda.synchronize()
+                outs[(mode, ktab)] = o.clone()
+    finally:
+        hip.attn_config(pipe_mode=2, ktab=1, lean=1)
+    ref = outs[(0, 1)]
+    assert torch.isfinite(ref).all() and ref.abs().max() > 0
+    for key, o in outs.items():
+        assert torch.equal(ref, o), (key, (ref - o).abs().max().item())
+    want, _ = R.attention_int(heads(q, T), heads(k, S), heads(v, S), scale, aq_q, aq_k, aq_v, aq_w, pre_scale=1.0)
+    got = ref.cpu().view(B, T, H, d).permute(0, 2, 1, 3).reshape(B * H, T, d)
+    rng_ = want.abs().max().item()
+    diff = (got.double() - want).abs()
+    assert (diff > 2e-4 * rng_).float().mean().item() <= 1e-2
+    assert diff.max().item() <= 2e-2 * rng_
