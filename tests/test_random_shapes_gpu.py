@@ -163,3 +163,30 @@ def test_random_attention_shapes(cuda, draw):
     diff = (got.double() - want).abs()
     assert (diff > 2e-4 * rng_).float().mean().item() <= 1e-2
     assert diff.max().item() <= 2e-2 * rng_
+
+
+def _heads_draws(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        wbits = rng.choice([4, 4, 4, 8])
+        H = rng.choice([1, 2, 4, 8, 14])
+        d = 4 * rng.randint(2, 48)
+        if wbits == 8 and H * d <= 64:
+            d = 72
+        if H * d > 1344:
+            H = max(1, 1344 // d)
+        out.append((i, 128 * rng.randint(1, 4), H * d, 8 * rng.randint(4, 160), H, wbits))
+    return out
+
+
+HEADS_DRAWS = _heads_draws(40, 61)
+
+
+@pytest.mark.parametrize("draw", HEADS_DRAWS, ids=[f"heads{d[0]}_T{d[1]}_N{d[2]}_K{d[3]}_H{d[4]}_w{d[5]}" for d in HEADS_DRAWS])
+def test_random_head_layout_epilogues(cuda, draw):
+    """q / k / v projections with the attention operand bytes written from the epilogue (single launches and the grouped launch
+    of round 6) against the fp32 projection + qd_quantize_heads, on head counts / head dims / K between the UNets' own."""
+    from test_hip_kernels import _heads_epilogue_case
+    _, T, N, K, H, wbits = draw
+    _heads_epilogue_case(cuda, T, N, K, H, wbits)
