@@ -193,8 +193,8 @@ class EmbGroup:
 
     def _compute(self, emb):
         lins = [l for _, l in self.members]
-        if not torch.is_tensor(emb) or emb.dim() != 2 or not emb.is_floating_point() or len(lins) < 2:
-            return
+        if not torch.is_tensor(emb) or emb.dim() != 2 or not emb.is_floating_point() or len(lins) < 2 or emb.shape[1] % 16:
+            return                                       # (qd_temb_mlp streams 16-byte chunks of K)
         if not _int_mode(*lins) or any(l.split or l.kind != 'linear' or not l.act_quantizer.inited for l in lins):
             return
         plans = [l.conv_plan() for l in lins]
@@ -502,7 +502,8 @@ def time_mlp(lin0, lin1, t_emb, act=F.silu):
     """`Linear -> SiLU -> Linear` on the sinusoid table (reference openaimodel.py:758-759 `time_embed`, ddim
     diffusion.py:318-320): two K6 launches on the integer path, the plain composition otherwise."""
     if (_int_mode(lin0, lin1) and lin0.kind == 'linear' and lin1.kind == 'linear' and not (lin0.split or lin1.split)
-            and lin0.act_quantizer.inited and lin1.act_quantizer.inited and torch.is_tensor(t_emb) and t_emb.dim() == 2):
+            and lin0.act_quantizer.inited and lin1.act_quantizer.inited and torch.is_tensor(t_emb) and t_emb.dim() == 2
+            and t_emb.shape[1] % 16 == 0 and lin1.weight.shape[1] % 16 == 0):
         p0, p1 = lin0.conv_plan(), lin1.conv_plan()
         if len(p0.segs) == 1 and len(p1.segs) == 1:
             h = torch.empty((t_emb.shape[0], p0.Cout), dtype=torch.float32, device=t_emb.device)

@@ -82,10 +82,7 @@ def test_random_conv_shapes(cuda, draw):
     ref = outs[(0, False)]
     assert torch.isfinite(ref).all()
     for key, o in outs.items():
-        if key[1] is False:
-            assert torch.equal(o, ref), key                                     # K-groups: integer adds commute
-        else:
-            assert (o - ref).abs().max().item() <= 1e-6 * ref.abs().max().item(), key     # split-K finalise: one fp32 expression, other association
+        assert torch.equal(o, ref), key          # K-groups: integer adds commute; split-K: int32 partials, the finalise pass runs the epilogue's float sequence
 
     # ... 3. and they are the reference's fake-quantised layer within the fp32 bound of test_conv_fp32_matches_fake_quant
     want = R.quant_module_forward(x, w, bias, "conv2d", dict(stride=stride, padding=k // 2),
@@ -190,3 +187,84 @@ def test_random_head_layout_epilogues(cuda, draw):
     from test_hip_kernels import _heads_epilogue_case
     _, T, N, K, H, wbits = draw
     _heads_epilogue_case(cuda, T, N, K, H, wbits)
+
+
+def _temb_draws(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        w_bits = rng.choice([4, 8])
+        B = rng.choice([1, 2, 3, 4, 5, 7, 8, 13, 16, 20, 33, 64, 100, 130, 257])
+        K = rng.choice([128, 224, 512, 1280, 16 * rng.randint(4, 80)])          # (multiples of 16: the kernel's contract, the engine falls back otherwise)
+        widths = tuple(rng.choice([64, 128, 224, 256, 320, 448, 640, 1280, 8 * rng.randint(4, 100)]) for _ in range(rng.randint(1, 6)))
+        out.append((i, w_bits, B, K, widths))
+    return out
+
+
+TEMB_DRAWS = _temb_draws(30, 17)
+
+
+@pytest.mark.parametrize("draw", TEMB_DRAWS, ids=[f"temb{d[0]}_w{d[1]}_B{d[2]}_K{d[3]}_L{len(d[4])}" for d in TEMB_DRAWS])
+def test_random_temb_mlp_shapes(cuda, draw):
+    """qd_temb_mlp (row groups on grid.y since round 6: how many depends on the layer count and the batch) against the
+    per-layer generic path, on batches / widths / layer counts around the policy's break points."""
+    from test_hip_kernels import test_temb_mlp_equals_generic_path
+    _, w_bits, B, K, widths = draw
+    test_temb_mlp_equals_generic_path(cuda, w_bits, B, K, widths)
+
+
+def _misc_draws(seed):
+    rng = random.Random(seed)
+    splitk, fp16, gnstat, gn, ups = [], [], [], [], []
+    while len(splitk) < 16:
+        k = rng.choice([1, 3])
+        H, W = rng.choice([(1, 1), (1, 77), (4, 4), (8, 8), (7, 9), (16, 16)])
+        B, Cin, N = rng.choice([1, 2, 4, 16]), 32 * rng.randint(4, 60), rng.choice([64, 128, 160, 224, 320, 640, 1280, 8 * rng.randint(4, 80)])
+        bn = 160 if N % 160 == 0 else 224 if N % 224 == 0 else 128 if N > 64 else 64
+        blocks = -(-B * H * W // 128) * -(-N // bn)
+        if blocks <= 64 and k * k * -(-Cin // 64) >= 32:          # the shapes the library contracts in K slices (choose_splitk)
+            splitk.append((f"rand{len(splitk)}", B, Cin, H, W, N, k))
+    for i in range(16):
+        fp16.append((rng.choice([1, 2, 3]), 8 * rng.randint(2, 80), rng.choice([8, 16, 32]), rng.choice([64, 128, 160, 196, 200, 224, 320, 448, 640, 8 * rng.randint(3, 80)]), rng.choice([1, 3])))
+    for i in range(12):
+        H = rng.choice([16, 32])                                  # H * H must be a multiple of 128 rows
+        gnstat.append((rng.choice([1, 2, 3]), 8 * rng.randint(2, 60), H, 32 * rng.randint(1, 20), rng.choice([1, 3])))
+    for i in range(16):
+        gn.append((rng.random() < 0.5, 32 * rng.randint(1, 60), rng.choice([1, 16, 64, 100, 144, 256, 1024])))
+    for i in range(10):
+        ups.append((rng.choice([1, 2, 3]), 8 * rng.randint(2, 80), rng.choice([4, 8, 16]), rng.choice([64, 128, 160, 224, 320, 640, 8 * rng.randint(4, 60)]), rng.choice([4, 4, 8])))
+    return splitk, fp16, gnstat, gn, ups
+
+
+SPLITK_DRAWS, FP16_DRAWS, GNSTAT_DRAWS, GN_DRAWS, UPS_DRAWS = _misc_draws(424242)
+
+
+@pytest.mark.parametrize("case", SPLITK_DRAWS, ids=[f"B{c[1]}_C{c[2]}_{c[3]}x{c[4]}_N{c[5]}_k{c[6]}" for c in SPLITK_DRAWS])
+def test_random_splitk_shapes(cuda, case):
+    """Small M, long K: whatever number of K slices the library picks, not a bit changes against the one-pass schedule."""
+    from test_hip_kernels import test_conv_splitk_is_bit_identical_to_unsplit
+    test_conv_splitk_is_bit_identical_to_unsplit(cuda, case)
+
+
+@pytest.mark.parametrize("shape", FP16_DRAWS, ids=[f"B{c[0]}_C{c[1]}_H{c[2]}_N{c[3]}_k{c[4]}" for c in FP16_DRAWS])
+def test_random_fp16_stream_shapes(cuda, shape):
+    from test_hip_kernels import test_conv_fp16_stream_is_the_rounded_fp32_epilogue
+    test_conv_fp16_stream_is_the_rounded_fp32_epilogue(cuda, shape)
+
+
+@pytest.mark.parametrize("shape", GNSTAT_DRAWS, ids=[f"B{c[0]}_C{c[1]}_H{c[2]}_N{c[3]}_k{c[4]}" for c in GNSTAT_DRAWS])
+def test_random_groupnorm_statistics_from_the_epilogue(cuda, shape):
+    from test_hip_kernels import test_conv_emits_groupnorm_statistics
+    test_conv_emits_groupnorm_statistics(cuda, *shape)
+
+
+@pytest.mark.parametrize("shape", GN_DRAWS, ids=[f"silu{int(c[0])}_C{c[1]}_S{c[2]}" for c in GN_DRAWS])
+def test_random_groupnorm_shapes(cuda, shape):
+    from test_hip_kernels import test_groupnorm_silu_quant
+    test_groupnorm_silu_quant(cuda, *shape)
+
+
+@pytest.mark.parametrize("shape", UPS_DRAWS, ids=[f"B{c[0]}_C{c[1]}_h{c[2]}_N{c[3]}_w{c[4]}" for c in UPS_DRAWS])
+def test_random_upsampling_fold_shapes(cuda, shape):
+    from test_hip_kernels import test_conv_folds_nearest_upsampling
+    test_conv_folds_nearest_upsampling(cuda, *shape)
