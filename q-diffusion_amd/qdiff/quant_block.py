@@ -502,10 +502,9 @@ def time_mlp(lin0, lin1, t_emb, act=F.silu):
     """`Linear -> SiLU -> Linear` on the sinusoid table (reference openaimodel.py:758-759 `time_embed`, ddim
     diffusion.py:318-320): two K6 launches on the integer path, the plain composition otherwise."""
     if (_int_mode(lin0, lin1) and lin0.kind == 'linear' and lin1.kind == 'linear' and not (lin0.split or lin1.split)
-            and lin0.act_quantizer.inited and lin1.act_quantizer.inited and torch.is_tensor(t_emb) and t_emb.dim() == 2
-            and t_emb.shape[1] % 16 == 0 and lin1.weight.shape[1] % 16 == 0):
+            and lin0.act_quantizer.inited and lin1.act_quantizer.inited and torch.is_tensor(t_emb) and t_emb.dim() == 2):
         p0, p1 = lin0.conv_plan(), lin1.conv_plan()
-        if len(p0.segs) == 1 and len(p1.segs) == 1:
+        if len(p0.segs) == 1 and len(p1.segs) == 1 and p0.pack.Cin % 16 == 0 and p1.pack.Cin % 16 == 0:      # (qd_temb_mlp streams 16-byte chunks of K)
             h = torch.empty((t_emb.shape[0], p0.Cout), dtype=torch.float32, device=t_emb.device)
             engine.hip.temb_mlp(t_emb.float(), False, [p0], [0], h)
             out = torch.empty((t_emb.shape[0], p1.Cout), dtype=torch.float32, device=t_emb.device)
