@@ -534,6 +534,9 @@ def layernorm_quant(x_rows, M, C, ln, plans):
     ldo = plans[0].ldx
     if any(p.ldx != ldo or len(p.segs) != 1 for p in plans):
         raise hip.HipEngineError("layernorm consumers must share one row layout")
+    if C % 16 or C > 1536:                                    # outside qd_layernorm_quant's widths: the library's norm, then one quantiser pass per consumer
+        y = torch.nn.functional.layer_norm(x_rows[:, :C].float(), (C,), ln.weight, ln.bias, ln.eps)
+        return [quantize_rows(y, p, 1, C, M, (0, 1, y.stride(0))) for p in plans]
     hip.layernorm_quant(x_rows, M, C, x_rows.stride(0), ln.eps, ln.weight, ln.bias, [p.qparams[0] for p in plans],
                         [p.grids[0] for p in plans], outs, ldo)
     return outs

@@ -268,3 +268,100 @@ def test_random_groupnorm_shapes(cuda, shape):
 def test_random_upsampling_fold_shapes(cuda, shape):
     from test_hip_kernels import test_conv_folds_nearest_upsampling
     test_conv_folds_nearest_upsampling(cuda, *shape)
+
+
+def _geglu_draws(n, seed):
+    rng = random.Random(seed)
+    return [(i, rng.choice([1, 50, 128, 200, 384, 1000]), 32 * rng.randint(1, 40), 8 * rng.randint(4, 160)) for i in range(n)]
+
+
+GEGLU_DRAWS = _geglu_draws(16, 4242)
+
+
+@pytest.mark.parametrize("draw", GEGLU_DRAWS, ids=[f"geglu{d[0]}_M{d[1]}_F{d[2]}_K{d[3]}" for d in GEGLU_DRAWS])
+def test_random_geglu_epilogue_shapes(cuda, draw):
+    """The GEGLU projection with value * gelu(gate) -> the next Linear's act quantiser in its epilogue (engine.conv_forward_geglu,
+    O_GEGLU; reference ldm/modules/attention.py:42-44 + quant_layer.py:248-279) against the unfused route on the same library:
+    fp32 projection, then qd_geglu_quant — the same fma, the same erf polynomial, the same quotient: the same codes — and both
+    against the oracle's GEGLU of the fake-quantised projection (a code apart on <= 0.1 % of elements: exact round() ties)."""
+    from qdiff import engine, hip
+    i, M, Fdim, K = draw
+    g = torch.Generator().manual_seed(7000 + i)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(2 * Fdim, K, generator=g) * 0.05
+    bias = torch.randn(2 * Fdim, generator=g) * 0.1
+    q = _weight_quantizer(w, 4, True, g)
+    dx, zx = R.uaq_init_scale(x, 8, False, False, "max")
+    aq = _aq(dx, zx)
+    want_h = R.quant_module_forward(x, w, bias, "linear", {},
+                                    [dict(delta=q.delta, zero_point=q.zero_point, alpha=q.alpha, n_levels=q.n_levels)],
+                                    [dict(delta=aq.delta, zero_point=zx, n_bits=8, sym=False)])
+    y = R.geglu(want_h)
+    dy, zy = R.uaq_init_scale(y, 8, False, False, "max")
+    nxt_w = torch.randn(64, Fdim, generator=g) * 0.05
+    nxt = engine.build_conv_plan(engine.pack_module_weights(nxt_w.to(cuda), [_weight_quantizer(nxt_w, 4, True, g)], 0), [_aq(dy, zy)], 1, 1, 1, 0, None)
+    plain = engine.build_conv_plan(engine.pack_module_weights(w.to(cuda), [q], 0), [aq], 1, 1, 1, 0, bias.to(cuda))
+    fused = engine.build_conv_plan(engine.pack_module_weights(w.to(cuda), [q], 0, row_perm=engine.geglu_row_perm(Fdim, cuda)), [aq], 1, 1, 1, 0, bias.to(cuda))
+    assert fused.pack.tiled and fused.pack.wbits == 4
+    xq = engine.quantize_rows(x.to(cuda), plain, 1, K, M, (0, 1, K))
+    h = engine.conv_forward(plain, xq, 1, 1, M, 1, M, splitk=False)
+    a = torch.zeros((M, nxt.ldx), dtype=torch.int8, device=cuda)
+    hip.geglu_quant(h, M, Fdim, 2 * Fdim, nxt.qparams[0], nxt.grids[0], a, nxt.ldx)
+    b = engine.conv_forward_geglu(fused, xq, M, nxt)
+    torch.cuda.synchronize()
+    assert torch.equal(a[:, :Fdim], b[:, :Fdim]), (a[:, :Fdim] != b[:, :Fdim]).float().mean().item()
+    want = (R.uaq_codes(y, dy, zy, 8, False) - 128).to(torch.int8)
+    diff = (b[:, :Fdim].cpu().int() - want.int()).abs()
+    assert diff.max().item() <= 1 and (diff > 0).float().mean().item() <= 2e-3
+
+
+def _ln_draws(n, seed):
+    rng = random.Random(seed)
+    return [(i, rng.choice([1, 7, 64, 70, 128, 300, 1024, 4096]), rng.choice([320, 640, 1280, 448, 672, 896, 16 * rng.randint(1, 96)]), rng.randint(1, 3))
+            for i in range(n)]
+
+
+LN_DRAWS = _ln_draws(24, 808)
+
+
+@pytest.mark.parametrize("draw", LN_DRAWS, ids=[f"ln{d[0]}_M{d[1]}_C{d[2]}_n{d[3]}" for d in LN_DRAWS])
+def test_random_layernorm_quant_shapes(cuda, draw):
+    """qd_layernorm_quant (one to three consumers: the q / k / v or GEGLU inputs of a transformer block; every row-count / width
+    form of the kernel) against torch's LayerNorm + the oracle's quantiser: a code apart on <= 0.1 % of elements."""
+    from qdiff import engine, hip
+    from test_hip_kernels import _code_mismatch
+    i, M, C, n = draw
+    g = torch.Generator().manual_seed(9000 + i)
+    x = torch.randn(M, C, generator=g) * 1.7 + 0.2
+    ln = torch.nn.LayerNorm(C)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(C, generator=g))
+        ln.bias.copy_(torch.randn(C, generator=g))
+        y = ln(x)
+    params = [(0.031, 120), (0.02, 133), (0.05, 100)][:n]
+    outs = [torch.empty((M, C), dtype=torch.int8, device=cuda) for _ in params]
+    hip.layernorm_quant(x.to(cuda), M, C, C, ln.eps, ln.weight.data.to(cuda), ln.bias.data.to(cuda),
+                        [torch.tensor([d, float(z)], device=cuda) for d, z in params], [engine.act_grid(8, False)] * n, outs, C)
+    torch.cuda.synchronize()
+    for o, (d, z) in zip(outs, params):
+        mx, frac = _code_mismatch(o.cpu(), R.uaq_codes(y, torch.tensor(d), z, 8, False) - 128)
+        assert mx <= 1 and frac <= 1e-3
+
+
+@pytest.mark.parametrize("C", [856, 1600])
+def test_layernorm_widths_outside_the_kernel_fall_back(cuda, C):
+    """engine.layernorm_quant on a width qd_layernorm_quant does not take (not a multiple of 16 / above 1536): torch's LayerNorm
+    + one quantiser launch per consumer — the same codes as the oracle's quantiser on torch's output."""
+    from qdiff import engine
+    g = torch.Generator().manual_seed(12)
+    M = 40
+    x = torch.randn(M, C, generator=g)
+    ln = torch.nn.LayerNorm(C).to(cuda)
+    w = torch.randn(32, C, generator=g) * 0.05
+    plans = [engine.build_conv_plan(engine.pack_module_weights(w.to(cuda), [_weight_quantizer(w, 4, True, g)], 0), [_aq(d, z)], 1, 1, 1, 0, None)
+             for d, z in ((0.031, 120), (0.02, 133))]
+    outs = engine.layernorm_quant(x.to(cuda), M, C, ln, plans)
+    torch.cuda.synchronize()
+    y = torch.nn.functional.layer_norm(x.to(cuda), (C,), ln.weight, ln.bias, ln.eps).cpu()
+    for o, (d, z) in zip(outs, ((0.031, 120), (0.02, 133))):
+        assert torch.equal(o[:, :C].cpu().int(), (R.uaq_codes(y, torch.tensor(d), z, 8, False) - 128).int())
