@@ -75,7 +75,11 @@ def build(force=False):
     os.makedirs(OBJDIR, exist_ok=True)
     if force:
         for f in os.listdir(OBJDIR):
-            os.remove(os.path.join(OBJDIR, f))
+            path = os.path.join(OBJDIR, f)
+            if os.path.isdir(path):                    # objects of a build_variant()
+                shutil.rmtree(path)
+            else:
+                os.remove(path)
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(_compile, SOURCES))
     if _stale(LIB, objs):
